@@ -1,0 +1,337 @@
+"""Synthetic Qwen3-TTS checkpoint writer.
+
+There are no real checkpoints in this environment, so tests and bench.py use
+random-init checkpoints written in the *reference's* on-disk layout: `config.json` +
+`*.safetensors` in the model dir and `speech_tokenizer/{config.json,*.safetensors}` with the
+upstream (PyTorch-style) key names and tensor layouts that the reference loader sanitises
+(/root/reference/Sources/Qwen3TTS/Models/Qwen3.swift:1382-1495, 1498-1750). The engine's C++
+loader and the oracle's Python loader both consume these files, so the key remaps, conv-weight
+transposes and the codebook = embedding_sum / clip(cluster_usage) step are exercised for real.
+
+Weight statistics follow BASELINE.md section 3: N(0, 0.02^2) matrices, norm weights 1,
+LayerScale 0.01, Snake alpha/beta ~ N(0, 0.1^2), codebooks N(0, 1).
+"""
+from __future__ import annotations
+
+import json
+import os
+import struct
+from typing import Dict, Tuple
+
+import numpy as np
+
+# --------------------------------------------------------------------------------------------
+# minimal safetensors writer (bf16 stored as raw uint16; numpy has no bf16 dtype)
+# --------------------------------------------------------------------------------------------
+
+_DT = {"F32": np.float32, "BF16": np.uint16, "I32": np.int32, "U32": np.uint32, "F16": np.float16}
+
+
+def f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
+    """Round-to-nearest-even fp32 -> bf16 bit patterns (uint16)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16
+    return u.astype(np.uint16)
+
+
+def bf16_bits_to_f32(b: np.ndarray) -> np.ndarray:
+    return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+def save_safetensors(path: str, tensors: Dict[str, Tuple[str, np.ndarray]]) -> None:
+    """tensors: name -> (dtype tag, array). BF16 arrays are uint16 bit patterns."""
+    header = {}
+    off = 0
+    order = sorted(tensors)
+    for k in order:
+        tag, arr = tensors[k]
+        n = arr.size * arr.dtype.itemsize
+        header[k] = {"dtype": tag, "shape": list(arr.shape), "data_offsets": [off, off + n]}
+        off += n
+    hj = json.dumps(header, separators=(",", ":")).encode()
+    hj += b" " * ((8 - len(hj) % 8) % 8)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<Q", len(hj)))
+        f.write(hj)
+        for k in order:
+            f.write(np.ascontiguousarray(tensors[k][1]).tobytes())
+
+
+# --------------------------------------------------------------------------------------------
+# config presets
+# --------------------------------------------------------------------------------------------
+
+def _codec_cfg(tiny: bool) -> dict:
+    if tiny:
+        # channel counts stay > 64 so the reference's conv-layout shape heuristic
+        # (Qwen3.swift:1246-1260) classifies every tensor the way it does for real checkpoints
+        return dict(latent_dim=128, codebook_dim=128, codebook_size=256, decoder_dim=1280,
+                    hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                    num_attention_heads=2, num_key_value_heads=2, head_dim=64, rms_norm_eps=1e-5,
+                    num_quantizers=16, num_semantic_quantizers=1, semantic_codebook_size=2048,
+                    upsample_rates=[8, 5, 4, 3], upsampling_ratios=[2, 2],
+                    layer_scale_initial_scale=0.01)
+    return dict(latent_dim=1024, codebook_dim=512, codebook_size=2048, decoder_dim=1536,
+                hidden_size=512, intermediate_size=1024, num_hidden_layers=8,
+                num_attention_heads=16, num_key_value_heads=16, head_dim=64, rms_norm_eps=1e-5,
+                num_quantizers=16, num_semantic_quantizers=1, semantic_codebook_size=4096,
+                upsample_rates=[8, 5, 4, 3], upsampling_ratios=[2, 2],
+                layer_scale_initial_scale=0.01)
+
+
+def preset(name: str) -> dict:
+    """Returns {"config": <config.json dict>, "speech_tokenizer": <speech_tokenizer/config.json>}.
+
+    tiny-a : talker hidden == code-predictor hidden (no small_to_mtp_projection, like 0.6B)
+    tiny-b : talker hidden != code-predictor hidden (projection present, like 1.7B)
+    0.6b / 1.7b : full dimensions (SURVEY.md section 8 header)
+    """
+    spk = {"aiden": 3010, "vivian": 3011, "eric": 3012}
+    if name in ("tiny-a", "tiny-b"):
+        H = 256 if name == "tiny-a" else 384
+        cp = dict(vocab_size=256, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
+                  num_attention_heads=4, num_key_value_heads=2, head_dim=128, num_code_groups=16,
+                  rms_norm_eps=1e-6, rope_theta=1e6)
+        talker = dict(vocab_size=3072, text_vocab_size=1024, hidden_size=H, text_hidden_size=256,
+                      intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2, head_dim=128, num_code_groups=16, rms_norm_eps=1e-6,
+                      rope_theta=1e6, code_predictor_config=cp, spk_id=spk,
+                      spk_is_dialect={"aiden": False, "vivian": False, "eric": "sichuan_dialect"},
+                      codec_language_id={"chinese": 2055, "english": 2050, "sichuan_dialect": 2062})
+        cfg = dict(model_type="qwen3_tts", tts_model_size="tiny", tts_model_type="custom_voice",
+                   talker_config=talker, im_start_token_id=1000, im_end_token_id=1001,
+                   tts_pad_token_id=1010, tts_bos_token_id=1011, tts_eos_token_id=1012,
+                   sample_rate=24000)
+        return {"config": cfg, "speech_tokenizer": {"decoder_config": _codec_cfg(True)}}
+    if name in ("0.6b", "1.7b"):
+        H, I = (1024, 3072) if name == "0.6b" else (2048, 6144)
+        cp = dict(vocab_size=2048, hidden_size=1024, intermediate_size=3072, num_hidden_layers=5,
+                  num_attention_heads=16, num_key_value_heads=8, head_dim=128, num_code_groups=16,
+                  rms_norm_eps=1e-6, rope_theta=1e6)
+        talker = dict(vocab_size=3072, text_vocab_size=151936, hidden_size=H, text_hidden_size=2048,
+                      intermediate_size=I, num_hidden_layers=28, num_attention_heads=16,
+                      num_key_value_heads=8, head_dim=128, num_code_groups=16, rms_norm_eps=1e-6,
+                      rope_theta=1e6, code_predictor_config=cp, spk_id=spk)
+        cfg = dict(model_type="qwen3_tts", tts_model_size="0b6" if name == "0.6b" else "1b7",
+                   tts_model_type="custom_voice" if name == "0.6b" else "voice_design",
+                   talker_config=talker, sample_rate=24000)
+        if name == "1.7b":
+            talker.pop("spk_id")
+        return {"config": cfg, "speech_tokenizer": {"decoder_config": _codec_cfg(False)}}
+    raise ValueError(f"unknown preset {name}")
+
+
+# --------------------------------------------------------------------------------------------
+# tensor generation
+# --------------------------------------------------------------------------------------------
+
+class _Gen:
+    """Deterministic normal generator. numpy PCG64 for small tensors; torch CPU for big ones
+    (two orders of magnitude faster for the 1.7B checkpoint)."""
+
+    def __init__(self, seed: int, big: bool):
+        self.rng = np.random.Generator(np.random.PCG64(seed))
+        self.big = big
+        self.tgen = None
+        if big:
+            import torch
+            self.torch = torch
+            self.tgen = torch.Generator().manual_seed(seed)
+
+    def normal(self, shape, std: float, mean: float = 0.0) -> np.ndarray:
+        n = int(np.prod(shape))
+        if self.big and n >= (1 << 16):
+            t = self.torch.empty(tuple(shape), dtype=self.torch.float32)
+            t.normal_(mean, std, generator=self.tgen)
+            return t.numpy()
+        return (self.rng.standard_normal(shape, dtype=np.float32) * np.float32(std)
+                + np.float32(mean)).astype(np.float32)
+
+    def uniform(self, shape, lo: float, hi: float) -> np.ndarray:
+        return self.rng.uniform(lo, hi, size=shape).astype(np.float32)
+
+
+def _bf16(x: np.ndarray) -> Tuple[str, np.ndarray]:
+    return ("BF16", f32_to_bf16_bits(x))
+
+
+def _f32(x: np.ndarray) -> Tuple[str, np.ndarray]:
+    return ("F32", np.ascontiguousarray(x, dtype=np.float32))
+
+
+def talker_tensors(cfg: dict, g: _Gen, std: float = 0.02) -> Dict[str, Tuple[str, np.ndarray]]:
+    """Main-model tensors, keys as the reference module tree (Talker.swift:165-171,403-405,439-440,
+    495-496,589-591; CodePredictor.swift:72-78,144-146,165-169,206,283,288)."""
+    t = cfg["talker_config"]
+    cp = t["code_predictor_config"]
+    H, TH, V, TV = t["hidden_size"], t["text_hidden_size"], t["vocab_size"], t["text_vocab_size"]
+    nh, nkv, hd = t["num_attention_heads"], t["num_key_value_heads"], t["head_dim"]
+    out: Dict[str, Tuple[str, np.ndarray]] = {}
+
+    def lin(name, n, k, bias=False):
+        out[name + ".weight"] = _bf16(g.normal((n, k), std))
+        if bias:
+            out[name + ".bias"] = _bf16(g.normal((n,), std))
+
+    def norm(name, d):
+        # norm weights 1 with a small perturbation so a forgotten weight multiply is caught
+        out[name + ".weight"] = _bf16(g.normal((d,), 0.05, 1.0))
+
+    def stack(prefix, hidden, inter_list, n_heads, n_kv, head_dim):
+        for l, inter in enumerate(inter_list):
+            p = f"{prefix}.layers.{l}"
+            lin(p + ".self_attn.q_proj", n_heads * head_dim, hidden)
+            lin(p + ".self_attn.k_proj", n_kv * head_dim, hidden)
+            lin(p + ".self_attn.v_proj", n_kv * head_dim, hidden)
+            lin(p + ".self_attn.o_proj", hidden, n_heads * head_dim)
+            norm(p + ".self_attn.q_norm", head_dim)
+            norm(p + ".self_attn.k_norm", head_dim)
+            lin(p + ".mlp.gate_proj", inter, hidden)
+            lin(p + ".mlp.up_proj", inter, hidden)
+            lin(p + ".mlp.down_proj", hidden, inter)
+            norm(p + ".input_layernorm", hidden)
+            norm(p + ".post_attention_layernorm", hidden)
+        norm(prefix + ".norm", hidden)
+
+    inter = t.get("per_layer_intermediate_sizes") or [t["intermediate_size"]] * t["num_hidden_layers"]
+    out["talker.model.codec_embedding.weight"] = _bf16(g.normal((V, H), std))
+    out["talker.model.text_embedding.weight"] = _bf16(g.normal((TV, TH), std))
+    stack("talker.model", H, inter, nh, nkv, hd)
+    lin("talker.text_projection.linear_fc1", TH, TH, bias=True)
+    lin("talker.text_projection.linear_fc2", H, TH, bias=True)
+    lin("talker.codec_head", V, H)
+    ch = cp["hidden_size"]
+    if ch != H:
+        lin("talker.code_predictor.small_to_mtp_projection", ch, H, bias=True)
+    for i in range(cp["num_code_groups"] - 1):
+        out[f"talker.code_predictor.model.codec_embedding.{i}.weight"] = _bf16(
+            g.normal((cp["vocab_size"], H), std))
+        lin(f"talker.code_predictor.lm_head.{i}", cp["vocab_size"], ch)
+    stack("talker.code_predictor.model", ch, [cp["intermediate_size"]] * cp["num_hidden_layers"],
+          cp["num_attention_heads"], cp["num_key_value_heads"], cp["head_dim"])
+    return out
+
+
+def codec_tensors(dc: dict, g: _Gen, std: float = 0.02) -> Dict[str, Tuple[str, np.ndarray]]:
+    """speech_tokenizer tensors with the upstream key names / PyTorch layouts that
+    sanitizeSpeechTokenizerWeights (Qwen3.swift:1498-1750) expects as input."""
+    out: Dict[str, Tuple[str, np.ndarray]] = {}
+    cd, latent, dd = dc["codebook_dim"], dc["latent_dim"], dc["decoder_dim"]
+    inner = cd // 2
+    hs, isz = dc["hidden_size"], dc["intermediate_size"]
+    nh, hd = dc["num_attention_heads"], dc["head_dim"]
+
+    def codebook(prefix, size):
+        emb = g.normal((size, inner), 1.0)
+        usage = g.uniform((size,), 0.5, 2.0)
+        usage[::7] = 0.0  # exercises the clip(usage, 1e-5) branch (Qwen3.swift:1721)
+        out[prefix + "._codebook.cluster_usage"] = _f32(usage)
+        out[prefix + "._codebook.embedding_sum"] = _f32(emb * np.maximum(usage, 1e-5)[:, None])
+
+    codebook("decoder.quantizer.rvq_first.vq.layers.0", dc["semantic_codebook_size"])
+    for i in range(dc["num_quantizers"] - dc["num_semantic_quantizers"]):
+        codebook(f"decoder.quantizer.rvq_rest.vq.layers.{i}", dc["codebook_size"])
+    for r in ("rvq_first", "rvq_rest"):
+        out[f"decoder.quantizer.{r}.input_proj.weight"] = _f32(g.normal((inner, cd, 1), std))
+        out[f"decoder.quantizer.{r}.output_proj.weight"] = _f32(g.normal((cd, inner, 1), 0.06))
+
+    def conv(prefix, cout, cin_g, k, wstd=std):  # torch Conv1d [out, in/groups, k]
+        out[prefix + ".weight"] = _f32(g.normal((cout, cin_g, k), wstd))
+        out[prefix + ".bias"] = _f32(g.normal((cout,), std))
+
+    def convtr(prefix, cin, cout, k):  # torch ConvTranspose1d [in, out, k]
+        out[prefix + ".weight"] = _f32(g.normal((cin, cout, k), std))
+        out[prefix + ".bias"] = _f32(g.normal((cout,), std))
+
+    def lin(prefix, n, k, bias):
+        out[prefix + ".weight"] = _f32(g.normal((n, k), std))
+        if bias:
+            out[prefix + ".bias"] = _f32(g.normal((n,), std))
+
+    def snake(prefix, c):
+        out[prefix + ".alpha"] = _f32(g.normal((c,), 0.1))
+        out[prefix + ".beta"] = _f32(g.normal((c,), 0.1))
+
+    conv("decoder.pre_conv.conv", latent, cd, 3)
+    pt = "decoder.pre_transformer"
+    lin(pt + ".input_proj", hs, latent, True)
+    lin(pt + ".output_proj", latent, hs, True)
+    for l in range(dc["num_hidden_layers"]):
+        p = f"{pt}.layers.{l}"
+        lin(p + ".self_attn.q_proj", nh * hd, hs, False)
+        lin(p + ".self_attn.k_proj", dc["num_key_value_heads"] * hd, hs, False)
+        lin(p + ".self_attn.v_proj", dc["num_key_value_heads"] * hd, hs, False)
+        lin(p + ".self_attn.o_proj", hs, nh * hd, False)
+        lin(p + ".mlp.gate_proj", isz, hs, False)
+        lin(p + ".mlp.up_proj", isz, hs, False)
+        lin(p + ".mlp.down_proj", hs, isz, False)
+        out[p + ".input_layernorm.weight"] = _f32(g.normal((hs,), 0.05, 1.0))
+        out[p + ".post_attention_layernorm.weight"] = _f32(g.normal((hs,), 0.05, 1.0))
+        # LayerScale 0.01 nominal; perturbed so a dropped multiply shows
+        out[p + ".self_attn_layer_scale.scale"] = _f32(g.normal((hs,), 0.002, dc["layer_scale_initial_scale"]))
+        out[p + ".mlp_layer_scale.scale"] = _f32(g.normal((hs,), 0.002, dc["layer_scale_initial_scale"]))
+    out[pt + ".norm.weight"] = _f32(g.normal((hs,), 0.05, 1.0))
+    for i, r in enumerate(dc["upsampling_ratios"]):
+        convtr(f"decoder.upsample.{i}.0.conv", latent, latent, r)
+        p = f"decoder.upsample.{i}.1"
+        conv(p + ".dwconv.conv", latent, 1, 7, wstd=0.3)
+        out[p + ".norm.weight"] = _f32(g.normal((latent,), 0.05, 1.0))
+        out[p + ".norm.bias"] = _f32(g.normal((latent,), 0.02))
+        lin(p + ".pwconv1", 4 * latent, latent, True)
+        lin(p + ".pwconv2", latent, 4 * latent, True)
+        out[p + ".gamma"] = _f32(g.normal((latent,), 0.02, 0.1))
+    conv("decoder.decoder.0.conv", dd, latent, 7)
+    c = dd
+    for b, rate in enumerate(dc["upsample_rates"]):
+        p = f"decoder.decoder.{b + 1}.block"
+        snake(p + ".0", c)
+        convtr(p + ".1.conv", c, c // 2, 2 * rate)
+        c //= 2
+        for j in (2, 3, 4):
+            snake(f"{p}.{j}.act1", c)
+            conv(f"{p}.{j}.conv1.conv", c, c, 7)
+            snake(f"{p}.{j}.act2", c)
+            conv(f"{p}.{j}.conv2.conv", c, c, 1, wstd=0.05)
+    snake("decoder.decoder.5", c)
+    conv("decoder.decoder.6.conv", 1, c, 7, wstd=0.05)
+    return out
+
+
+def write_checkpoint(model_dir: str, name: str = "tiny-a", seed: int = 1234,
+                     overrides: dict | None = None) -> dict:
+    """Write a synthetic checkpoint for preset `name` into `model_dir`. Returns the preset dict."""
+    p = preset(name)
+    if overrides:
+        for k, v in overrides.items():
+            d = p["config"]
+            parts = k.split(".")
+            for q in parts[:-1]:
+                d = d[q]
+            d[parts[-1]] = v
+    big = name in ("0.6b", "1.7b")
+    g = _Gen(seed, big)
+    os.makedirs(os.path.join(model_dir, "speech_tokenizer"), exist_ok=True)
+    with open(os.path.join(model_dir, "config.json"), "w") as f:
+        json.dump(p["config"], f, indent=1)
+    with open(os.path.join(model_dir, "speech_tokenizer", "config.json"), "w") as f:
+        json.dump(p["speech_tokenizer"], f, indent=1)
+    save_safetensors(os.path.join(model_dir, "model.safetensors"), talker_tensors(p["config"], g))
+    save_safetensors(os.path.join(model_dir, "speech_tokenizer", "model.safetensors"),
+                     codec_tensors(p["speech_tokenizer"]["decoder_config"], g))
+    return p
+
+
+def synthetic_prompt(row: int, n_text: int = 32, n_instruct: int = 0, text_vocab: int = 151643,
+                     im_start: int = 151644, im_end: int = 151645) -> dict:
+    """Fixed-length synthetic token ids shaped like the reference's chat template
+    (Qwen3.swift:274-275, 364-365): '<|im_start|>assistant\\n' + text + '<|im_end|>\\n<|im_start|>assistant\\n'.
+    BASELINE.md section 3: 32 uniform ids, seed 7 + row."""
+    rng = np.random.Generator(np.random.PCG64(7 + row))
+    nl, assistant, user = 198 % text_vocab, 77091 % text_vocab, 872 % text_vocab
+    body = rng.integers(0, text_vocab, size=n_text).astype(np.int32).tolist()
+    text_ids = [im_start, assistant, nl] + body + [im_end, nl, im_start, assistant, nl]
+    out = {"text_ids": text_ids, "target_token_count": n_text}
+    if n_instruct:
+        ib = rng.integers(0, text_vocab, size=n_instruct).astype(np.int32).tolist()
+        out["instruct_ids"] = [im_start, user, nl] + ib + [im_end, nl]
+    return out
