@@ -1,0 +1,215 @@
+/*
+ * q3tts.h -- C ABI of the MI355X-native Qwen3-TTS engine (libq3tts_hip.so).
+ *
+ * The reference (AtomGradient/swift-qwen3-tts) has no FFI boundary of its own: Swift calls the
+ * mlx-swift API directly. This header is the boundary a Swift shim binds
+ * to so that `Qwen3TTSModel` / `.generate` / `.generateStream` keep their signatures while the
+ * MLX/Metal backend is replaced by hand-written HIP. Each entry point cites the reference
+ * interface it replaces (paths relative to /root/reference/Sources/Qwen3TTS/). The Swift-side
+ * binding is shown in INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes, opaque handle, int status codes, no exceptions and no
+ * torch/HIP types across the boundary. Tokenisation stays on the caller's side
+ * (swift-transformers in the reference, Qwen3.swift:274-275): the engine takes token ids.
+ * One q3tts_model per GPU; calls on one handle are serialised by the caller (the reference
+ * model object is not re-entrant either).
+ */
+#ifndef Q3TTS_H
+#define Q3TTS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define Q3TTS_ABI_VERSION 1
+
+typedef struct q3tts_model q3tts_model;
+
+/* Status codes 1..5 map 1:1 to AudioGenerationError (Core/GenerationTypes.swift:63-84). */
+typedef enum {
+    Q3TTS_OK = 0,
+    Q3TTS_ERR_MODEL_NOT_INITIALIZED = 1, /* .modelNotInitialized  "Model not initialized: ..." */
+    Q3TTS_ERR_GENERATION_FAILED = 2,     /* .generationFailed     "Generation failed: ..."     */
+    Q3TTS_ERR_INVALID_INPUT = 3,         /* .invalidInput         "Invalid input: ..."         */
+    Q3TTS_ERR_AUDIO_DECODING_FAILED = 4, /* .audioDecodingFailed                               */
+    Q3TTS_ERR_AUDIO_ENCODING_FAILED = 5, /* .audioEncodingFailed                               */
+    Q3TTS_ERR_IO = 6,     /* checkpoint/config read or parse failure (thrown Foundation errors) */
+    Q3TTS_ERR_DEVICE = 7  /* HIP runtime failure; the engine never falls back to the CPU        */
+} q3tts_status;
+
+typedef struct {
+    int32_t device;     /* HIP device ordinal */
+    int32_t max_batch;  /* rows per q3tts_generate call, 1..64 (reference: always 1) */
+    int32_t max_frames; /* upper bound on codec frames per row; sizes the paged KV pool (default 2048) */
+    int32_t max_prompt; /* upper bound on prompt positions per row (default 512) */
+    int32_t use_graph;  /* 1: replay the per-frame step as a hipGraph (default); 0: eager launches */
+    int32_t weights_from_broadcast; /* 1: allocate the weight arena but do not read tensor data from
+                                       disk; the caller fills it (RCCL broadcast from rank 0) via
+                                       q3tts_model_arena before the first generate */
+} q3tts_load_opts;
+
+void q3tts_default_load_opts(q3tts_load_opts* o);
+
+/* Qwen3TTSModel.fromPretrained(_:) (Models/Qwen3.swift:1382-1452) + postLoadHook (:1455-1495,
+ * minus the text tokenizer, which stays with the caller). */
+q3tts_status q3tts_model_load(const char* model_dir, const q3tts_load_opts* opts, q3tts_model** out);
+void q3tts_model_free(q3tts_model* m);
+
+/* Message of the last failure on this handle (NULL handle: last load failure on this thread).
+ * Texts match the reference's error descriptions (GenerationTypes.swift:70-83). */
+const char* q3tts_last_error(const q3tts_model* m);
+
+/* Device weight arena (one contiguous allocation; layout is a pure function of the config, so
+ * rank 0 can broadcast it to replicas at load: SURVEY.md section 8e). */
+q3tts_status q3tts_model_arena(q3tts_model* m, void** device_ptr, size_t* bytes);
+
+typedef struct {
+    char tts_model_type[32]; /* Qwen3TTSModel.ttsModelType (Qwen3.swift:1269-1271) */
+    int32_t sample_rate;     /* .sampleRate (Qwen3.swift:1262-1264) */
+    int32_t supports_voice_cloning; /* .supportsVoiceCloning (Qwen3.swift:1210-1214) */
+    int32_t has_voice_cloning;      /* .hasVoiceCloning (Qwen3.swift:61-63) */
+    int32_t hidden_size, num_layers, vocab_size, text_vocab_size, num_code_groups;
+    int32_t cp_hidden_size, cp_num_layers, cp_vocab_size;
+    int32_t codec_eos_token_id;
+    int32_t samples_per_frame; /* decodeUpsampleRate, 1920 */
+    int32_t max_batch;
+    int64_t weight_bytes;      /* distinct bytes streamed per decode step (roofline accounting) */
+} q3tts_model_info;
+q3tts_status q3tts_model_get_info(const q3tts_model* m, q3tts_model_info* out);
+
+/* Qwen3TTSModel.supportedSpeakers, sorted (Qwen3.swift:965-971). */
+int32_t q3tts_model_num_speakers(const q3tts_model* m);
+const char* q3tts_model_speaker_name(const q3tts_model* m, int32_t i);
+
+/* One utterance. Mirrors the arguments of generate(text:speaker:instruct:language:...)
+ * (Qwen3.swift:1291-1301) after tokenisation:
+ *   text_ids      = tokens of "<|im_start|>assistant\n{text}<|im_end|>\n<|im_start|>assistant\n" (:274-275)
+ *   instruct_ids  = tokens of "<|im_start|>user\n{instruct}<|im_end|>\n" or NULL (:364-365)
+ *   target_token_count = tokens of {text} alone, for the max-token cap (:822-823) */
+typedef struct {
+    const int32_t* text_ids;
+    int32_t n_text_ids;
+    const int32_t* instruct_ids;
+    int32_t n_instruct_ids;
+    int32_t target_token_count;
+    const char* speaker;  /* NULL = none */
+    const char* language; /* NULL = "auto" */
+    int32_t max_tokens;   /* 0 = 2048 (reference default) */
+} q3tts_request;
+
+/* Defaults as generate(): 0.9 / 50 / 1.0 / 1.05 (Qwen3.swift:1296-1299). */
+typedef struct {
+    float temperature; /* <= 0: greedy argmax (Qwen3.swift:182-185) */
+    int32_t top_k;
+    float top_p;
+    float repetition_penalty;
+    uint64_t seed;        /* new: the reference draws from MLX's global key and has no seed API */
+    int32_t force_frames; /* bench only: mask EOS and emit exactly this many frames per row */
+} q3tts_sampling;
+void q3tts_default_sampling(q3tts_sampling* s);
+
+/* AudioGenerationInfo (Core/GenerationTypes.swift:15-21). */
+typedef struct {
+    int32_t prompt_token_count;
+    int32_t generation_token_count;
+    double prefill_time;
+    double generate_time;
+    double tokens_per_second;
+    double peak_memory_usage; /* GB */
+} q3tts_gen_info;
+
+/* enum AudioGeneration { token, info, audio } (Core/GenerationTypes.swift:51-58). Per request the
+ * order is TOKEN* (EOS is not reported: Qwen3.swift:868-871), INFO, AUDIO -- the order
+ * generateStream yields them (Qwen3+Streaming.swift:24-27,118-120). */
+typedef enum { Q3TTS_EVENT_TOKEN = 0, Q3TTS_EVENT_INFO = 1, Q3TTS_EVENT_AUDIO = 2 } q3tts_event_kind;
+typedef struct {
+    q3tts_event_kind kind;
+    int32_t request_index;
+    int32_t token;              /* TOKEN */
+    const q3tts_gen_info* info; /* INFO  */
+    const float* pcm;           /* AUDIO: valid during the callback */
+    int64_t n_samples;
+} q3tts_event;
+typedef void (*q3tts_event_cb)(void* user, const q3tts_event* ev);
+
+typedef struct {
+    q3tts_status status; /* per-request outcome (e.g. GENERATION_FAILED "No tokens generated") */
+    float* pcm;          /* 24 kHz mono float32, trimmed as Qwen3.swift:954-959; engine-owned */
+    int64_t n_samples;
+    int32_t* codes;      /* [n_frames][num_code_groups]; engine-owned */
+    int32_t n_frames;
+    q3tts_gen_info info;
+} q3tts_result;
+
+/* generate / generateStream (Qwen3.swift:1291-1373, Qwen3+Streaming.swift:8-125) for n_reqs
+ * utterances at once (row-independent: each row equals the batch-1 result for that request).
+ * `cb` may be NULL. `results` has n_reqs entries, released with q3tts_result_free. */
+q3tts_status q3tts_generate(q3tts_model* m, const q3tts_request* reqs, int32_t n_reqs,
+                            const q3tts_sampling* sampling, q3tts_event_cb cb, void* user,
+                            q3tts_result* results);
+void q3tts_result_free(q3tts_result* results, int32_t n);
+
+/* Qwen3TTSSpeechTokenizer.decode (Models/SpeechTokenizer.swift:823-836): codes
+ * [batch][max_frames][num_code_groups] -> pcm [batch][max_frames*1920] (caller-allocated),
+ * audio_lengths[batch] = count(code0 > 0) * 1920. n_frames[b] <= max_frames are the valid rows. */
+q3tts_status q3tts_codec_decode(q3tts_model* m, const int32_t* codes, const int32_t* n_frames,
+                                int32_t batch, int32_t max_frames, float* pcm, int64_t* audio_lengths);
+
+/* Timing of the last q3tts_generate / q3tts_codec_decode on this handle, measured with HIP events
+ * on the engine's own stream (bench.py's roofline object reads these). */
+typedef struct {
+    double prefill_ms;
+    double decode_ms;       /* all frame steps */
+    double codec_ms;
+    int32_t frame_steps;    /* frame-step launches in decode_ms */
+    int32_t rows;
+    int64_t kv_bytes_read;  /* algorithmic KV bytes read over all frame steps */
+} q3tts_timing;
+q3tts_status q3tts_last_timing(const q3tts_model* m, q3tts_timing* out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Test hooks: block-level entry points used by tests/ to compare each stage with the oracle.
+ * Not part of the drop-in surface. All bf16 buffers are raw uint16 bit patterns, host memory.
+ * ------------------------------------------------------------------------------------------- */
+
+/* prepareGenerationInputs (Qwen3.swift:259-409). Outputs (caller-allocated, capacities in rows):
+ * input_embeds [*n_prompt][H], trailing [*n_trailing][H], tts_pad [H]. */
+q3tts_status q3tts_debug_prepare_inputs(q3tts_model* m, const q3tts_request* req,
+                                        uint16_t* input_embeds, int32_t cap_prompt, int32_t* n_prompt,
+                                        uint16_t* trailing, int32_t cap_trailing, int32_t* n_trailing,
+                                        uint16_t* tts_pad);
+
+/* Teacher-forced generation: same kernels as q3tts_generate, but the tokens fed back are
+ * forced_codes [n_reqs][n_frames][groups]; per-frame logits are returned:
+ * talker_logits [n_reqs][n_frames][V], cp_logits [n_reqs][n_frames][groups-1][Vcp] (either may be
+ * NULL). Sampled tokens (what the sampler would have chosen) go to sampled [n_reqs][n_frames][groups]. */
+q3tts_status q3tts_debug_generate_forced(q3tts_model* m, const q3tts_request* reqs, int32_t n_reqs,
+                                         const q3tts_sampling* sampling, const int32_t* forced_codes,
+                                         int32_t n_frames, uint16_t* talker_logits, uint16_t* cp_logits,
+                                         int32_t* sampled);
+
+/* sampleToken (Qwen3.swift:130-213) on caller-supplied logits [rows][V] (bf16) with the engine's
+ * sampler kernel. seen [rows][V] uint8 may be NULL. */
+q3tts_status q3tts_debug_sample(q3tts_model* m, const uint16_t* logits, int32_t rows, int32_t V,
+                                const q3tts_sampling* sampling, const uint8_t* seen,
+                                int32_t suppress_lo, int32_t suppress_hi, int32_t eos_id,
+                                uint32_t row0, uint32_t draw, int32_t* tokens);
+
+/* Skinny bf16 GEMM used by every Linear on the decode path (Talker.swift:183-186,413-415):
+ * y[M][N] = x[M][K] W[N][K]^T (+bias), M <= 64. */
+q3tts_status q3tts_debug_linear(q3tts_model* m, const uint16_t* x, const uint16_t* W, const uint16_t* bias,
+                                int32_t M, int32_t K, int32_t N, uint16_t* y);
+
+/* Codec decoder with intermediate activations (SpeechTokenizer.swift:754-784) for one utterance:
+ * stage names: "quantizer","pre_conv","pre_transformer","upsample0","upsample1","init_conv",
+ * "block0".."block3". Output is channels-last [T][C] float32; *T,*C receive the shape. */
+q3tts_status q3tts_debug_codec_stage(q3tts_model* m, const int32_t* codes, int32_t n_frames,
+                                     const char* stage, float* out, int64_t cap_floats, int32_t* T, int32_t* C);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* Q3TTS_H */

@@ -380,6 +380,30 @@ static inline float q3_logf(float x) {
     return r;
 }
 
+/* exp with the same construction rules (Cephes expf coefficients); used by top-p */
+static inline float q3_expf(float x) {
+    if (x < -87.0f) return 0.0f;
+    if (x > 88.0f) return INFINITY;
+    float fx = floorf(fmaf(x, 1.44269504088896341f, 0.5f));
+    float r = fmaf(fx, -0.693359375f, x);
+    r = fmaf(fx, 2.12194440e-4f, r);
+    float z = r * r;
+    float y = 1.9875691500E-4f;
+    y = fmaf(y, r, 1.3981999507E-3f);
+    y = fmaf(y, r, 8.3334519073E-3f);
+    y = fmaf(y, r, 4.1665795894E-2f);
+    y = fmaf(y, r, 1.6666665459E-1f);
+    y = fmaf(y, r, 5.0000001201E-1f);
+    y = fmaf(y, z, r);
+    y = y + 1.0f;
+    int n = (int)fx;
+    uint32_t sb = (uint32_t)(n + 127) << 23;
+    float sc;
+    memcpy(&sc, &sb, 4);
+    return y * sc;
+}
+O_API float o_expf(float x) { return q3_expf(x); }
+
 /* Gumbel noise for element i of row `row` at draw `draw` (mx.random.categorical =
  * argmax(logits + gumbel), called from Qwen3.swift:124-125). u in (0,1) from 24 random bits. */
 static inline float gumbel_noise(uint64_t seed, uint32_t row, uint32_t draw, uint32_t i) {
@@ -461,7 +485,7 @@ O_API int o_sample_token(const uint16_t* logits, int V, float temperature, int t
         float run = 0.f;
         uint8_t* keep = (uint8_t*)calloc((size_t)V, 1);
         for (int r = 0; r < V; ++r) {
-            run += rbf(expf(l[idx[r]]));
+            run += rbf(q3_expf(l[idx[r]]));
             keep[idx[r]] = (uint8_t)(rbf(run) > thr);
         }
         for (int i = 0; i < V; ++i)

@@ -1,0 +1,218 @@
+// api.cc -- extern "C" surface declared in include/q3tts.h. No exception crosses the boundary:
+// every entry point returns a q3tts_status and records the message for q3tts_last_error().
+#include <cstring>
+
+#include "engine.h"
+
+using q3::Engine;
+
+struct q3tts_model {
+    std::unique_ptr<Engine> eng;
+};
+
+namespace {
+thread_local std::string g_load_error;
+
+template <class F>
+q3tts_status guarded(q3tts_model* m, F&& f) {
+    try {
+        f();
+        return Q3TTS_OK;
+    } catch (const q3::Error& e) {
+        if (m && m->eng) m->eng->last_error = e.what();
+        else g_load_error = e.what();
+        return static_cast<q3tts_status>(e.status);
+    } catch (const std::exception& e) {
+        if (m && m->eng) m->eng->last_error = e.what();
+        else g_load_error = e.what();
+        return Q3TTS_ERR_DEVICE;
+    }
+}
+}  // namespace
+
+extern "C" {
+
+void q3tts_default_load_opts(q3tts_load_opts* o) {
+    std::memset(o, 0, sizeof(*o));
+    o->device = 0;
+    o->max_batch = 1;
+    o->max_frames = 2048;
+    o->max_prompt = 512;
+    o->use_graph = 1;
+    o->weights_from_broadcast = 0;
+}
+
+void q3tts_default_sampling(q3tts_sampling* s) {  // Qwen3.swift:1296-1299
+    s->temperature = 0.9f;
+    s->top_k = 50;
+    s->top_p = 1.0f;
+    s->repetition_penalty = 1.05f;
+    s->seed = 0;
+    s->force_frames = 0;
+}
+
+q3tts_status q3tts_model_load(const char* model_dir, const q3tts_load_opts* opts, q3tts_model** out) {
+    if (out) *out = nullptr;
+    return guarded(nullptr, [&] {
+        Q3_CHECK(model_dir && out, 3, "Invalid input: null argument");
+        q3tts_load_opts o;
+        if (opts) o = *opts;
+        else q3tts_default_load_opts(&o);
+        Q3_CHECK(o.max_batch >= 1 && o.max_batch <= 64, 3, "Invalid input: max_batch must be in 1..64");
+        Q3_CHECK(o.max_frames >= 1 && o.max_prompt >= 16, 3, "Invalid input: max_frames / max_prompt too small");
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        Q3_CHECK(e == hipSuccess && ndev > 0, 7, "no HIP device available: this engine has no CPU fallback");
+        Q3_CHECK(o.device >= 0 && o.device < ndev, 3, "Invalid input: device ordinal out of range");
+        q3::LoadOptions lo;
+        lo.device = o.device;
+        lo.max_pos_talker = o.max_prompt + o.max_frames + 8;
+        lo.skip_tensor_data = o.weights_from_broadcast != 0;
+        auto model = q3::load_model(model_dir, lo);
+        auto h = std::make_unique<q3tts_model>();
+        h->eng = std::make_unique<Engine>(std::move(model), o);
+        *out = h.release();
+    });
+}
+
+void q3tts_model_free(q3tts_model* m) { delete m; }
+
+const char* q3tts_last_error(const q3tts_model* m) {
+    if (m && m->eng) return m->eng->last_error.c_str();
+    return g_load_error.c_str();
+}
+
+q3tts_status q3tts_model_arena(q3tts_model* m, void** device_ptr, size_t* bytes) {
+    return guarded(m, [&] {
+        Q3_CHECK(m && device_ptr && bytes, 3, "Invalid input: null argument");
+        *device_ptr = m->eng->model().arena;
+        *bytes = m->eng->model().arena_bytes;
+    });
+}
+
+q3tts_status q3tts_model_get_info(const q3tts_model* m, q3tts_model_info* out) {
+    return guarded(const_cast<q3tts_model*>(m), [&] {
+        Q3_CHECK(m && out, 3, "Invalid input: null argument");
+        std::memset(out, 0, sizeof(*out));
+        const q3::Model& md = m->eng->model();
+        const q3::ModelConfig& c = md.cfg;
+        std::strncpy(out->tts_model_type, c.tts_model_type.c_str(), sizeof(out->tts_model_type) - 1);
+        out->sample_rate = c.sample_rate;
+        // supportsVoiceCloning needs the codec encoder (Qwen3.swift:1210-1214): not built yet -> 0
+        out->supports_voice_cloning = 0;
+        out->has_voice_cloning = 0;
+        out->hidden_size = c.talker.hidden_size;
+        out->num_layers = c.talker.num_hidden_layers;
+        out->vocab_size = c.talker.vocab_size;
+        out->text_vocab_size = c.talker.text_vocab_size;
+        out->num_code_groups = c.talker.num_code_groups;
+        out->cp_hidden_size = c.talker.cp.hidden_size;
+        out->cp_num_layers = c.talker.cp.num_hidden_layers;
+        out->cp_vocab_size = c.talker.cp.vocab_size;
+        out->codec_eos_token_id = c.talker.codec_eos_token_id;
+        out->samples_per_frame = c.has_codec ? c.codec.total_upsample() : c.decode_upsample_rate;
+        out->max_batch = m->eng->opts().max_batch;
+        out->weight_bytes = md.step_weight_bytes;
+    });
+}
+
+int32_t q3tts_model_num_speakers(const q3tts_model* m) { return m ? int32_t(m->eng->speakers.size()) : 0; }
+const char* q3tts_model_speaker_name(const q3tts_model* m, int32_t i) {
+    if (!m || i < 0 || size_t(i) >= m->eng->speakers.size()) return nullptr;
+    return m->eng->speakers[size_t(i)].c_str();
+}
+
+q3tts_status q3tts_generate(q3tts_model* m, const q3tts_request* reqs, int32_t n_reqs, const q3tts_sampling* sampling,
+                            q3tts_event_cb cb, void* user, q3tts_result* results) {
+    return guarded(m, [&] {
+        Q3_CHECK(m && reqs && results, 3, "Invalid input: null argument");
+        q3tts_sampling sp;
+        if (sampling) sp = *sampling;
+        else q3tts_default_sampling(&sp);
+        std::memset(results, 0, sizeof(q3tts_result) * size_t(n_reqs > 0 ? n_reqs : 0));
+        m->eng->generate(reqs, n_reqs, sp, cb, user, results, nullptr);
+        for (int i = 0; i < n_reqs; ++i)
+            if (results[i].status == Q3TTS_ERR_GENERATION_FAILED)
+                m->eng->last_error = "Generation failed: No tokens generated";  // Qwen3.swift:940
+    });
+}
+
+void q3tts_result_free(q3tts_result* results, int32_t n) {
+    if (!results) return;
+    for (int i = 0; i < n; ++i) {
+        std::free(results[i].pcm);
+        std::free(results[i].codes);
+        results[i].pcm = nullptr;
+        results[i].codes = nullptr;
+    }
+}
+
+q3tts_status q3tts_codec_decode(q3tts_model* m, const int32_t* codes, const int32_t* n_frames, int32_t batch,
+                                int32_t max_frames, float* pcm, int64_t* audio_lengths) {
+    return guarded(m, [&] {
+        Q3_CHECK(m && codes && n_frames && pcm && audio_lengths, 3, "Invalid input: null argument");
+        m->eng->codec_decode(codes, n_frames, batch, max_frames, pcm, audio_lengths);
+    });
+}
+
+q3tts_status q3tts_last_timing(const q3tts_model* m, q3tts_timing* out) {
+    if (!m || !out) return Q3TTS_ERR_INVALID_INPUT;
+    *out = m->eng->timing;
+    return Q3TTS_OK;
+}
+
+q3tts_status q3tts_debug_prepare_inputs(q3tts_model* m, const q3tts_request* req, uint16_t* input_embeds,
+                                        int32_t cap_prompt, int32_t* n_prompt, uint16_t* trailing, int32_t cap_trailing,
+                                        int32_t* n_trailing, uint16_t* tts_pad) {
+    return guarded(m, [&] {
+        Q3_CHECK(m && req && input_embeds && n_prompt && trailing && n_trailing && tts_pad, 3, "Invalid input: null argument");
+        m->eng->debug_prepare_inputs(*req, input_embeds, cap_prompt, n_prompt, trailing, cap_trailing, n_trailing, tts_pad);
+    });
+}
+
+q3tts_status q3tts_debug_generate_forced(q3tts_model* m, const q3tts_request* reqs, int32_t n_reqs,
+                                         const q3tts_sampling* sampling, const int32_t* forced_codes, int32_t n_frames,
+                                         uint16_t* talker_logits, uint16_t* cp_logits, int32_t* sampled) {
+    return guarded(m, [&] {
+        Q3_CHECK(m && reqs && n_frames > 0, 3, "Invalid input: null argument");
+        q3tts_sampling sp;
+        if (sampling) sp = *sampling;
+        else q3tts_default_sampling(&sp);
+        q3::DebugOpts d;
+        d.forced_codes = forced_codes;
+        d.frames = n_frames;
+        d.talker_logits = talker_logits;
+        d.cp_logits = cp_logits;
+        d.sampled = sampled;
+        std::vector<q3tts_result> res((size_t)(n_reqs));
+        m->eng->generate(reqs, n_reqs, sp, nullptr, nullptr, res.data(), &d);
+        q3tts_result_free(res.data(), n_reqs);
+    });
+}
+
+q3tts_status q3tts_debug_sample(q3tts_model* m, const uint16_t* logits, int32_t rows, int32_t V,
+                                const q3tts_sampling* sampling, const uint8_t* seen, int32_t suppress_lo,
+                                int32_t suppress_hi, int32_t eos_id, uint32_t row0, uint32_t draw, int32_t* tokens) {
+    return guarded(m, [&] {
+        Q3_CHECK(m && logits && sampling && tokens, 3, "Invalid input: null argument");
+        m->eng->debug_sample(logits, rows, V, *sampling, seen, suppress_lo, suppress_hi, eos_id, row0, draw, tokens);
+    });
+}
+
+q3tts_status q3tts_debug_linear(q3tts_model* m, const uint16_t* x, const uint16_t* W, const uint16_t* bias, int32_t M,
+                                int32_t K, int32_t N, uint16_t* y) {
+    return guarded(m, [&] {
+        Q3_CHECK(m && x && W && y, 3, "Invalid input: null argument");
+        m->eng->debug_linear(x, W, bias, M, K, N, y);
+    });
+}
+
+q3tts_status q3tts_debug_codec_stage(q3tts_model* m, const int32_t* codes, int32_t n_frames, const char* stage,
+                                     float* out, int64_t cap_floats, int32_t* T, int32_t* C) {
+    return guarded(m, [&] {
+        Q3_CHECK(m && codes && stage && out && T && C && n_frames > 0, 3, "Invalid input: null argument");
+        m->eng->debug_codec_stage(codes, n_frames, stage, out, cap_floats, T, C);
+    });
+}
+
+}  // extern "C"

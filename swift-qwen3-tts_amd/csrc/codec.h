@@ -1,0 +1,35 @@
+// codec.h -- neural codec decoder runner (codes -> 24 kHz PCM) on the HIP kernels in
+// kernels/codec_conv.hip and kernels/codec_misc.hip. Mirrors Qwen3TTSSpeechTokenizerDecoder
+// (/root/reference/Sources/Qwen3TTS/Models/SpeechTokenizer.swift:754-784).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "model.h"
+
+namespace q3 {
+
+class CodecRunner {
+  public:
+    CodecRunner(const Model& m, hipStream_t st);
+    ~CodecRunner();
+    // codes_dev: [B][code_stride_frames][16] int32 on the device; rows decode frames[b] frames.
+    // pcm_dev receives [B][Fmax*upsample] float32 (Fmax = max(frames)); returns Fmax.
+    // If `stage` is non-empty the activation after that stage is copied to stage_out ([B][T][C]).
+    int decode(const int32_t* codes_dev, int code_stride_frames, const std::vector<int>& frames, float** pcm_dev,
+               const std::string& stage = std::string(), std::vector<float>* stage_out = nullptr, int* stage_T = nullptr,
+               int* stage_C = nullptr);
+    int upsample() const { return up_; }
+
+  private:
+    const Model& m_;
+    hipStream_t st_;
+    int up_ = 1920;
+    uint8_t* buf_ = nullptr;
+    size_t buf_bytes_ = 0;
+    int32_t* lens_dev_ = nullptr;
+    int lens_cap_ = 0;
+    void ensure(size_t bytes);
+};
+
+}  // namespace q3

@@ -1,0 +1,779 @@
+// engine.cc -- generation driver. See engine.h.
+#include "engine.h"
+
+#include <algorithm>
+#include <cctype>
+#include <chrono>
+#include <cmath>
+
+#include "codec.h"
+
+namespace q3 {
+
+namespace {
+std::string lower(const std::string& s) {
+    std::string o = s;
+    for (auto& c : o) c = char(std::tolower((unsigned char)c));
+    return o;
+}
+double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+struct Bump {
+    uint8_t* base;
+    size_t off = 0;
+    template <class T>
+    T* take(size_t n) {
+        off = align_up(off, 256);
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+}  // namespace
+
+Engine::Engine(std::unique_ptr<Model> model, const q3tts_load_opts& opts) : m_(std::move(model)), opts_(opts) {
+    Q3_HIP(hipSetDevice(m_->device));
+    Q3_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+    for (auto& e : ev_) Q3_HIP(hipEventCreate(&e));
+    Bm_ = opts.max_batch;
+    Mp_ = int(align_up(size_t(Bm_), 16));
+    Pcap_ = opts.max_prompt;
+    Tcap_ = opts.max_prompt;
+    Fcap_ = opts.max_frames;
+    max_pages_ = ceil_div(Pcap_ + Fcap_ + 1, kPageTokens);
+    n_pages_ = Bm_ * max_pages_;
+    for (auto& kv : m_->cfg.talker.spk_id) speakers.push_back(kv.first);
+    std::sort(speakers.begin(), speakers.end());
+    alloc_workspace();
+    if (m_->has_codec) codec_ = std::make_unique<CodecRunner>(*m_, st_);
+}
+
+Engine::~Engine() {
+    for (auto& g : graphs_) (void)hipGraphExecDestroy(g.second);
+    codec_.reset();
+    if (ws_) (void)hipFree(ws_);
+    for (void* p : {(void*)forced_dev_, (void*)sampled_dev_, (void*)tl_dump_, (void*)cl_dump_})
+        if (p) (void)hipFree(p);
+    for (auto& e : ev_)
+        if (e) (void)hipEventDestroy(e);
+    if (st_) (void)hipStreamDestroy(st_);
+}
+
+void Engine::alloc_workspace() {
+    const TalkerConfig& t = m_->cfg.talker;
+    const int H = t.hidden_size, CH = t.cp.hidden_size, TH = t.text_hidden_size;
+    const int qd = t.num_attention_heads * kHeadDim, kd = t.num_key_value_heads * kHeadDim;
+    const int cqd = t.cp.num_attention_heads * kHeadDim, ckd = t.cp.num_key_value_heads * kHeadDim;
+    const int L = t.num_hidden_layers, CL = t.cp.num_hidden_layers;
+    kv_layer_stride_ = size_t(n_pages_) * t.num_key_value_heads * kPageTokens * kHeadDim;
+    cp_kv_layer_stride_ = size_t(Bm_) * t.cp.num_key_value_heads * kPageTokens * kHeadDim;
+    proj_cap_ = Bm_ * (Pcap_ + 8);
+    for (int pass = 0; pass < 2; ++pass) {
+        Bump b{pass ? ws_ : nullptr};
+        auto stream = [&](Stream& s, int hid, int q, int k, int inter_p, int vocab) {
+            s.ld_qkv = q + 2 * k;
+            s.ld_act = inter_p;
+            s.ld_logits = vocab;
+            s.h = b.take<uint16_t>(size_t(Mp_) * hid);
+            s.xn = b.take<uint16_t>(size_t(Mp_) * hid);
+            s.qkv = b.take<uint16_t>(size_t(Mp_) * s.ld_qkv);
+            s.ao = b.take<uint16_t>(size_t(Mp_) * q);
+            s.act = b.take<uint16_t>(size_t(Mp_) * inter_p);
+            s.hidden = b.take<uint16_t>(size_t(Mp_) * hid);
+            s.logits = b.take<uint16_t>(size_t(Mp_) * vocab);
+        };
+        stream(tk_, H, qd, kd, m_->talker.max_inter_p, t.vocab_size);
+        stream(cp_, CH, cqd, ckd, m_->cp.max_inter_p, t.cp.vocab_size);
+        cp_x_ = b.take<uint16_t>(size_t(Mp_) * H);
+        part_ = b.take<float>(size_t(8) * Mp_ * std::max(H, CH));
+        kpool_ = b.take<uint16_t>(kv_layer_stride_ * L);
+        vpool_ = b.take<uint16_t>(kv_layer_stride_ * L);
+        cp_kpool_ = b.take<uint16_t>(cp_kv_layer_stride_ * CL);
+        cp_vpool_ = b.take<uint16_t>(cp_kv_layer_stride_ * CL);
+        block_table_ = b.take<int32_t>(size_t(Bm_) * max_pages_);
+        cp_block_table_ = b.take<int32_t>(size_t(Bm_));
+        kv_len_ = b.take<int32_t>(size_t(Bm_));
+        cp_len_ = b.take<int32_t>(size_t(Bm_));
+        n_frames_ = b.take<int32_t>(size_t(Bm_));
+        max_frames_ = b.take<int32_t>(size_t(Bm_));
+        trailing_idx_ = b.take<int32_t>(size_t(Bm_));
+        n_trailing_ = b.take<int32_t>(size_t(Bm_));
+        n_prompt_ = b.take<int32_t>(size_t(Bm_));
+        cur_codes_ = b.take<int32_t>(size_t(Bm_) * 16);
+        codes_ = b.take<int32_t>(size_t(Bm_) * Fcap_ * 16);
+        active_ = b.take<uint8_t>(size_t(Bm_));
+        finished_ = b.take<uint8_t>(size_t(Bm_));
+        seen_ = b.take<uint8_t>(size_t(Bm_) * t.vocab_size);
+        prompt_ = b.take<uint16_t>(size_t(Bm_) * Pcap_ * H);
+        trailing_ = b.take<uint16_t>(size_t(Bm_) * Tcap_ * H);
+        tts_pad_ = b.take<uint16_t>(size_t(H));
+        sp_dev_ = b.take<SamplingParams>(1);
+        ids_dev_ = b.take<int32_t>(size_t(proj_cap_));
+        proj_in_ = b.take<uint16_t>(size_t(64) * TH);
+        proj_mid_ = b.take<uint16_t>(size_t(64) * TH);
+        proj_out_ = b.take<uint16_t>(size_t(proj_cap_ + 64) * H);
+        compose_a_ = b.take<int32_t>(size_t(3) * Bm_ * (Pcap_ + Tcap_));
+        compose_b_ = nullptr;
+        if (!pass) {
+            ws_bytes_ = align_up(b.off, 256);
+            Q3_HIP(hipMalloc(reinterpret_cast<void**>(&ws_), ws_bytes_));
+            Q3_HIP(hipMemset(ws_, 0, ws_bytes_));
+        }
+    }
+    std::vector<int32_t> cbt((size_t)(Bm_));  // code-predictor cache: one private page per row
+    for (int i = 0; i < Bm_; ++i) cbt[size_t(i)] = i;
+    Q3_HIP(hipMemcpy(cp_block_table_, cbt.data(), cbt.size() * 4, hipMemcpyHostToDevice));
+}
+
+int Engine::pick_split(int tiles, int chunks) const {
+    // smallest divisor S of `chunks` (<= 8) that gives >= 256 workgroups; else the largest one
+    int best = 1;
+    for (int s = 1; s <= 8; ++s) {
+        if (chunks % s) continue;
+        best = s;
+        if (tiles * s >= 256) break;
+    }
+    return best;
+}
+
+void Engine::gemm(const LinearW& L, const uint16_t* x, int ldx, int M, int epi, uint16_t* y, int ldy, bool silu, int S) {
+    GemmArgs a{};
+    a.W = L.w;
+    a.x = x;
+    a.ldx = ldx;
+    a.M = M;
+    a.Mpad = int(align_up(size_t(M), 16));
+    a.N = (epi == 2) ? L.Np : L.Np;
+    a.K = L.Kp;
+    a.S = S;
+    a.epi = epi;
+    a.y = y;
+    a.ldy = ldy;
+    a.bias = L.bias;
+    a.act_silu = silu ? 1 : 0;
+    a.part = part_;
+    launch_gemm_skinny(a, st_);
+}
+
+void Engine::enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, uint16_t* vpool, size_t layer_stride,
+                            const int32_t* block_table, int max_pages, const int32_t* kv_len, const uint8_t* active,
+                            const uint16_t* final_w, bool need_final) {
+    const int H = s.hidden, Mp = int(align_up(size_t(B), 16));
+    const int qd = s.n_heads * kHeadDim;
+    int prevS = 0;  // splits of the pending down_proj partials
+    for (size_t l = 0; l < s.layers.size(); ++l) {
+        const LayerW& L = s.layers[l];
+        ResidNormArgs n1{};
+        n1.h = w.h; n1.ldh = H; n1.part = prevS ? part_ : nullptr; n1.S = prevS; n1.Mpad = Mp;
+        n1.w = L.ln1; n1.eps = s.eps; n1.xn = w.xn; n1.ldxn = H; n1.M = B; n1.H = H;
+        launch_resid_norm(n1, st_);
+        gemm(L.qkv, w.xn, H, B, 0, w.qkv, w.ld_qkv, false, 1);
+        AttnArgs at{};
+        at.qkv = w.qkv; at.ld = w.ld_qkv; at.qn_w = L.qn; at.kn_w = L.kn; at.eps = s.eps;
+        at.rope_cos = s.rope_cos; at.rope_sin = s.rope_sin;
+        at.kpool = kpool + l * layer_stride; at.vpool = vpool + l * layer_stride;
+        at.block_table = block_table; at.max_pages = max_pages; at.kv_len = kv_len; at.active = active;
+        at.out = w.ao; at.ldo = qd; at.n_heads = s.n_heads; at.n_kv = s.n_kv; at.B = B;
+        at.scale = powf(float(kHeadDim), -0.5f);  // Talker.swift:179
+        launch_attn_decode(at, st_);
+        const int So = pick_split(L.o.Np / 16, L.o.Kp / 128);
+        gemm(L.o, w.ao, qd, B, 1, nullptr, 0, false, So);
+        ResidNormArgs n2 = n1;
+        n2.part = part_; n2.S = So; n2.w = L.ln2;
+        launch_resid_norm(n2, st_);
+        gemm(L.gateup, w.xn, H, B, 2, w.act, w.ld_act, false, 1);
+        const int Sd = pick_split(L.down.Np / 16, L.down.Kp / 128);
+        gemm(L.down, w.act, w.ld_act, B, 1, nullptr, 0, false, Sd);
+        prevS = Sd;
+    }
+    if (need_final) {
+        ResidNormArgs nf{};
+        nf.h = w.h; nf.ldh = H; nf.part = part_; nf.S = prevS; nf.Mpad = Mp;
+        nf.w = final_w; nf.eps = s.eps; nf.xn = w.hidden; nf.ldxn = H; nf.M = B; nf.H = H;
+        launch_resid_norm(nf, st_);
+    }
+}
+
+void Engine::enqueue_talker_step(int B, bool need_hidden) {
+    enqueue_layers(m_->talker, tk_, B, kpool_, vpool_, kv_layer_stride_, block_table_, max_pages_, kv_len_, active_,
+                   m_->talker.final_norm, need_hidden);
+}
+
+void Engine::enqueue_cp_pass(int B, const uint16_t* x, int ldx) {
+    const int CH = m_->cp.hidden;
+    if (m_->has_cp_proj)  // small_to_mtp_projection, CodePredictor.swift:327-330
+        gemm(m_->cp_proj, x, ldx, B, 0, cp_.h, CH, false, 1);
+    else
+        launch_copy_rows(x, ldx, cp_.h, CH, B, CH, st_);
+    enqueue_layers(m_->cp, cp_, B, cp_kpool_, cp_vpool_, cp_kv_layer_stride_, cp_block_table_, 1, cp_len_, nullptr,
+                   m_->cp.final_norm, true);
+}
+
+void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
+    const TalkerConfig& t = m_->cfg.talker;
+    const int H = t.hidden_size, V = t.vocab_size, Vc = t.cp.vocab_size, CH = t.cp.hidden_size;
+    const int groups = t.num_code_groups;
+    enqueue_talker_step(B, true);
+    gemm(m_->codec_head, tk_.hidden, H, B, 0, tk_.logits, tk_.ld_logits, false, 1);
+    SamplerArgs sa{};
+    sa.logits = tk_.logits; sa.ldl = tk_.ld_logits; sa.V = V; sa.sp = sp_dev_; sa.is_talker = 1;
+    sa.suppress_lo = V - 1024; sa.suppress_hi = V; sa.eos_id = t.codec_eos_token_id;  // Qwen3.swift:829-835
+    sa.seen = seen_; sa.cb = 0; sa.n_frames = n_frames_; sa.max_frames = max_frames_;
+    sa.finished = finished_; sa.active = active_; sa.kv_len = kv_len_; sa.advance = 1; sa.advance_gate = active_;
+    sa.cur_codes = cur_codes_; sa.codes = codes_; sa.Fmax = Fcap_;
+    sa.forced = dbg ? forced_dev_ : nullptr; sa.forced_frames = dbg ? dbg->frames : 0;
+    sa.sampled = dbg ? sampled_dev_ : nullptr;
+    sa.emb = m_->codec_emb; sa.emb_ld = H; sa.next_x = cp_x_; sa.ld_next = H; sa.H = H; sa.B = B;
+    sa.logits_dump = (dbg && dbg->talker_logits) ? tl_dump_ : nullptr; sa.dump_ld = V; sa.dump_off = 0;
+    launch_sampler(sa, st_);
+    // code predictor, step 0 = [hidden, embed(code0)] (Qwen3.swift:884-887) run as two positions
+    enqueue_cp_pass(B, tk_.hidden, H);
+    launch_advance_len(cp_len_, nullptr, B, st_);
+    for (int i = 0; i < groups - 1; ++i) {
+        enqueue_cp_pass(B, cp_x_, H);
+        gemm(m_->lm_head[size_t(i)], cp_.hidden, CH, B, 0, cp_.logits, cp_.ld_logits, false, 1);
+        SamplerArgs sc{};
+        sc.logits = cp_.logits; sc.ldl = cp_.ld_logits; sc.V = Vc; sc.sp = sp_dev_; sc.is_talker = 0;
+        sc.eos_id = -1; sc.cb = i + 1; sc.n_frames = n_frames_; sc.max_frames = max_frames_;
+        sc.finished = finished_; sc.active = active_; sc.kv_len = cp_len_; sc.advance = 1; sc.advance_gate = nullptr;
+        sc.cur_codes = cur_codes_; sc.codes = codes_; sc.Fmax = Fcap_;
+        sc.forced = dbg ? forced_dev_ : nullptr; sc.forced_frames = dbg ? dbg->frames : 0;
+        sc.sampled = dbg ? sampled_dev_ : nullptr;
+        if (i + 1 < groups - 1) {  // embedding of this code feeds the next pass (Qwen3.swift:889-892)
+            sc.emb = m_->cp_emb[size_t(i)]; sc.emb_ld = H; sc.next_x = cp_x_; sc.ld_next = H;
+        }
+        sc.H = H; sc.B = B;
+        sc.logits_dump = (dbg && dbg->cp_logits) ? cl_dump_ : nullptr; sc.dump_ld = (groups - 1) * Vc; sc.dump_off = i * Vc;
+        launch_sampler(sc, st_);
+    }
+    FrameEndArgs fe{};
+    fe.cur_codes = cur_codes_; fe.codec_emb = m_->codec_emb; fe.cp_emb = m_->cp_emb_dev;
+    fe.trailing = trailing_; fe.n_trailing = n_trailing_; fe.trailing_idx = trailing_idx_; fe.Tmax = Tcap_;
+    fe.tts_pad = tts_pad_; fe.h = tk_.h; fe.ldh = H; fe.H = H; fe.B = B; fe.groups = groups;
+    fe.n_frames = n_frames_; fe.max_frames = max_frames_; fe.finished = finished_; fe.active = active_; fe.cp_len = cp_len_;
+    launch_frame_end(fe, st_);
+}
+
+hipGraphExec_t Engine::frame_graph(int B) {
+    auto it = graphs_.find(B);
+    if (it != graphs_.end()) return it->second;
+    hipGraph_t g = nullptr;
+    Q3_HIP(hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal));
+    try {
+        enqueue_frame(B, nullptr);
+    } catch (...) {
+        (void)hipStreamEndCapture(st_, &g);
+        if (g) (void)hipGraphDestroy(g);
+        throw;
+    }
+    Q3_HIP(hipStreamEndCapture(st_, &g));
+    hipGraphExec_t ge = nullptr;
+    Q3_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    Q3_HIP(hipGraphDestroy(g));
+    graphs_[B] = ge;
+    return ge;
+}
+
+// ------------------------------------------------------------------------------------------------
+// request resolution: routing and validation of generate() (Qwen3.swift:1291-1373, 803-811, 303-319)
+// ------------------------------------------------------------------------------------------------
+ResolvedRequest Engine::resolve(const q3tts_request& r, const q3tts_sampling& sp) const {
+    const ModelConfig& cfg = m_->cfg;
+    const TalkerConfig& t = cfg.talker;
+    ResolvedRequest o;
+    Q3_CHECK(r.text_ids && r.n_text_ids >= 4, 3, "Invalid input: text_ids must hold the chat-template tokens");
+    o.text_ids.assign(r.text_ids, r.text_ids + r.n_text_ids);
+    const bool have_instruct = r.instruct_ids && r.n_instruct_ids > 0;
+    const std::string type = cfg.tts_model_type;
+    auto speaker_list = [&]() {
+        std::string s;
+        for (size_t i = 0; i < speakers.size(); ++i) s += (i ? ", " : "") + speakers[i];
+        return s;
+    };
+    bool use_speaker = false, use_instruct = false;
+    if (type == "custom_voice" || type == "base") {
+        const char* nm = type == "custom_voice" ? "CustomVoice" : "Base";
+        Q3_CHECK(r.speaker != nullptr, 3,
+                 std::string("Invalid input: ") + nm + " model requires 'speaker' (e.g., 'Vivian', 'Ryan'). Available speakers: " + speaker_list());
+        use_speaker = true;
+        use_instruct = (type == "custom_voice");  // Base ignores instruct (Qwen3.swift:1352)
+    } else {  // voice_design and unknown types (Qwen3.swift:1360-1371)
+        if (type == "voice_design")
+            Q3_CHECK(have_instruct, 3,
+                     "Invalid input: VoiceDesign model requires 'instruct' to describe the voice (e.g., 'A cheerful young female voice with high pitch')");
+        use_instruct = true;
+    }
+    if (use_speaker) {  // Qwen3.swift:803-811
+        Q3_CHECK(t.has_spk_id, 3, "Invalid input: This model does not support CustomVoice. No speakers defined.");
+        auto it = t.spk_id.find(lower(r.speaker));
+        Q3_CHECK(it != t.spk_id.end(), 3,
+                 std::string("Invalid input: Speaker '") + r.speaker + "' not found. Available speakers: " + speaker_list());
+        o.speaker_token = it->second;
+    }
+    if (use_instruct && have_instruct) o.instruct_ids.assign(r.instruct_ids, r.instruct_ids + r.n_instruct_ids);
+    const std::string lang = lower(r.language ? r.language : "auto");
+    if (lang != "auto") {  // Qwen3.swift:304-308 (unknown names silently mean "no language")
+        auto it = t.codec_language_id.find(lang);
+        if (it != t.codec_language_id.end()) o.language_id = it->second;
+    }
+    if ((lang == "chinese" || lang == "auto") && use_speaker) {  // dialect override, Qwen3.swift:311-319
+        auto d = t.spk_dialect.find(lower(r.speaker));
+        if (d != t.spk_dialect.end()) {
+            auto it = t.codec_language_id.find(d->second);
+            if (it != t.codec_language_id.end()) o.language_id = it->second;
+        }
+    }
+    o.target_token_count = r.target_token_count;
+    const int mt = r.max_tokens > 0 ? r.max_tokens : 2048;
+    o.max_frames = sp.force_frames > 0 ? sp.force_frames : std::min(mt, std::max(75, r.target_token_count * 6));  // :822-823
+    for (int id : o.text_ids) Q3_CHECK(id >= 0 && id < t.text_vocab_size, 3, "Invalid input: text token id out of range");
+    for (int id : o.instruct_ids) Q3_CHECK(id >= 0 && id < t.text_vocab_size, 3, "Invalid input: instruct token id out of range");
+    return o;
+}
+
+// ids -> text_projection(embedText(ids)) (Talker.swift:627-633, 475-487), 64 rows per GEMM pass
+void Engine::project_rows(const std::vector<int32_t>& ids, int rows) {
+    const TalkerConfig& t = m_->cfg.talker;
+    const int TH = t.text_hidden_size, H = t.hidden_size;
+    Q3_CHECK(rows <= proj_cap_, 3, "Invalid input: prompt too long for the configured max_prompt");
+    Q3_HIP(hipMemcpyAsync(ids_dev_, ids.data(), size_t(rows) * 4, hipMemcpyHostToDevice, st_));
+    for (int r0 = 0; r0 < rows; r0 += 64) {
+        const int n = std::min(64, rows - r0);
+        launch_gather_rows(m_->text_emb, TH, ids_dev_ + r0, m_->token_map, n, TH, proj_in_, TH, st_);
+        gemm(m_->fc1, proj_in_, TH, n, 0, proj_mid_, TH, true, 1);
+        gemm(m_->fc2, proj_mid_, TH, n, 0, proj_out_ + size_t(r0) * H, H, false, 1);
+    }
+}
+
+void Engine::assemble_prompts(const std::vector<ResolvedRequest>& reqs, std::vector<int>& n_prompt, std::vector<int>& n_trailing) {
+    const ModelConfig& cfg = m_->cfg;
+    const TalkerConfig& t = cfg.talker;
+    const int H = t.hidden_size;
+    const int n = int(reqs.size());
+    std::vector<int32_t> ids;
+    std::vector<int> text_off((size_t)(n)), instr_off((size_t)(n)), tts_off((size_t)(n));
+    for (int b = 0; b < n; ++b) {
+        const auto& r = reqs[size_t(b)];
+        text_off[size_t(b)] = int(ids.size());
+        ids.insert(ids.end(), r.text_ids.begin(), r.text_ids.end());
+        instr_off[size_t(b)] = int(ids.size());
+        ids.insert(ids.end(), r.instruct_ids.begin(), r.instruct_ids.end());
+        tts_off[size_t(b)] = int(ids.size());
+        ids.push_back(cfg.tts_bos_token_id);  // Qwen3.swift:282-292
+        ids.push_back(cfg.tts_eos_token_id);
+        ids.push_back(cfg.tts_pad_token_id);
+    }
+    project_rows(ids, int(ids.size()));
+    std::vector<int32_t> pa, pb, pd, ta, tb, td;  // (proj row, codec id or -1, destination row)
+    n_prompt.assign(size_t(n), 0);
+    n_trailing.assign(size_t(n), 0);
+    for (int b = 0; b < n; ++b) {
+        const auto& r = reqs[size_t(b)];
+        const int bos = tts_off[size_t(b)], eos = bos + 1, pad = bos + 2;
+        std::vector<int> cp_ids;  // codec prefix, Qwen3.swift:322-359
+        if (r.language_id < 0) cp_ids = {t.codec_nothink_id, t.codec_think_bos_id, t.codec_think_eos_id};
+        else cp_ids = {t.codec_think_id, t.codec_think_bos_id, r.language_id, t.codec_think_eos_id};
+        if (r.speaker_token >= 0) cp_ids.push_back(r.speaker_token);
+        cp_ids.push_back(t.codec_pad_id);
+        cp_ids.push_back(t.codec_bos_id);
+        for (int id : cp_ids) Q3_CHECK(id >= 0 && id < t.vocab_size, 3, "Invalid input: codec prefix id out of range");
+        const int nc = int(cp_ids.size());
+        int p = 0;
+        auto push = [&](int a, int c) {
+            pa.push_back(a);
+            pb.push_back(c);
+            pd.push_back(b * Pcap_ + p);
+            ++p;
+        };
+        for (int i = 0; i < int(r.instruct_ids.size()); ++i) push(instr_off[size_t(b)] + i, -1);  // :383-384
+        for (int i = 0; i < 3; ++i) push(text_off[size_t(b)] + i, -1);                            // role, :371
+        for (int i = 0; i < nc - 1; ++i) push(i < nc - 2 ? pad : bos, cp_ids[size_t(i)]);         // :375-379
+        push(text_off[size_t(b)] + 3, cp_ids[size_t(nc - 1)]);                                    // :390
+        Q3_CHECK(p <= Pcap_, 3, "Invalid input: prompt longer than max_prompt");
+        n_prompt[size_t(b)] = p;
+        const int tl = int(r.text_ids.size());
+        int q = 0;
+        auto pusht = [&](int a) {
+            ta.push_back(a);
+            tb.push_back(-1);
+            td.push_back(b * Tcap_ + q);
+            ++q;
+        };
+        if (tl - 5 > 4)  // Qwen3.swift:394-406
+            for (int i = 4; i < tl - 5; ++i) pusht(text_off[size_t(b)] + i);
+        pusht(eos);
+        Q3_CHECK(q <= Tcap_, 3, "Invalid input: text longer than max_prompt");
+        n_trailing[size_t(b)] = q;
+    }
+    auto run = [&](std::vector<int32_t>& a, std::vector<int32_t>& bb, std::vector<int32_t>& d, uint16_t* dst) {
+        const size_t k = a.size();
+        int32_t* da = compose_a_;
+        int32_t* db = compose_a_ + k;
+        int32_t* dd = compose_a_ + 2 * k;
+        Q3_HIP(hipMemcpyAsync(da, a.data(), k * 4, hipMemcpyHostToDevice, st_));
+        Q3_HIP(hipMemcpyAsync(db, bb.data(), k * 4, hipMemcpyHostToDevice, st_));
+        Q3_HIP(hipMemcpyAsync(dd, d.data(), k * 4, hipMemcpyHostToDevice, st_));
+        launch_compose_rows(proj_out_, H, m_->codec_emb, H, da, db, dd, dst, H, int(k), H, st_);
+        Q3_HIP(hipStreamSynchronize(st_));  // host vectors are reused by the next call
+    };
+    run(pa, pb, pd, prompt_);
+    run(ta, tb, td, trailing_);
+    launch_copy_rows(proj_out_ + size_t(tts_off[0] + 2) * H, H, tts_pad_, H, 1, H, st_);
+}
+
+void Engine::debug_prepare_inputs(const q3tts_request& req, uint16_t* input_embeds, int cap_prompt, int* n_prompt,
+                                  uint16_t* trailing, int cap_trailing, int* n_trailing, uint16_t* tts_pad) {
+    q3tts_sampling sp{};
+    q3tts_default_sampling(&sp);
+    std::vector<ResolvedRequest> rr{resolve(req, sp)};
+    std::vector<int> np, nt;
+    assemble_prompts(rr, np, nt);
+    const int H = m_->cfg.talker.hidden_size;
+    Q3_CHECK(np[0] <= cap_prompt && nt[0] <= cap_trailing, 3, "Invalid input: output buffers too small");
+    Q3_HIP(hipStreamSynchronize(st_));
+    Q3_HIP(hipMemcpy(input_embeds, prompt_, size_t(np[0]) * H * 2, hipMemcpyDeviceToHost));
+    Q3_HIP(hipMemcpy(trailing, trailing_, size_t(nt[0]) * H * 2, hipMemcpyDeviceToHost));
+    Q3_HIP(hipMemcpy(tts_pad, tts_pad_, size_t(H) * 2, hipMemcpyDeviceToHost));
+    *n_prompt = np[0];
+    *n_trailing = nt[0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// generate
+// ------------------------------------------------------------------------------------------------
+void Engine::generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3tts_event_cb cb, void* user,
+                      q3tts_result* results, const DebugOpts* dbg) {
+    const TalkerConfig& t = m_->cfg.talker;
+    const int H = t.hidden_size, V = t.vocab_size, Vc = t.cp.vocab_size, groups = t.num_code_groups;
+    Q3_CHECK(n >= 1 && n <= Bm_, 3, "Invalid input: batch size must be between 1 and max_batch");
+    Q3_CHECK(groups == 16, 3, "Invalid input: num_code_groups must be 16");
+    const double t_start = now_s();
+    std::vector<ResolvedRequest> rr;
+    for (int i = 0; i < n; ++i) rr.push_back(resolve(reqs[i], sp));
+    if (dbg)
+        for (auto& r : rr) r.max_frames = dbg->frames;
+    for (auto& r : rr) Q3_CHECK(r.max_frames <= Fcap_, 3, "Invalid input: max_tokens exceeds the configured max_frames");
+    if (m_->has_codec == false)
+        throw Error(1, "Model not initialized: Speech tokenizer not loaded");  // Qwen3.swift:799-801
+
+    std::vector<int> np, nt;
+    assemble_prompts(rr, np, nt);
+    int Pmax = 0;
+    for (int p : np) Pmax = std::max(Pmax, p);
+
+    // ---- per-row state ----
+    std::vector<int32_t> bt((size_t)(n) * max_pages_, 0), zeros((size_t)(n), 0), maxf((size_t)(n)), ntr((size_t)(n)), npr((size_t)(n));
+    int next_page = 0;
+    for (int b = 0; b < n; ++b) {
+        const int need = ceil_div(np[size_t(b)] + rr[size_t(b)].max_frames + 1, kPageTokens);
+        Q3_CHECK(need <= max_pages_ && next_page + need <= n_pages_, 3, "Invalid input: KV pool exhausted");
+        for (int i = 0; i < need; ++i) bt[size_t(b) * max_pages_ + i] = next_page++;
+        maxf[size_t(b)] = rr[size_t(b)].max_frames;
+        ntr[size_t(b)] = nt[size_t(b)];
+        npr[size_t(b)] = np[size_t(b)];
+    }
+    Q3_CHECK(Pmax + *std::max_element(maxf.begin(), maxf.end()) + 1 <= m_->talker.max_pos, 3,
+             "Invalid input: sequence longer than the RoPE table");
+    Q3_HIP(hipMemcpyAsync(block_table_, bt.data(), bt.size() * 4, hipMemcpyHostToDevice, st_));
+    Q3_HIP(hipMemcpyAsync(max_frames_, maxf.data(), size_t(n) * 4, hipMemcpyHostToDevice, st_));
+    Q3_HIP(hipMemcpyAsync(n_trailing_, ntr.data(), size_t(n) * 4, hipMemcpyHostToDevice, st_));
+    Q3_HIP(hipMemcpyAsync(n_prompt_, npr.data(), size_t(n) * 4, hipMemcpyHostToDevice, st_));
+    for (int32_t* p : {kv_len_, cp_len_, n_frames_, trailing_idx_}) Q3_HIP(hipMemsetAsync(p, 0, size_t(n) * 4, st_));
+    Q3_HIP(hipMemsetAsync(active_, 0, size_t(n), st_));
+    Q3_HIP(hipMemsetAsync(finished_, 0, size_t(n), st_));
+    Q3_HIP(hipMemsetAsync(seen_, 0, size_t(n) * V, st_));
+    Q3_HIP(hipMemsetAsync(codes_, 0, size_t(n) * Fcap_ * 16 * 4, st_));
+    SamplingParams sph{sp.temperature, sp.top_k, sp.top_p, sp.repetition_penalty, sp.seed, 0u, sp.force_frames > 0 ? 1 : 0};
+    Q3_HIP(hipMemcpyAsync(sp_dev_, &sph, sizeof(sph), hipMemcpyHostToDevice, st_));
+    int frames_cap = 0;
+    for (int f : maxf) frames_cap = std::max(frames_cap, f);
+    if (dbg) {
+        for (void* p : {(void*)forced_dev_, (void*)sampled_dev_, (void*)tl_dump_, (void*)cl_dump_})
+            if (p) (void)hipFree(p);
+        forced_dev_ = sampled_dev_ = nullptr;
+        tl_dump_ = cl_dump_ = nullptr;
+        const size_t nf = size_t(n) * dbg->frames;
+        if (dbg->forced_codes) {
+            Q3_HIP(hipMalloc(reinterpret_cast<void**>(&forced_dev_), nf * 16 * 4));
+            Q3_HIP(hipMemcpy(forced_dev_, dbg->forced_codes, nf * 16 * 4, hipMemcpyHostToDevice));
+        }
+        Q3_HIP(hipMalloc(reinterpret_cast<void**>(&sampled_dev_), nf * 16 * 4));
+        Q3_HIP(hipMemset(sampled_dev_, 0xff, nf * 16 * 4));
+        if (dbg->talker_logits) Q3_HIP(hipMalloc(reinterpret_cast<void**>(&tl_dump_), nf * V * 2));
+        if (dbg->cp_logits) Q3_HIP(hipMalloc(reinterpret_cast<void**>(&cl_dump_), nf * (groups - 1) * Vc * 2));
+    }
+
+    // ---- prefill: positions 0 .. Pmax-2 of the right-aligned prompts, then load the last one ----
+    Q3_HIP(hipEventRecord(ev_[0], st_));
+    PrefillLoadArgs pl{};
+    pl.prompt = prompt_; pl.n_prompt = n_prompt_; pl.Pmax = Pcap_; pl.H = H; pl.B = n; pl.h = tk_.h; pl.ldh = H; pl.active = active_;
+    // prompt_ rows are laid out with stride Pcap_; right alignment is relative to the longest prompt
+    for (int s = 0; s < Pmax; ++s) {
+        pl.step = s + (Pcap_ - Pmax);
+        launch_prefill_load(pl, st_);
+        if (s + 1 < Pmax) {
+            enqueue_talker_step(n, false);
+            launch_advance_len(kv_len_, active_, n, st_);
+        }
+    }
+    Q3_HIP(hipEventRecord(ev_[1], st_));
+
+    // ---- frame loop ----
+    const bool use_graph = opts_.use_graph && !dbg;
+    hipGraphExec_t ge = use_graph ? frame_graph(n) : nullptr;
+    std::vector<int32_t> h_nframes((size_t)(n), 0), h_codes;
+    std::vector<uint8_t> h_fin((size_t)(n), 0);
+    std::vector<int> reported((size_t)(n), 0);
+    const int poll = 8;
+    int launched = 0;
+    const bool fixed_len = sp.force_frames > 0 || dbg;
+    bool done = false;
+    while (!done && launched < frames_cap) {
+        const int burst = (fixed_len && !cb) ? (frames_cap - launched) : std::min(poll, frames_cap - launched);
+        for (int i = 0; i < burst; ++i) {
+            if (use_graph) Q3_HIP(hipGraphLaunch(ge, st_));
+            else enqueue_frame(n, dbg);
+        }
+        launched += burst;
+        if (fixed_len && !cb) break;
+        Q3_HIP(hipMemcpyAsync(h_nframes.data(), n_frames_, size_t(n) * 4, hipMemcpyDeviceToHost, st_));
+        Q3_HIP(hipMemcpyAsync(h_fin.data(), finished_, size_t(n), hipMemcpyDeviceToHost, st_));
+        Q3_HIP(hipStreamSynchronize(st_));
+        done = true;
+        for (int b = 0; b < n; ++b) done = done && h_fin[size_t(b)];
+        if (cb) {  // .token events in generation order (Qwen3+Streaming.swift:24-27)
+            for (int b = 0; b < n; ++b) {
+                const int nf = h_nframes[size_t(b)];
+                if (nf > reported[size_t(b)]) {
+                    std::vector<int32_t> tmp((size_t)(nf - reported[size_t(b)]) * 16);
+                    Q3_HIP(hipMemcpy(tmp.data(), codes_ + (size_t(b) * Fcap_ + reported[size_t(b)]) * 16, tmp.size() * 4,
+                                     hipMemcpyDeviceToHost));
+                    for (int f = 0; f < nf - reported[size_t(b)]; ++f) {
+                        q3tts_event ev{};
+                        ev.kind = Q3TTS_EVENT_TOKEN;
+                        ev.request_index = b;
+                        ev.token = tmp[size_t(f) * 16];
+                        cb(user, &ev);
+                    }
+                    reported[size_t(b)] = nf;
+                }
+            }
+        }
+    }
+    Q3_HIP(hipEventRecord(ev_[2], st_));
+    Q3_HIP(hipMemcpyAsync(h_nframes.data(), n_frames_, size_t(n) * 4, hipMemcpyDeviceToHost, st_));
+    Q3_HIP(hipStreamSynchronize(st_));
+    if (dbg) {
+        const size_t nf = size_t(n) * dbg->frames;
+        if (dbg->sampled) Q3_HIP(hipMemcpy(dbg->sampled, sampled_dev_, nf * 16 * 4, hipMemcpyDeviceToHost));
+        if (dbg->talker_logits) Q3_HIP(hipMemcpy(dbg->talker_logits, tl_dump_, nf * V * 2, hipMemcpyDeviceToHost));
+        if (dbg->cp_logits) Q3_HIP(hipMemcpy(dbg->cp_logits, cl_dump_, nf * (groups - 1) * Vc * 2, hipMemcpyDeviceToHost));
+    }
+
+    // ---- codec decode (Qwen3.swift:943-961) ----
+    std::vector<int> frames((size_t)(n));
+    int Fmax = 0;
+    for (int b = 0; b < n; ++b) {
+        frames[size_t(b)] = h_nframes[size_t(b)];
+        Fmax = std::max(Fmax, frames[size_t(b)]);
+    }
+    float* pcm_dev = nullptr;
+    const int up = codec_->upsample();
+    if (Fmax > 0) codec_->decode(codes_, Fcap_, frames, &pcm_dev);
+    Q3_HIP(hipEventRecord(ev_[3], st_));
+    Q3_HIP(hipStreamSynchronize(st_));
+    float ms = 0;
+    Q3_HIP(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
+    timing.prefill_ms = ms;
+    Q3_HIP(hipEventElapsedTime(&ms, ev_[1], ev_[2]));
+    timing.decode_ms = ms;
+    Q3_HIP(hipEventElapsedTime(&ms, ev_[2], ev_[3]));
+    timing.codec_ms = ms;
+    timing.frame_steps = launched;
+    timing.rows = n;
+    {
+        int64_t kvb = 0;
+        const int64_t per_tok = int64_t(t.num_hidden_layers) * t.num_key_value_heads * kHeadDim * 2 * 2;
+        for (int b = 0; b < n; ++b)
+            for (int f = 0; f < frames[size_t(b)]; ++f) kvb += int64_t(np[size_t(b)] - 1 + f) * per_tok;
+        timing.kv_bytes_read = kvb;
+    }
+    const double total = now_s() - t_start;
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    for (int b = 0; b < n; ++b) {
+        q3tts_result& r = results[b];
+        std::memset(&r, 0, sizeof(r));
+        const int F = frames[size_t(b)];
+        r.info.prompt_token_count = rr[size_t(b)].target_token_count;  // tokens of `text` (Qwen3+Streaming.swift:106)
+        r.info.generation_token_count = F;
+        r.info.prefill_time = 0;  // hard-coded in the reference (Qwen3+Streaming.swift:112)
+        r.info.generate_time = total;
+        r.info.tokens_per_second = total > 0 ? double(F) / total : 0;
+        r.info.peak_memory_usage = double(total_b - free_b) / 1e9;
+        if (F == 0) {  // Qwen3.swift:939-941
+            r.status = Q3TTS_ERR_GENERATION_FAILED;
+            continue;
+        }
+        r.n_frames = F;
+        r.codes = static_cast<int32_t*>(std::malloc(size_t(F) * 16 * 4));
+        Q3_HIP(hipMemcpy(r.codes, codes_ + size_t(b) * Fcap_ * 16, size_t(F) * 16 * 4, hipMemcpyDeviceToHost));
+        // audioLengths = count(code0 > 0) * 1920, trim when 0 < valid < len (SpeechTokenizer.swift:831-833, Qwen3.swift:954-959)
+        int valid_tok = 0;
+        for (int f = 0; f < F; ++f) valid_tok += r.codes[size_t(f) * 16] > 0 ? 1 : 0;
+        int64_t ns = int64_t(F) * up;
+        const int64_t valid = int64_t(valid_tok) * up;
+        if (valid > 0 && valid < ns) ns = valid;
+        r.n_samples = ns;
+        r.pcm = static_cast<float*>(std::malloc(size_t(ns) * 4));
+        Q3_HIP(hipMemcpy(r.pcm, pcm_dev + size_t(b) * Fmax * up, size_t(ns) * 4, hipMemcpyDeviceToHost));
+        r.status = Q3TTS_OK;
+    }
+    if (cb) {
+        for (int b = 0; b < n; ++b) {
+            if (results[b].status != Q3TTS_OK) continue;
+            q3tts_event ev{};
+            ev.kind = Q3TTS_EVENT_INFO;
+            ev.request_index = b;
+            ev.info = &results[b].info;
+            cb(user, &ev);
+            ev.kind = Q3TTS_EVENT_AUDIO;
+            ev.info = nullptr;
+            ev.pcm = results[b].pcm;
+            ev.n_samples = results[b].n_samples;
+            cb(user, &ev);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// block-level hooks
+// ------------------------------------------------------------------------------------------------
+void Engine::debug_sample(const uint16_t* logits, int rows, int V, const q3tts_sampling& sp, const uint8_t* seen,
+                          int suppress_lo, int suppress_hi, int eos_id, uint32_t row0, uint32_t draw, int32_t* tokens) {
+    Q3_CHECK(rows >= 1 && rows <= Bm_ && V <= m_->cfg.talker.vocab_size, 3, "debug_sample: rows/V out of range");
+    Q3_CHECK(draw % 16 == 0, 3, "debug_sample: draw must be a multiple of 16 (frame * 16)");
+    const int Vt = m_->cfg.talker.vocab_size;
+    Q3_HIP(hipMemcpy2D(tk_.logits, size_t(Vt) * 2, logits, size_t(V) * 2, size_t(V) * 2, size_t(rows), hipMemcpyHostToDevice));
+    if (seen) Q3_HIP(hipMemcpy(seen_, seen, size_t(rows) * V, hipMemcpyHostToDevice));
+    std::vector<int32_t> fr((size_t)(rows), int32_t(draw / 16)), big((size_t)(rows), 1 << 30);
+    Q3_HIP(hipMemcpy(n_frames_, fr.data(), size_t(rows) * 4, hipMemcpyHostToDevice));
+    Q3_HIP(hipMemcpy(max_frames_, big.data(), size_t(rows) * 4, hipMemcpyHostToDevice));
+    Q3_HIP(hipMemset(finished_, 0, size_t(rows)));
+    Q3_HIP(hipMemset(active_, 1, size_t(rows)));
+    SamplingParams sph{sp.temperature, sp.top_k, sp.top_p, sp.repetition_penalty, sp.seed, row0, sp.force_frames > 0 ? 1 : 0};
+    Q3_HIP(hipMemcpy(sp_dev_, &sph, sizeof(sph), hipMemcpyHostToDevice));
+    SamplerArgs sa{};
+    sa.logits = tk_.logits; sa.ldl = Vt; sa.V = V; sa.sp = sp_dev_;
+    sa.is_talker = (eos_id >= 0 || suppress_hi > suppress_lo || seen) ? 1 : 0;
+    sa.suppress_lo = suppress_lo; sa.suppress_hi = suppress_hi; sa.eos_id = eos_id;
+    sa.seen = seen ? seen_ : nullptr; sa.cb = 0; sa.n_frames = n_frames_; sa.max_frames = max_frames_;
+    sa.finished = finished_; sa.active = active_; sa.kv_len = kv_len_; sa.advance = 0;
+    sa.cur_codes = cur_codes_; sa.codes = codes_; sa.Fmax = 0; sa.B = rows; sa.H = m_->cfg.talker.hidden_size;
+    launch_sampler(sa, st_);
+    Q3_HIP(hipStreamSynchronize(st_));
+    std::vector<int32_t> cc((size_t)(rows) * 16);
+    Q3_HIP(hipMemcpy(cc.data(), cur_codes_, cc.size() * 4, hipMemcpyDeviceToHost));
+    for (int r = 0; r < rows; ++r) tokens[r] = cc[size_t(r) * 16];
+    Q3_HIP(hipMemset(seen_, 0, size_t(rows) * V));
+}
+
+void Engine::debug_linear(const uint16_t* x, const uint16_t* W, const uint16_t* bias, int M, int K, int N, uint16_t* y) {
+    Q3_CHECK(M >= 1 && M <= 64 && K % 8 == 0 && N >= 1, 3, "debug_linear: unsupported shape");
+    const int Kp = int(align_up(size_t(K), 128)), Np = int(align_up(size_t(N), 16)), Mp = int(align_up(size_t(M), 16));
+    uint16_t *dW = nullptr, *dWt = nullptr, *dx = nullptr, *dy = nullptr, *db = nullptr;
+    float* dpart = nullptr;
+    Q3_HIP(hipMalloc(reinterpret_cast<void**>(&dW), size_t(N) * K * 2));
+    Q3_HIP(hipMalloc(reinterpret_cast<void**>(&dWt), size_t(Np) * Kp * 2));
+    Q3_HIP(hipMalloc(reinterpret_cast<void**>(&dx), size_t(Mp) * Kp * 2));
+    Q3_HIP(hipMalloc(reinterpret_cast<void**>(&dy), size_t(Mp) * Np * 2));
+    Q3_HIP(hipMalloc(reinterpret_cast<void**>(&db), size_t(Np) * 2));
+    Q3_HIP(hipMemset(dWt, 0, size_t(Np) * Kp * 2));
+    Q3_HIP(hipMemset(dx, 0, size_t(Mp) * Kp * 2));
+    Q3_HIP(hipMemset(db, 0, size_t(Np) * 2));
+    Q3_HIP(hipMemcpy(dW, W, size_t(N) * K * 2, hipMemcpyHostToDevice));
+    Q3_HIP(hipMemcpy2D(dx, size_t(Kp) * 2, x, size_t(K) * 2, size_t(K) * 2, size_t(M), hipMemcpyHostToDevice));
+    if (bias) Q3_HIP(hipMemcpy(db, bias, size_t(N) * 2, hipMemcpyHostToDevice));
+    launch_tile_weights(dW, N, K, dWt, Kp / 128, 0, 1, st_);
+    LinearW L;
+    L.w = dWt; L.bias = bias ? db : nullptr; L.N = N; L.K = K; L.Np = Np; L.Kp = Kp;
+    // exercise both code paths: direct bf16 epilogue when it fills the chip, split-K + resid_norm fold otherwise
+    const int S = pick_split(Np / 16, Kp / 128);
+    if (S == 1 || bias) {
+        gemm(L, dx, Kp, M, 0, dy, Np, false, 1);
+    } else {
+        Q3_HIP(hipMalloc(reinterpret_cast<void**>(&dpart), size_t(S) * Mp * Np * 4));
+        Q3_HIP(hipMemsetAsync(dy, 0, size_t(Mp) * Np * 2, st_));  // residual stream = 0, so h <- bf16(0 + bf16(sum))
+        GemmArgs a{};
+        a.W = dWt; a.x = dx; a.ldx = Kp; a.M = M; a.Mpad = Mp; a.N = Np; a.K = Kp; a.S = S; a.epi = 1; a.part = dpart;
+        launch_gemm_skinny(a, st_);
+        ResidNormArgs rn{};
+        rn.h = dy; rn.ldh = Np; rn.part = dpart; rn.S = S; rn.Mpad = Mp; rn.w = nullptr; rn.M = M; rn.H = Np;
+        launch_resid_norm(rn, st_);
+    }
+    Q3_HIP(hipStreamSynchronize(st_));
+    Q3_HIP(hipMemcpy2D(y, size_t(N) * 2, dy, size_t(Np) * 2, size_t(N) * 2, size_t(M), hipMemcpyDeviceToHost));
+    for (void* p : {(void*)dW, (void*)dWt, (void*)dx, (void*)dy, (void*)db, (void*)dpart})
+        if (p) (void)hipFree(p);
+}
+
+void Engine::codec_decode(const int32_t* codes, const int32_t* n_frames, int batch, int max_frames, float* pcm,
+                          int64_t* audio_lengths) {
+    Q3_CHECK(m_->has_codec, 1, "Model not initialized: Speech tokenizer not loaded");
+    Q3_CHECK(batch >= 1 && max_frames >= 1, 3, "Invalid input: empty codec batch");
+    const int up = codec_->upsample();
+    int32_t* dcodes = nullptr;
+    Q3_HIP(hipMalloc(reinterpret_cast<void**>(&dcodes), size_t(batch) * max_frames * 16 * 4));
+    Q3_HIP(hipMemcpy(dcodes, codes, size_t(batch) * max_frames * 16 * 4, hipMemcpyHostToDevice));
+    std::vector<int> frames((size_t)(batch));
+    int Fmax = 0;
+    for (int b = 0; b < batch; ++b) {
+        Q3_CHECK(n_frames[b] >= 0 && n_frames[b] <= max_frames, 3, "Invalid input: n_frames out of range");
+        frames[size_t(b)] = n_frames[b];
+        Fmax = std::max(Fmax, n_frames[b]);
+    }
+    float* pcm_dev = nullptr;
+    Q3_HIP(hipEventRecord(ev_[2], st_));
+    try {
+        if (Fmax > 0) codec_->decode(dcodes, max_frames, frames, &pcm_dev);
+    } catch (...) {
+        (void)hipFree(dcodes);
+        throw;
+    }
+    Q3_HIP(hipEventRecord(ev_[3], st_));
+    Q3_HIP(hipStreamSynchronize(st_));
+    float ms = 0;
+    Q3_HIP(hipEventElapsedTime(&ms, ev_[2], ev_[3]));
+    timing.codec_ms = ms;
+    for (int b = 0; b < batch; ++b) {
+        const int F = frames[size_t(b)];
+        if (F > 0)
+            Q3_HIP(hipMemcpy(pcm + size_t(b) * max_frames * up, pcm_dev + size_t(b) * Fmax * up, size_t(F) * up * 4,
+                             hipMemcpyDeviceToHost));
+        int valid = 0;
+        for (int f = 0; f < F; ++f) valid += codes[(size_t(b) * max_frames + f) * 16] > 0 ? 1 : 0;
+        audio_lengths[b] = int64_t(valid) * up;  // SpeechTokenizer.swift:831-833
+    }
+    (void)hipFree(dcodes);
+}
+
+void Engine::debug_codec_stage(const int32_t* codes, int n_frames, const char* stage, float* out, int64_t cap, int* T, int* C) {
+    Q3_CHECK(m_->has_codec, 1, "Model not initialized: Speech tokenizer not loaded");
+    int32_t* dcodes = nullptr;
+    Q3_HIP(hipMalloc(reinterpret_cast<void**>(&dcodes), size_t(n_frames) * 16 * 4));
+    Q3_HIP(hipMemcpy(dcodes, codes, size_t(n_frames) * 16 * 4, hipMemcpyHostToDevice));
+    std::vector<float> so;
+    float* pcm_dev = nullptr;
+    try {
+        codec_->decode(dcodes, n_frames, {n_frames}, &pcm_dev, stage, &so, T, C);
+    } catch (...) {
+        (void)hipFree(dcodes);
+        throw;
+    }
+    (void)hipFree(dcodes);
+    Q3_CHECK(int64_t(so.size()) <= cap, 3, "debug_codec_stage: output buffer too small");
+    std::memcpy(out, so.data(), so.size() * 4);
+}
+
+}  // namespace q3

@@ -1,0 +1,113 @@
+// engine.h -- host-side generation driver on top of the HIP kernels.
+//
+// Mirrors the reference's generation driver (/root/reference/Sources/Qwen3TTS/Models/Qwen3.swift:
+// prompt assembly :259-409, AR loop :847-936 / :640-729, routing :1291-1373, decode + trim
+// :943-961) with batching added: rows are independent sequences with their own KV pages,
+// repetition sets and RNG streams.
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/q3tts.h"
+#include "kernels.h"
+#include "model.h"
+
+namespace q3 {
+
+struct DebugOpts {
+    const int32_t* forced_codes = nullptr;  // host [n][frames][16]
+    int frames = 0;
+    uint16_t* talker_logits = nullptr;  // host [n][frames][V]
+    uint16_t* cp_logits = nullptr;      // host [n][frames][groups-1][Vcp]
+    int32_t* sampled = nullptr;         // host [n][frames][16]
+};
+
+struct ResolvedRequest {
+    std::vector<int32_t> text_ids, instruct_ids;
+    int speaker_token = -1;  // row of the codec embedding table, -1: none
+    int language_id = -1;    // -1: none ("auto" without dialect)
+    int max_frames = 0;
+    int target_token_count = 0;
+};
+
+class CodecRunner;
+
+class Engine {
+  public:
+    Engine(std::unique_ptr<Model> model, const q3tts_load_opts& opts);
+    ~Engine();
+
+    Model& model() { return *m_; }
+    const q3tts_load_opts& opts() const { return opts_; }
+    std::string last_error;
+    q3tts_timing timing{};
+
+    void generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3tts_event_cb cb, void* user,
+                  q3tts_result* results, const DebugOpts* dbg);
+    void debug_prepare_inputs(const q3tts_request& req, uint16_t* input_embeds, int cap_prompt, int* n_prompt,
+                              uint16_t* trailing, int cap_trailing, int* n_trailing, uint16_t* tts_pad);
+    void debug_sample(const uint16_t* logits, int rows, int V, const q3tts_sampling& sp, const uint8_t* seen,
+                      int suppress_lo, int suppress_hi, int eos_id, uint32_t row0, uint32_t draw, int32_t* tokens);
+    void debug_linear(const uint16_t* x, const uint16_t* W, const uint16_t* bias, int M, int K, int N, uint16_t* y);
+    void codec_decode(const int32_t* codes, const int32_t* n_frames, int batch, int max_frames, float* pcm,
+                      int64_t* audio_lengths);
+    void debug_codec_stage(const int32_t* codes, int n_frames, const char* stage, float* out, int64_t cap, int* T, int* C);
+
+    std::vector<std::string> speakers;  // sorted (Qwen3.swift:965-971)
+
+  private:
+    std::unique_ptr<Model> m_;
+    q3tts_load_opts opts_;
+    hipStream_t st_ = nullptr;
+    hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
+    int Bm_ = 0, Mp_ = 0;  // max batch, padded to 16
+    int Pcap_ = 0, Tcap_ = 0, Fcap_ = 0, max_pages_ = 0, n_pages_ = 0;
+
+    // device workspace (one allocation)
+    uint8_t* ws_ = nullptr;
+    size_t ws_bytes_ = 0;
+    struct Stream {  // activation buffers of one decoder stack
+        uint16_t *h, *xn, *qkv, *ao, *act, *hidden, *logits;
+        int ld_qkv, ld_act, ld_logits;
+    } tk_{}, cp_{};
+    uint16_t* cp_x_ = nullptr;  // [Mp][H] code-predictor input before the projection
+    float* part_ = nullptr;
+    uint16_t *kpool_ = nullptr, *vpool_ = nullptr, *cp_kpool_ = nullptr, *cp_vpool_ = nullptr;
+    size_t kv_layer_stride_ = 0, cp_kv_layer_stride_ = 0;
+    int32_t *block_table_ = nullptr, *cp_block_table_ = nullptr;
+    int32_t *kv_len_ = nullptr, *cp_len_ = nullptr, *n_frames_ = nullptr, *max_frames_ = nullptr;
+    int32_t *trailing_idx_ = nullptr, *n_trailing_ = nullptr, *n_prompt_ = nullptr, *cur_codes_ = nullptr, *codes_ = nullptr;
+    uint8_t *active_ = nullptr, *finished_ = nullptr, *seen_ = nullptr;
+    uint16_t *prompt_ = nullptr, *trailing_ = nullptr, *tts_pad_ = nullptr;
+    SamplingParams* sp_dev_ = nullptr;
+    // prompt-assembly scratch
+    int32_t* ids_dev_ = nullptr;
+    uint16_t *proj_in_ = nullptr, *proj_mid_ = nullptr, *proj_out_ = nullptr;
+    int proj_cap_ = 0;
+    int32_t *compose_a_ = nullptr, *compose_b_ = nullptr;
+    // debug buffers (allocated on demand)
+    int32_t *forced_dev_ = nullptr, *sampled_dev_ = nullptr;
+    uint16_t *tl_dump_ = nullptr, *cl_dump_ = nullptr;
+
+    std::map<int, hipGraphExec_t> graphs_;  // keyed by batch size
+    std::unique_ptr<CodecRunner> codec_;
+
+    void alloc_workspace();
+    ResolvedRequest resolve(const q3tts_request& r, const q3tts_sampling& sp) const;
+    // builds prompt_/trailing_/tts_pad_ for rows [0,n); fills host-side lengths
+    void assemble_prompts(const std::vector<ResolvedRequest>& reqs, std::vector<int>& n_prompt, std::vector<int>& n_trailing);
+    void project_rows(const std::vector<int32_t>& ids, int rows);  // ids -> proj_out_[rows][H]
+    void enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, uint16_t* vpool, size_t layer_stride,
+                        const int32_t* block_table, int max_pages, const int32_t* kv_len, const uint8_t* active,
+                        const uint16_t* final_w, bool need_final);
+    void enqueue_talker_step(int B, bool need_hidden);
+    void enqueue_cp_pass(int B, const uint16_t* x, int ldx);
+    void enqueue_frame(int B, const DebugOpts* dbg);
+    hipGraphExec_t frame_graph(int B);
+    int pick_split(int tiles, int chunks) const;
+    void gemm(const LinearW& L, const uint16_t* x, int ldx, int M, int epi, uint16_t* y, int ldy, bool silu, int S);
+};
+
+}  // namespace q3

@@ -1,0 +1,155 @@
+// kernels.h -- host-callable launchers of the HIP kernels (definitions in kernels/*.hip).
+// Every launcher only enqueues work on `st` (no allocation, no sync), so the whole frame step can
+// be captured into a hipGraph (cdna_hip_programming.md Guideline 9).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace q3 {
+
+constexpr int kPageTokens = 64;  // tokens per KV page
+constexpr int kHeadDim = 128;    // Qwen3-TTS talker / code predictor head_dim (Config.swift:154,301)
+
+// ---- skinny GEMM (gemm_decode.hip) -------------------------------------------------------------
+struct GemmArgs {
+    const uint16_t* W;  // tiled weights (weights.cc: tile_weights)
+    const uint16_t* x;  // [Mpad][ldx] bf16, rows >= M are zero/ignored
+    int ldx;
+    int M, Mpad, N, K;  // N, K are the padded (tiled) sizes
+    int S;              // K splits across workgroups (epi 1 only when > 1)
+    int epi;            // 0: y=bf16(acc+bias) (+silu)   1: fp32 partial slab   2: gate/up -> silu(g)*u
+    uint16_t* y;
+    int ldy;
+    const uint16_t* bias;
+    int act_silu;
+    float* part;        // [S][Mpad][N]
+};
+void launch_gemm_skinny(const GemmArgs& a, hipStream_t st);
+
+// ---- residual add + RMSNorm (lm_misc.hip) ------------------------------------------------------
+struct ResidNormArgs {
+    uint16_t* h;        // [M][ldh] residual stream, updated in place when part != nullptr
+    int ldh;
+    const float* part;  // [S][Mpad][H] partial slabs of the preceding projection, or nullptr
+    int S, Mpad;
+    const uint16_t* w;  // norm weight [H]; nullptr: only fold the partials into h
+    float eps;
+    uint16_t* xn;       // [M][ldxn]
+    int ldxn;
+    int M, H;
+};
+void launch_resid_norm(const ResidNormArgs& a, hipStream_t st);
+
+// ---- QK-norm + RoPE + KV append + paged decode attention (attn_decode.hip) ---------------------
+struct AttnArgs {
+    const uint16_t* qkv;  // [B][ld] : q heads | k heads | v heads
+    int ld;
+    const uint16_t* qn_w;
+    const uint16_t* kn_w;
+    float eps;
+    const uint16_t* rope_cos;  // [max_pos][128] bf16
+    const uint16_t* rope_sin;
+    uint16_t* kpool;           // this layer: [n_pages][n_kv][kPageTokens][128]
+    uint16_t* vpool;
+    const int32_t* block_table;  // [B][max_pages]
+    int max_pages;
+    const int32_t* kv_len;       // [B] tokens already cached (= position of the new token)
+    const uint8_t* active;       // [B] or nullptr (always): append this token to the cache
+    uint16_t* out;               // [B][n_heads*128]
+    int ldo;
+    int n_heads, n_kv, B;
+    float scale;
+};
+void launch_attn_decode(const AttnArgs& a, hipStream_t st);
+
+// ---- sampler (sampler.hip) ---------------------------------------------------------------------
+struct SamplingParams {  // lives in device memory so the captured graph does not depend on it
+    float temperature;
+    int top_k;
+    float top_p;
+    float rep_penalty;
+    uint64_t seed;
+    uint32_t row0;
+    int mask_eos;
+};
+
+struct SamplerArgs {
+    const uint16_t* logits;  // [B][ldl]
+    int ldl, V;
+    const SamplingParams* sp;
+    int is_talker;           // 1: suppress range + repetition penalty + EOS handling; 0: plain (code predictor)
+    int suppress_lo, suppress_hi, eos_id;
+    uint8_t* seen;           // [B][V] (talker only)
+    int cb;                  // codebook index written
+    const int32_t* n_frames; // [B] frames completed so far (draw index = frame*16 + cb)
+    const int32_t* max_frames;  // [B]
+    uint8_t* finished;       // [B]
+    uint8_t* active;         // [B] talker: cleared when the row finishes
+    int32_t* kv_len;         // [B] advanced by `advance` when the row consumed this step
+    int advance;             // 1: kv_len[b] += (active ? 1 : 0) -- end of a talker / predictor pass
+    const uint8_t* advance_gate;  // nullptr: unconditional
+    int32_t* cur_codes;      // [B][16] codes of the frame in flight
+    int32_t* codes;          // [B][Fmax][16]
+    int Fmax;
+    const int32_t* forced;   // [B][forced_frames][16] teacher forcing (tests) or nullptr
+    int forced_frames;
+    int32_t* sampled;        // [B][forced_frames][16] what the sampler chose (tests) or nullptr
+    const uint16_t* emb;     // embedding table of the sampled id -> next code-predictor input
+    int emb_ld;
+    uint16_t* next_x;        // [B][ld_next] or nullptr
+    int ld_next;
+    int H;
+    int B;
+    uint16_t* logits_dump;   // [B][forced_frames][dump_ld] (tests) or nullptr
+    int dump_ld, dump_off;
+};
+void launch_sampler(const SamplerArgs& a, hipStream_t st);
+
+// ---- embedding plumbing (lm_misc.hip) ----------------------------------------------------------
+// gather rows of a bf16 table: out[i] = table[ids[i]] (optionally through a token map)
+void launch_gather_rows(const uint16_t* table, int ld, const int32_t* ids, const int32_t* token_map,
+                        int n, int dim, uint16_t* out, int ldo, hipStream_t st);
+// out = a + b (bf16, one rounding), rows x dim; b_stride 0 broadcasts one row
+void launch_add_rows(const uint16_t* a, int lda, const uint16_t* b, int ldb, int rows, int dim,
+                     uint16_t* out, int ldo, hipStream_t st);
+
+struct PrefillLoadArgs {
+    const uint16_t* prompt;   // [B][Pmax][H]
+    const int32_t* n_prompt;  // [B]
+    int Pmax, step, H, B;
+    uint16_t* h;              // [B][ldh]
+    int ldh;
+    uint8_t* active;          // [B]
+};
+void launch_prefill_load(const PrefillLoadArgs& a, hipStream_t st);
+void launch_advance_len(int32_t* kv_len, const uint8_t* active, int B, hipStream_t st);
+
+struct FrameEndArgs {  // Qwen3.swift:919-935 + loop bookkeeping
+    const int32_t* cur_codes;     // [B][16]
+    const uint16_t* codec_emb;    // talker codec_embedding [V][H]
+    const uint16_t* const* cp_emb;  // device array of 15 tables [Vcp][H]
+    const uint16_t* trailing;     // [B][Tmax][H]
+    const int32_t* n_trailing;    // [B]
+    int32_t* trailing_idx;        // [B]
+    int Tmax;
+    const uint16_t* tts_pad;      // [H]
+    uint16_t* h;                  // [B][ldh] next talker input
+    int ldh, H, B, groups;
+    int32_t* n_frames;
+    const int32_t* max_frames;
+    uint8_t* finished;
+    uint8_t* active;
+    int32_t* cp_len;              // [B] reset to 0
+};
+void launch_frame_end(const FrameEndArgs& a, hipStream_t st);
+
+// prompt assembly (Qwen3.swift:371-406): dst[dst_row[i]] = b[i] < 0 ? proj[a[i]] : bf16(proj[a[i]] + table[b[i]])
+void launch_compose_rows(const uint16_t* proj, int ldp, const uint16_t* table, int ldt, const int32_t* a,
+                         const int32_t* b, const int32_t* dst_row, uint16_t* dst, int ldd, int n, int dim,
+                         hipStream_t st);
+
+// copies rows (bf16) between strided buffers: dst[r][0..dim) = src[r][0..dim)
+void launch_copy_rows(const uint16_t* src, int lds, uint16_t* dst, int ldd, int rows, int dim, hipStream_t st);
+
+}  // namespace q3

@@ -1,0 +1,188 @@
+// attn_decode.hip -- one decode step of TalkerAttention / CodePredictorAttention after the fused
+// QKV projection: per-head QK RMSNorm -> RoPE -> KV append -> GQA attention over the paged cache.
+//
+// Reference: /root/reference/Sources/Qwen3TTS/Models/Talker.swift:207-235 (norm :212-213, RoPE
+// :221 with applyRotaryPosEmb :139-152, cache.update :224-226, SDPA :229-235) and
+// CodePredictor.swift:111-134. KVCacheSimple (contiguous, grown by concatenation) becomes a paged
+// pool: page = 64 tokens x 128 dims per kv head, block table per row.
+//
+// Roofline: HBM (KV read: 2 * T * 256 B per (row, kv head, layer)). One workgroup per
+// (kv head, row); the `rep` query heads that share the kv head are processed together so K/V are
+// read once. 16 lanes cover one 256-byte K (or V) row with 16-byte loads, so a wave-instruction
+// reads 4 consecutive cache rows = 1 KiB contiguous; the 16 lane-groups of the workgroup stride
+// over T and are merged with a log-sum-exp reduction through LDS.
+#include "../common.h"
+#include "../kernels.h"
+
+namespace q3 {
+namespace {
+
+constexpr int D = kHeadDim;
+constexpr int kMaxRep = 4;
+
+// RMSNorm over 128 dims + RoPE for one head vector held as 2 elements per lane (i = lane, lane+64).
+// Rounding points follow the oracle: n = bf16(x*rstd); y = bf16(n*w); rope = bf16(bf16(y*cos) + bf16(rot*sin)).
+__device__ __forceinline__ void norm_rope(float x0, float x1, const uint16_t* w, float eps, const uint16_t* cosr,
+                                          const uint16_t* sinr, int lane, float& o0, float& o1) {
+    float ss = wave_sum(x0 * x0 + x1 * x1);
+    float rstd = 1.0f / sqrtf(ss / (float)D + eps);
+    float y0 = rbf(rbf(x0 * rstd) * bf2f(w[lane]));
+    float y1 = rbf(rbf(x1 * rstd) * bf2f(w[lane + 64]));
+    // rotate_half: first half pairs with -x2, second half with x1 (Talker.swift:125-130)
+    o0 = rbf(rbf(y0 * bf2f(cosr[lane])) + rbf(-y1 * bf2f(sinr[lane])));
+    o1 = rbf(rbf(y1 * bf2f(cosr[lane + 64])) + rbf(y0 * bf2f(sinr[lane + 64])));
+}
+
+template <int REP>
+__global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
+    __shared__ float q_s[REP][D];
+    __shared__ float k_s[D];
+    __shared__ float v_s[D];
+    __shared__ float m_s[16][REP];
+    __shared__ float l_s[16][REP];
+    __shared__ float acc_s[16][REP][D];
+
+    const int kvh = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int len = a.kv_len[b];  // position of the new token
+    const bool append = a.active ? (a.active[b] != 0) : true;
+    const uint16_t* row = a.qkv + (size_t)b * a.ld;
+    const uint16_t* cosr = a.rope_cos + (size_t)len * D;
+    const uint16_t* sinr = a.rope_sin + (size_t)len * D;
+    const int qdim = a.n_heads * D, kdim = a.n_kv * D;
+
+    // new-token page slot
+    const int32_t* bt = a.block_table + (size_t)b * a.max_pages;
+    const int npage = bt[len / kPageTokens];
+    const size_t nslot = (((size_t)npage * a.n_kv + kvh) * kPageTokens + (len % kPageTokens)) * D;
+
+    // ---- phase 1: q/k norm + rope, v copy; vectors round-robin over the 4 waves ----
+    for (int j = wave; j < REP + 2; j += 4) {
+        if (j < REP) {
+            const uint16_t* qp = row + (size_t)(kvh * REP + j) * D;
+            float o0, o1;
+            norm_rope(bf2f(qp[lane]), bf2f(qp[lane + 64]), a.qn_w, a.eps, cosr, sinr, lane, o0, o1);
+            q_s[j][lane] = o0;
+            q_s[j][lane + 64] = o1;
+        } else if (j == REP) {
+            const uint16_t* kp = row + qdim + (size_t)kvh * D;
+            float o0, o1;
+            norm_rope(bf2f(kp[lane]), bf2f(kp[lane + 64]), a.kn_w, a.eps, cosr, sinr, lane, o0, o1);
+            k_s[lane] = o0;
+            k_s[lane + 64] = o1;
+            if (append) {
+                a.kpool[nslot + lane] = f2bf(o0);
+                a.kpool[nslot + lane + 64] = f2bf(o1);
+            }
+        } else {
+            const uint16_t* vp = row + qdim + kdim + (size_t)kvh * D;
+            uint16_t v0 = vp[lane], v1 = vp[lane + 64];
+            v_s[lane] = bf2f(v0);
+            v_s[lane + 64] = bf2f(v1);
+            if (append) {
+                a.vpool[nslot + lane] = v0;
+                a.vpool[nslot + lane + 64] = v1;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: online-softmax attention; lane group g (16 lanes) strides over positions ----
+    const int g = tid >> 4, c = tid & 15;  // 16 groups x 16 lanes; lane c owns dims 8c..8c+7
+    float q[REP][8];
+#pragma unroll
+    for (int h = 0; h < REP; ++h)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[h][j] = q_s[h][8 * c + j];
+    float m[REP], l[REP], acc[REP][8];
+#pragma unroll
+    for (int h = 0; h < REP; ++h) {
+        m[h] = -INFINITY;
+        l[h] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[h][j] = 0.f;
+    }
+
+    auto step = [&](const float (&kf)[8], const float (&vf)[8]) {
+#pragma unroll
+        for (int h = 0; h < REP; ++h) {
+            float d = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d += q[h][j] * kf[j];
+            d += __shfl_xor(d, 1, 64);
+            d += __shfl_xor(d, 2, 64);
+            d += __shfl_xor(d, 4, 64);
+            d += __shfl_xor(d, 8, 64);
+            const float sc = d * a.scale;
+            const float mn = fmaxf(m[h], sc);
+            const float alpha = __expf(m[h] - mn);  // exp(-inf) = 0 on the first position
+            const float p = __expf(sc - mn);
+            l[h] = l[h] * alpha + p;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[h][j] = acc[h][j] * alpha + p * vf[j];
+            m[h] = mn;
+        }
+    };
+
+    for (int t = g; t < len; t += 16) {
+        const int page = bt[t / kPageTokens];
+        const size_t off = (((size_t)page * a.n_kv + kvh) * kPageTokens + (t % kPageTokens)) * D + 8 * c;
+        const uint4 kr = *reinterpret_cast<const uint4*>(a.kpool + off);
+        const uint4 vr = *reinterpret_cast<const uint4*>(a.vpool + off);
+        float kf[8] = {lo_bf(kr.x), hi_bf(kr.x), lo_bf(kr.y), hi_bf(kr.y), lo_bf(kr.z), hi_bf(kr.z), lo_bf(kr.w), hi_bf(kr.w)};
+        float vf[8] = {lo_bf(vr.x), hi_bf(vr.x), lo_bf(vr.y), hi_bf(vr.y), lo_bf(vr.z), hi_bf(vr.z), lo_bf(vr.w), hi_bf(vr.w)};
+        step(kf, vf);
+    }
+    if (g == (len & 15)) {  // the new token (kept in LDS: it may not be in the cache when !append)
+        float kf[8], vf[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            kf[j] = k_s[8 * c + j];
+            vf[j] = v_s[8 * c + j];
+        }
+        step(kf, vf);
+    }
+
+#pragma unroll
+    for (int h = 0; h < REP; ++h) {
+        if (c == 0) {
+            m_s[g][h] = m[h];
+            l_s[g][h] = l[h];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc_s[g][h][8 * c + j] = acc[h][j];
+    }
+    __syncthreads();
+
+    // ---- merge the 16 groups: thread -> (head, dim) ----
+    for (int o = tid; o < REP * D; o += 256) {
+        const int h = o / D, d = o % D;
+        float M = -INFINITY;
+#pragma unroll
+        for (int gg = 0; gg < 16; ++gg) M = fmaxf(M, m_s[gg][h]);
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int gg = 0; gg < 16; ++gg) {
+            const float w = (m_s[gg][h] == -INFINITY) ? 0.f : __expf(m_s[gg][h] - M);
+            num += acc_s[gg][h][d] * w;
+            den += l_s[gg][h] * w;
+        }
+        a.out[(size_t)b * a.ldo + (size_t)(kvh * REP + h) * D + d] = f2bf(num / den);
+    }
+}
+
+}  // namespace
+
+void launch_attn_decode(const AttnArgs& a, hipStream_t st) {
+    const int rep = a.n_heads / a.n_kv;
+    Q3_CHECK(rep * a.n_kv == a.n_heads && rep >= 1 && rep <= kMaxRep, 3, "attn_decode: unsupported GQA ratio");
+    dim3 grid(a.n_kv, a.B), block(256);
+    switch (rep) {
+        case 1: hipLaunchKernelGGL(attn_decode_kernel<1>, grid, block, 0, st, a); break;
+        case 2: hipLaunchKernelGGL(attn_decode_kernel<2>, grid, block, 0, st, a); break;
+        case 3: hipLaunchKernelGGL(attn_decode_kernel<3>, grid, block, 0, st, a); break;
+        case 4: hipLaunchKernelGGL(attn_decode_kernel<4>, grid, block, 0, st, a); break;
+    }
+}
+
+}  // namespace q3

@@ -1,0 +1,197 @@
+// codec_conv.hip -- causal (dilated) 1-D convolution as an implicit GEMM on the fp32 matrix cores.
+//
+// One kernel serves every dense contraction of the codec decoder
+// (/root/reference/Sources/Qwen3TTS/Models/SpeechTokenizer.swift): CausalConv1d (:259-306),
+// CausalTransposeConv1d (:311-354, stored in polyphase form by model.cc so that it is a causal
+// K<=2 conv whose N = stride*Cout outputs ARE the upsampled rows in channels-last memory), the
+// pointwise convs / Linears of the ConvNeXt blocks and the transformer (K = 1), with
+//   prologue : SnakeBeta on the input (:232-254) while staging the tile,
+//   epilogue : + bias, exact-erf GELU, per-channel scale (LayerScale / gamma), + residual.
+//
+//   out[b][t][n] = res[b][t][n] + scale[n] * act( bias[n] + sum_{tap,ci} W[n][tap][ci] * A(b, t-(K-1-tap)*dil, ci) )
+//
+// Roofline: fp32 MFMA (v_mfma_f32_16x16x4_f32, exact fmaf chain; 157 TFLOP/s peak). Activations are
+// channels-last [b][t][c]. A 128-position input tile plus its causal halo ((K-1)*dil rows) is
+// staged ONCE per 32-channel chunk into LDS and all K taps read shifted windows of it (the "LDS
+// ring buffer" of the north star); the weight tile of each (tap, chunk) is double-buffered in LDS
+// with the next one prefetched into registers under the MFMAs. Weights are the MFMA A operand
+// (M = out channels), activations the B operand (N = positions), so each lane ends with 4
+// consecutive channels of one position -> 16-byte epilogue loads/stores.
+// LDS rows are padded to 40 floats: conflict-free for ds_read_b128 (MI355X_MICROARCH.md LDS table).
+#include "../common.h"
+#include "../codec_kernels.h"
+
+namespace q3 {
+namespace {
+
+constexpr int BM = 128;        // positions per workgroup
+constexpr int KC = 32;         // input channels per chunk
+constexpr int LDS_LD = 40;     // padded row (floats)
+constexpr int MAX_HALO = 56;   // (K-1)*dil <= 54 in the decoder (k7, dil 9)
+
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+template <int BN>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
+    constexpr int CT = BN / 32;  // 16-channel tiles per wave (wave tile = 64 positions x BN/2 channels)
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // > 64 KiB for BN = 128: dynamic LDS
+    float* As = smem;                                        // [(BM + MAX_HALO)][LDS_LD]
+    float* Ws0 = smem + (BM + MAX_HALO) * LDS_LD;            // [2][BN][LDS_LD]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;  // position half, channel half
+    const int b = blockIdx.z;
+    const int n0 = blockIdx.x * BN;
+    const int t0 = blockIdx.y * BM;
+    const int T = a.frames[b] * a.ppf;
+    if (t0 >= T) return;
+    const int halo = (a.K - 1) * a.dil;
+    const int rows = BM + halo;
+    const float* xb = a.x + (size_t)b * a.x_bstride;
+    const int nchunks = (a.Cin + KC - 1) / KC;
+    const int steps = nchunks * a.K;
+
+    f32x4 acc[4][CT];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // weight tile prefetch registers: BN rows x 8 float4 per row / 256 threads
+    constexpr int WV = BN * 8 / 256;
+    float4 wreg[WV];
+    auto load_w = [&](int step) {
+        const int chunk = step / a.K, tap = step % a.K;
+        const int c0 = chunk * KC;
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int item = i * 256 + tid;
+            const int n = item >> 3, c4 = (item & 7) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n0 + n < a.N && c0 + c4 < a.Cin)
+                v = *reinterpret_cast<const float4*>(a.w + ((size_t)(n0 + n) * a.K + tap) * a.Cin + c0 + c4);
+            wreg[i] = v;
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int item = i * 256 + tid;
+            const int n = item >> 3, c4 = (item & 7) * 4;
+            *reinterpret_cast<float4*>(&Ws0[(buf * BN + n) * LDS_LD + c4]) = wreg[i];
+        }
+    };
+
+    load_w(0);
+    int buf = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int c0 = chunk * KC;
+        __syncthreads();  // previous chunk's MFMAs are done with As
+        for (int item = tid; item < rows * 8; item += 256) {
+            const int r = item >> 3, c4 = (item & 7) * 4;
+            const int t = t0 - halo + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t >= 0 && t < T && c0 + c4 < a.Cin) {
+                v = *reinterpret_cast<const float4*>(xb + (size_t)t * a.ldx + c0 + c4);
+                if (a.snake_ea) {
+                    const float4 ea = *reinterpret_cast<const float4*>(a.snake_ea + c0 + c4);
+                    const float4 ib = *reinterpret_cast<const float4*>(a.snake_ib + c0 + c4);
+                    float s;
+                    s = sinf(v.x * ea.x); v.x = v.x + ib.x * (s * s);
+                    s = sinf(v.y * ea.y); v.y = v.y + ib.y * (s * s);
+                    s = sinf(v.z * ea.z); v.z = v.z + ib.z * (s * s);
+                    s = sinf(v.w * ea.w); v.w = v.w + ib.w * (s * s);
+                }
+            }
+            *reinterpret_cast<float4*>(&As[r * LDS_LD + c4]) = v;
+        }
+        for (int tap = 0; tap < a.K; ++tap) {
+            const int step = chunk * a.K + tap;
+            store_w(buf);
+            __syncthreads();
+            if (step + 1 < steps) load_w(step + 1);
+            const float* arow = &As[(wm * 64 + tap * a.dil + (lane & 15)) * LDS_LD + 4 * (lane >> 4)];
+            const float* wrow = &Ws0[(buf * BN + wn * (BN / 2) + (lane & 15)) * LDS_LD + 4 * (lane >> 4)];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                float4 xa[4], wa[CT];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) xa[p] = *reinterpret_cast<const float4*>(arow + p * 16 * LDS_LD + g * 16);
+#pragma unroll
+                for (int c = 0; c < CT; ++c) wa[c] = *reinterpret_cast<const float4*>(wrow + c * 16 * LDS_LD + g * 16);
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) {
+                        acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c].x, xa[p].x, acc[p][c], 0, 0, 0);
+                        acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c].y, xa[p].y, acc[p][c], 0, 0, 0);
+                        acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c].z, xa[p].z, acc[p][c], 0, 0, 0);
+                        acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c].w, xa[p].w, acc[p][c], 0, 0, 0);
+                    }
+            }
+            buf ^= 1;
+        }
+    }
+
+    // epilogue: lane holds channels n..n+3 (rows of D) of position t (column of D)
+    float* ob = a.out + (size_t)b * a.out_bstride;
+    const float* rb = a.res ? a.res + (size_t)b * a.res_bstride : nullptr;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int t = t0 + wm * 64 + p * 16 + (lane & 15);
+        if (t >= T) continue;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int n = n0 + wn * (BN / 2) + c * 16 + 4 * (lane >> 4);
+            if (n >= a.N) continue;
+            float v[4] = {acc[p][c][0], acc[p][c][1], acc[p][c][2], acc[p][c][3]};
+            if (a.bias) {
+                const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
+                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+            }
+            if (a.act == 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+            }
+            if (a.scale) {
+                const float4 sv = *reinterpret_cast<const float4*>(a.scale + n);
+                v[0] *= sv.x; v[1] *= sv.y; v[2] *= sv.z; v[3] *= sv.w;
+            }
+            if (rb) {
+                const float4 rv = *reinterpret_cast<const float4*>(rb + (size_t)t * a.ldr + n);
+                v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+            }
+            *reinterpret_cast<float4*>(ob + (size_t)t * a.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+}  // namespace
+
+void launch_conv_gemm(const ConvGemmArgs& a, hipStream_t st) {
+    Q3_CHECK((a.K - 1) * a.dil <= MAX_HALO, 3, "conv_gemm: receptive field too large");
+    Q3_CHECK(a.Cin % 4 == 0 && a.N % 4 == 0 && a.ldx % 4 == 0 && a.ldo % 4 == 0, 3, "conv_gemm: channels must be multiples of 4");
+    const int mt = (a.Tmax + BM - 1) / BM;
+    if (mt <= 0 || a.B <= 0) return;
+    // tile width: 128 when it divides evenly, 96 for the 96/192/288-channel stages, else 64 (masked tail)
+    int BN = 64;
+    if (a.N % 128 == 0) BN = 128;
+    else if (a.N % 96 == 0) BN = 96;
+    else if (a.N > 128 && (a.N % 64) != 0) BN = 128;
+    dim3 grid((a.N + BN - 1) / BN, mt, a.B), block(256);
+    const size_t smem = size_t(BM + MAX_HALO + 2 * BN) * LDS_LD * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {  // 160 KiB of LDS per CU on gfx950; the default static cap is 64 KiB
+        Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<96>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        attr_set = true;
+    }
+    switch (BN) {
+        case 128: hipLaunchKernelGGL(conv_gemm_kernel<128>, grid, block, smem, st, a); break;
+        case 96: hipLaunchKernelGGL(conv_gemm_kernel<96>, grid, block, smem, st, a); break;
+        default: hipLaunchKernelGGL(conv_gemm_kernel<64>, grid, block, smem, st, a); break;
+    }
+}
+
+}  // namespace q3

@@ -1,0 +1,218 @@
+// codec_misc.hip -- the non-GEMM pieces of the codec decoder
+// (/root/reference/Sources/Qwen3TTS/Models/SpeechTokenizer.swift): Split-RVQ gather, fp32 RMSNorm,
+// depthwise conv + LayerNorm, SwiGLU gating, full attention of the 8-layer pre-transformer and the
+// Snake -> conv(C->1) -> clip tail. All are HBM/L2 bound row kernels over channels-last tensors.
+#include "../common.h"
+#include "../codec_kernels.h"
+
+namespace q3 {
+namespace {
+
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return ((sh[0] + sh[1]) + sh[2]) + sh[3];
+}
+
+// one workgroup per (frame, row)
+__global__ __launch_bounds__(256) void rvq_gather_kernel(const int32_t* codes, int code_stride_frames,
+                                                         const float* cb_first, const float* const* cb_rest, int n_rest,
+                                                         int inner, const int32_t* frames, int Fmax, float* out) {
+    const int f = blockIdx.x, b = blockIdx.y;
+    if (f >= frames[b]) return;
+    const int32_t* c = codes + ((size_t)b * code_stride_frames + f) * 16;
+    float* o = out + ((size_t)b * Fmax + f) * 2 * inner;
+    for (int i = threadIdx.x; i < inner; i += 256) {
+        o[i] = cb_first[(size_t)c[0] * inner + i];
+        float q = cb_rest[0][(size_t)c[1] * inner + i];  // layers summed in index order (:84-93)
+        for (int j = 1; j < n_rest; ++j) q = q + cb_rest[j][(size_t)c[1 + j] * inner + i];
+        o[inner + i] = q;
+    }
+}
+
+__global__ __launch_bounds__(256) void rmsnorm_f32_kernel(const float* x, const float* w, float eps, int C,
+                                                          const int32_t* frames, int ppf, int Tmax, float* out) {
+    __shared__ float sh[4];
+    const int t = blockIdx.x, b = blockIdx.y;
+    if (t >= frames[b] * ppf) return;
+    const float* xr = x + ((size_t)b * Tmax + t) * C;
+    float* orow = out + ((size_t)b * Tmax + t) * C;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < C; i += 256) ss += xr[i] * xr[i];
+    const float tot = block_sum_256(ss, sh);
+    const float rstd = 1.0f / sqrtf(tot / (float)C + eps);
+    for (int i = threadIdx.x; i < C; i += 256) orow[i] = (xr[i] * rstd) * w[i];
+}
+
+// ConvNeXt front half: y = dwconv_k7_causal(x) + b ; out = LayerNorm(y) (eps 1e-6)
+__global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* x, const float* dw_w, const float* dw_b,
+                                                        const float* ln_w, const float* ln_b, float eps, int C,
+                                                        const int32_t* frames, int ppf, int Tmax, float* out) {
+    __shared__ float sh[4];
+    constexpr int kMaxPer = 16;  // C <= 4096
+    const int t = blockIdx.x, b = blockIdx.y;
+    if (t >= frames[b] * ppf) return;
+    const float* xb = x + (size_t)b * Tmax * C;
+    float y[kMaxPer];
+    float s = 0.f;
+    int cnt = 0;
+    for (int c = threadIdx.x; c < C; c += 256, ++cnt) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int ti = t - 6 + k;
+            if (ti >= 0) acc += xb[(size_t)ti * C + c] * dw_w[c * 7 + k];
+        }
+        acc += dw_b[c];
+        y[cnt] = acc;
+        s += acc;
+    }
+    const float mean = block_sum_256(s, sh) / (float)C;
+    float v = 0.f;
+    for (int i = 0; i < cnt; ++i) v += (y[i] - mean) * (y[i] - mean);
+    const float var = block_sum_256(v, sh) / (float)C;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    float* orow = out + ((size_t)b * Tmax + t) * C;
+    cnt = 0;
+    for (int c = threadIdx.x; c < C; c += 256, ++cnt) orow[c] = (y[cnt] - mean) * rstd * ln_w[c] + ln_b[c];
+}
+
+__global__ void silu_mul_f32_kernel(const float* gu, int I, const int32_t* frames, int ppf, int Tmax, float* out) {
+    const int t = blockIdx.x, b = blockIdx.y;
+    if (t >= frames[b] * ppf) return;
+    const float* g = gu + ((size_t)b * Tmax + t) * 2 * I;
+    float* o = out + ((size_t)b * Tmax + t) * I;
+    for (int i = threadIdx.x; i < I; i += blockDim.x) {
+        const float gv = g[i];
+        o[i] = (gv / (1.0f + expf(-gv))) * g[I + i];
+    }
+}
+
+// Full attention, head_dim 64, one query per thread, keys/values streamed through LDS in tiles of 64.
+__global__ __launch_bounds__(64) void attn_full_f32_kernel(const float* qkv, int heads, const int32_t* frames,
+                                                           int Tmax, float* out) {
+    constexpr int Dh = 64, TK = 64;
+    __shared__ __attribute__((aligned(16))) float Ks[TK][Dh];
+    __shared__ __attribute__((aligned(16))) float Vs[TK][Dh];
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int T = frames[b];
+    const int q0 = blockIdx.x * 64;
+    if (q0 >= T) return;
+    const int ld = 3 * heads * Dh;
+    const float* base = qkv + (size_t)b * Tmax * ld;
+    const int qi = q0 + threadIdx.x;
+    const bool qvalid = qi < T;
+    float q[Dh], acc[Dh];
+    const float scale = 0.125f;  // 64^-0.5 (SpeechTokenizer.swift:502)
+#pragma unroll
+    for (int d = 0; d < Dh; ++d) {
+        q[d] = qvalid ? base[(size_t)qi * ld + h * Dh + d] : 0.f;
+        acc[d] = 0.f;
+    }
+    float m = -INFINITY, l = 0.f;
+    for (int k0 = 0; k0 < T; k0 += TK) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < TK * Dh / 4; i += 64) {
+            const int r = i / (Dh / 4), c4 = (i % (Dh / 4)) * 4;
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+            if (k0 + r < T) {
+                kv = *reinterpret_cast<const float4*>(base + (size_t)(k0 + r) * ld + (heads + h) * Dh + c4);
+                vv = *reinterpret_cast<const float4*>(base + (size_t)(k0 + r) * ld + (2 * heads + h) * Dh + c4);
+            }
+            *reinterpret_cast<float4*>(&Ks[r][c4]) = kv;
+            *reinterpret_cast<float4*>(&Vs[r][c4]) = vv;
+        }
+        __syncthreads();
+        const int kn = min(TK, T - k0);
+        for (int j = 0; j < kn; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < Dh; ++d) s += q[d] * Ks[j][d];
+            s *= scale;
+            const float mn = fmaxf(m, s);
+            const float alpha = expf(m - mn), p = expf(s - mn);
+            l = l * alpha + p;
+#pragma unroll
+            for (int d = 0; d < Dh; ++d) acc[d] = acc[d] * alpha + p * Vs[j][d];
+            m = mn;
+        }
+    }
+    if (qvalid) {
+        float* o = out + ((size_t)b * Tmax + qi) * heads * Dh + h * Dh;
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int d = 0; d < Dh; ++d) o[d] = acc[d] * inv;
+    }
+}
+
+// out[t] = clip(bias + sum_{k,c} snake(x[t-6+k][c]) * w[k][c]); 64 positions per workgroup, 4 lanes each
+__global__ __launch_bounds__(256) void out_conv_kernel(const float* x, int C, const float* ea, const float* ib,
+                                                       const float* w, const float* bias, const int32_t* frames, int ppf,
+                                                       int Tmax, float* pcm) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [(64+6)][C] snake(x)
+    const int b = blockIdx.y, t0 = blockIdx.x * 64;
+    const int T = frames[b] * ppf;
+    if (t0 >= T) return;
+    const float* xb = x + (size_t)b * Tmax * C;
+    for (int i = threadIdx.x; i < 70 * C; i += 256) {
+        const int r = i / C, c = i % C;
+        const int t = t0 - 6 + r;
+        float v = 0.f;
+        if (t >= 0 && t < T) {
+            v = xb[(size_t)t * C + c];
+            const float s = sinf(v * ea[c]);
+            v = v + ib[c] * (s * s);
+        }
+        xs[i] = v;
+    }
+    __syncthreads();
+    const int p = threadIdx.x >> 2, part = threadIdx.x & 3;
+    float acc = 0.f;
+    for (int k = 0; k < 7; ++k)
+        for (int c = part; c < C; c += 4) acc += xs[(p + k) * C + c] * w[k * C + c];
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    const int t = t0 + p;
+    if (part == 0 && t < T) {
+        const float v = acc + bias[0];
+        pcm[(size_t)b * Tmax + t] = fminf(fmaxf(v, -1.0f), 1.0f);
+    }
+}
+
+}  // namespace
+
+void launch_rvq_gather(const int32_t* codes, int code_stride_frames, const float* cb_first, const float* const* cb_rest,
+                       int n_rest, int inner, const int32_t* frames, int Fmax, int B, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(rvq_gather_kernel, dim3(Fmax, B), dim3(256), 0, st, codes, code_stride_frames, cb_first, cb_rest,
+                       n_rest, inner, frames, Fmax, out);
+}
+void launch_rmsnorm_f32(const float* x, const float* w, float eps, int C, const int32_t* frames, int ppf, int Tmax, int B,
+                        float* out, hipStream_t st) {
+    hipLaunchKernelGGL(rmsnorm_f32_kernel, dim3(Tmax, B), dim3(256), 0, st, x, w, eps, C, frames, ppf, Tmax, out);
+}
+void launch_dwconv_ln(const float* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
+                      float eps, int C, const int32_t* frames, int ppf, int Tmax, int B, float* out, hipStream_t st) {
+    Q3_CHECK(C <= 4096, 3, "dwconv_ln: more than 4096 channels");
+    hipLaunchKernelGGL(dwconv_ln_kernel, dim3(Tmax, B), dim3(256), 0, st, x, dw_w, dw_b, ln_w, ln_b, eps, C, frames, ppf,
+                       Tmax, out);
+}
+void launch_silu_mul_f32(const float* gu, int I, const int32_t* frames, int ppf, int Tmax, int B, float* out,
+                         hipStream_t st) {
+    hipLaunchKernelGGL(silu_mul_f32_kernel, dim3(Tmax, B), dim3(256), 0, st, gu, I, frames, ppf, Tmax, out);
+}
+void launch_attn_full_f32(const float* qkv, int heads, const int32_t* frames, int Tmax, int B, float* out,
+                          hipStream_t st) {
+    hipLaunchKernelGGL(attn_full_f32_kernel, dim3((Tmax + 63) / 64, heads, B), dim3(64), 0, st, qkv, heads, frames, Tmax,
+                       out);
+}
+void launch_out_conv(const float* x, int C, const float* ea, const float* ib, const float* w, const float* bias,
+                     const int32_t* frames, int ppf, int Tmax, int B, float* pcm, hipStream_t st) {
+    const size_t smem = size_t(70) * C * sizeof(float);
+    Q3_CHECK(smem <= 64 * 1024, 3, "out_conv: too many channels");
+    hipLaunchKernelGGL(out_conv_kernel, dim3((Tmax + 63) / 64, B), dim3(256), smem, st, x, C, ea, ib, w, bias, frames, ppf,
+                       Tmax, pcm);
+}
+
+}  // namespace q3

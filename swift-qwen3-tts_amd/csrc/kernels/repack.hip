@@ -1,0 +1,39 @@
+// repack.hip -- load-time weight re-tiling on the GPU (byte permutation only).
+// [N][K] row-major bf16 (MLXNN.Linear.weight, /root/reference/.../Talker.swift:183-186) ->
+// 4 KiB tiles [16 rows x 128 k] stored as [instr i=0..3][lane 0..63][8 bf16], where
+// lane = (row & 15) + 16 * h and the 8 elements are k = kc*128 + 32*h + 8*i + (0..7).
+// One global_load_dwordx4 per lane then fills one MFMA A fragment (gemm_decode.hip).
+#include "../common.h"
+#include "../model.h"
+
+namespace q3 {
+namespace {
+
+__global__ __launch_bounds__(256) void tile_weights_kernel(const uint16_t* src, int N, int K, uint16_t* dst, int KC,
+                                                           int tile_off, int tile_stride) {
+    const int kc = blockIdx.x, j = blockIdx.y;
+    const int i = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = 16 * j + (lane & 15);
+    const int k = kc * 128 + 32 * (lane >> 4) + 8 * i;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < N && k + 8 <= K) {
+        v = *reinterpret_cast<const uint4*>(src + (size_t)row * K + k);
+    } else if (row < N && k < K) {
+        uint16_t tmp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int e = 0; e < 8 && k + e < K; ++e) tmp[e] = src[(size_t)row * K + k + e];
+        __builtin_memcpy(&v, tmp, 16);
+    }
+    const size_t tile = (size_t)(tile_off + tile_stride * j) * KC + kc;
+    *reinterpret_cast<uint4*>(dst + tile * 2048 + (size_t)i * 512 + lane * 8) = v;
+}
+
+}  // namespace
+
+void launch_tile_weights(const uint16_t* src, int N, int K, uint16_t* dst, int KC, int tile_off, int tile_stride,
+                         hipStream_t st) {
+    Q3_CHECK(K % 8 == 0, 6, "linear weights need an inner size that is a multiple of 8");
+    dim3 grid(KC, (N + 15) / 16);
+    hipLaunchKernelGGL(tile_weights_kernel, grid, dim3(256), 0, st, src, N, K, dst, KC, tile_off, tile_stride);
+}
+
+}  // namespace q3

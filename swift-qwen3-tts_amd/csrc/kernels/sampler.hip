@@ -1,0 +1,341 @@
+// sampler.hip -- fused per-row token sampler (one workgroup per row; vocab <= 4096 fits LDS).
+//
+// Restates sampleToken / applyTopK / applyTopP / categoricalSampling
+// (/root/reference/Sources/Qwen3TTS/Models/Qwen3.swift:130-213, 68-89, 92-117, 120-126) as ONE
+// kernel instead of ~16 MLX op launches plus eval()/.item() host syncs per codebook:
+//   suppress -> repetition penalty -> [T<=0: argmax] -> save EOS -> top-k -> top-p -> restore EOS
+//   -> categorical(logits * 1/T) = argmax(scaled + Gumbel noise).
+// Array arithmetic is in bf16 like the reference (Float scalars become bf16 arrays in mlx-swift).
+// Integer / compare work is bit-exact against the oracle; the two transcendental helpers
+// (q3_logf, q3_expf) are written with explicit fma so that host and device agree bit for bit.
+// This translation unit is compiled with -ffp-contract=off.
+//
+// Also folded in (so the frame step needs no extra launches): teacher forcing for tests, the
+// code/flag bookkeeping of the Swift loop (Qwen3.swift:864-871), the embedding gather that feeds
+// the next code-predictor pass (:884-892) and the KV-length advance.
+#include "../common.h"
+#include "../kernels.h"
+
+namespace q3 {
+namespace {
+
+constexpr int kThreads = 1024;
+constexpr int kMaxV = 4096;
+constexpr int kElems = kMaxV / kThreads;
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// natural log, Cephes logf coefficients, +,*,fma and bit operations only
+__device__ __forceinline__ float q3_logf(float x) {
+    uint32_t u = __float_as_uint(x);
+    int e = (int)((u >> 23) & 0xff) - 126;
+    u = (u & 0x007fffffu) | 0x3f000000u;
+    float m = __uint_as_float(u);
+    if (m < 0.70710678118654752440f) {
+        e -= 1;
+        m = m + m;
+    }
+    const float f = m - 1.0f;
+    const float z = f * f;
+    float y = 7.0376836292E-2f;
+    y = __fmaf_rn(y, f, -1.1514610310E-1f);
+    y = __fmaf_rn(y, f, 1.1676998740E-1f);
+    y = __fmaf_rn(y, f, -1.2420140846E-1f);
+    y = __fmaf_rn(y, f, 1.4249322787E-1f);
+    y = __fmaf_rn(y, f, -1.6668057665E-1f);
+    y = __fmaf_rn(y, f, 2.0000714765E-1f);
+    y = __fmaf_rn(y, f, -2.4999993993E-1f);
+    y = __fmaf_rn(y, f, 3.3333331174E-1f);
+    y = y * f;
+    y = y * z;
+    const float fe = (float)e;
+    y = __fmaf_rn(fe, -2.12194440e-4f, y);
+    y = __fmaf_rn(z, -0.5f, y);
+    float r = f + y;
+    r = __fmaf_rn(fe, 0.693359375f, r);
+    return r;
+}
+
+// exp, Cephes expf coefficients, same construction rules
+__device__ __forceinline__ float q3_expf(float x) {
+    if (x < -87.0f) return 0.0f;
+    if (x > 88.0f) return INFINITY;
+    const float fx = floorf(__fmaf_rn(x, 1.44269504088896341f, 0.5f));
+    float r = __fmaf_rn(fx, -0.693359375f, x);
+    r = __fmaf_rn(fx, 2.12194440e-4f, r);
+    const float z = r * r;
+    float y = 1.9875691500E-4f;
+    y = __fmaf_rn(y, r, 1.3981999507E-3f);
+    y = __fmaf_rn(y, r, 8.3334519073E-3f);
+    y = __fmaf_rn(y, r, 4.1665795894E-2f);
+    y = __fmaf_rn(y, r, 1.6666665459E-1f);
+    y = __fmaf_rn(y, r, 5.0000001201E-1f);
+    y = __fmaf_rn(y, z, r);
+    y = y + 1.0f;
+    const int n = (int)fx;
+    return y * __uint_as_float((uint32_t)(n + 127) << 23);
+}
+
+__device__ __forceinline__ float gumbel_noise(uint64_t seed, uint32_t row, uint32_t draw, uint32_t i) {
+    uint32_t r[4];
+    philox4x32_10(i, row, draw, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const float u = ((float)(r[0] >> 8) + 0.5f) * 5.9604644775390625e-08f;
+    return -q3_logf(-q3_logf(u));
+}
+
+// monotone 16-bit key of a bf16-exact float (ascending)
+__device__ __forceinline__ uint32_t key16(float v) {
+    const uint32_t u = __float_as_uint(v) >> 16;
+    return (u & 0x8000u) ? (~u & 0xffffu) : (u | 0x8000u);
+}
+
+struct Best {
+    float v;
+    int i;
+};
+__device__ __forceinline__ Best better(Best a, Best b) {  // larger value, then lower index
+    return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+
+__device__ Best block_argmax(Best x, Best* scratch) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        Best y;
+        y.v = __shfl_xor(x.v, o, 64);
+        y.i = __shfl_xor(x.i, o, 64);
+        x = better(x, y);
+    }
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[wave] = x;
+    __syncthreads();
+    Best r = scratch[0];
+    for (int w = 1; w < kThreads / 64; ++w) r = better(r, scratch[w]);
+    return r;
+}
+
+__global__ __launch_bounds__(kThreads) void sampler_kernel(SamplerArgs a) {
+    __shared__ float vals[kMaxV];
+    __shared__ uint32_t sortbuf[kMaxV];
+    __shared__ uint32_t hist[256];
+    __shared__ Best scratch[kThreads / 64];
+    __shared__ uint32_t wcount[kThreads / 64];
+    __shared__ int sel[4];
+
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const SamplingParams sp = *a.sp;
+    const bool row_done = a.finished[b] != 0;
+    const int frame = a.n_frames[b];
+    const bool gate = a.advance_gate ? (a.advance_gate[b] != 0) : true;
+    if (row_done) {
+        if (tid == 0 && a.advance && gate && !a.advance_gate) a.kv_len[b] += 1;  // predictor rows keep in step
+        return;
+    }
+    const int V = a.V;
+    const uint16_t* lrow = a.logits + (size_t)b * a.ldl;
+    if (a.logits_dump && frame < a.forced_frames)
+        for (int i = tid; i < V; i += kThreads)
+            a.logits_dump[((size_t)b * a.forced_frames + frame) * a.dump_ld + a.dump_off + i] = lrow[i];
+
+    // ---- 1+2: suppress, repetition penalty ----
+    const float pen = rbf(sp.rep_penalty);
+    const bool use_pen = a.is_talker && a.seen && sp.rep_penalty != 1.0f;
+    float l[kElems];
+#pragma unroll
+    for (int k = 0; k < kElems; ++k) {
+        const int i = k * kThreads + tid;
+        float v = -INFINITY;
+        if (i < V) {
+            v = bf2f(lrow[i]);
+            if (a.is_talker) {
+                if (i >= a.suppress_lo && i < a.suppress_hi && i != a.eos_id) v = -INFINITY;
+                if (sp.mask_eos && i == a.eos_id) v = -INFINITY;
+                if (use_pen && a.seen[(size_t)b * V + i]) v = (v < 0.f) ? rbf(v * pen) : rbf(v / pen);
+            }
+        }
+        l[k] = v;
+        vals[k * kThreads + tid] = v;
+    }
+    __syncthreads();
+
+    int tok;
+    if (sp.temperature <= 0.f) {
+        // ---- 3: greedy = first maximum ----
+        Best x{-INFINITY, 0x7fffffff};
+#pragma unroll
+        for (int k = 0; k < kElems; ++k) {
+            const int i = k * kThreads + tid;
+            if (i < V) x = better(x, Best{l[k], i});
+        }
+        tok = block_argmax(x, scratch).i;
+    } else {
+        const bool have_eos = a.is_talker && a.eos_id >= 0 && a.eos_id < V;
+        const float eos_logit = have_eos ? vals[a.eos_id] : 0.f;
+        // ---- 5: top-k, two-level radix select on the 16-bit key; ties by lower index ----
+        if (sp.top_k > 0 && sp.top_k < V) {
+            uint32_t key[kElems];
+#pragma unroll
+            for (int k = 0; k < kElems; ++k) key[k] = key16(l[k]);
+            int need = sp.top_k;
+            uint32_t prefix = 0;  // selected high byte
+            for (int level = 0; level < 2; ++level) {
+                if (tid < 256) hist[tid] = 0;
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < kElems; ++k) {
+                    const int i = k * kThreads + tid;
+                    if (i < V && (level == 0 || (key[k] >> 8) == prefix))
+                        atomicAdd(&hist[level == 0 ? (key[k] >> 8) : (key[k] & 0xff)], 1u);
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    int cum = 0, bin = 255;
+                    for (; bin > 0; --bin) {
+                        if (cum + (int)hist[bin] >= need) break;
+                        cum += (int)hist[bin];
+                    }
+                    sel[0] = bin;
+                    sel[1] = need - cum;
+                }
+                __syncthreads();
+                if (level == 0) prefix = (uint32_t)sel[0];
+                else prefix = (prefix << 8) | (uint32_t)sel[0];
+                need = sel[1];
+                __syncthreads();
+            }
+            const uint32_t kt = prefix;  // threshold key; `need` equal-key elements survive
+            int base = 0;
+#pragma unroll
+            for (int k = 0; k < kElems; ++k) {
+                const int i = k * kThreads + tid;
+                const bool eq = (i < V) && key[k] == kt;
+                const unsigned long long bal = __ballot(eq);
+                const int lane = tid & 63, wave = tid >> 6;
+                const int below = __popcll(bal & ((1ull << lane) - 1ull));
+                if (lane == 0) wcount[wave] = (uint32_t)__popcll(bal);
+                __syncthreads();
+                int woff = 0, total = 0;
+                for (int w = 0; w < kThreads / 64; ++w) {
+                    if (w < wave) woff += (int)wcount[w];
+                    total += (int)wcount[w];
+                }
+                const int rank = base + woff + below;
+                if (i < V && (key[k] < kt || (eq && rank >= need))) l[k] = -INFINITY;
+                base += total;
+                __syncthreads();
+            }
+#pragma unroll
+            for (int k = 0; k < kElems; ++k) vals[k * kThreads + tid] = l[k];
+            __syncthreads();
+        }
+        // ---- 6: top-p (rare path): ascending sort, sequential cumulative sum like the oracle ----
+        if (sp.top_p > 0.f && sp.top_p < 1.0f) {
+#pragma unroll
+            for (int k = 0; k < kElems; ++k) {
+                const int i = k * kThreads + tid;
+                sortbuf[i] = (i < V) ? ((key16(l[k]) << 16) | (uint32_t)i) : 0xffffffffu;
+            }
+            __syncthreads();
+            for (int size = 2; size <= kMaxV; size <<= 1) {
+                for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                    for (int t = tid; t < kMaxV / 2; t += kThreads) {
+                        const int lo = 2 * t - (t & (stride - 1));
+                        const int hi = lo + stride;
+                        const bool up = ((lo & size) == 0);
+                        const uint32_t x = sortbuf[lo], y = sortbuf[hi];
+                        if ((x > y) == up) {
+                            sortbuf[lo] = y;
+                            sortbuf[hi] = x;
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            if (tid == 0) {
+                const float thr = rbf(1.0f - sp.top_p);
+                float run = 0.f;
+                for (int r = 0; r < V; ++r) {
+                    const int i = (int)(sortbuf[r] & 0xffffu);
+                    run += rbf(q3_expf(vals[i]));
+                    if (!(rbf(run) > thr)) vals[i] = -INFINITY;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < kElems; ++k) l[k] = vals[k * kThreads + tid];
+        }
+        // ---- 7: restore EOS ----
+        if (have_eos && !sp.mask_eos) {
+#pragma unroll
+            for (int k = 0; k < kElems; ++k)
+                if (k * kThreads + tid == a.eos_id) l[k] = eos_logit;
+        }
+        // ---- 8: categorical(logits * (1/T)) ----
+        const float invt = rbf(1.0f / sp.temperature);
+        const uint32_t draw = (uint32_t)frame * 16u + (uint32_t)a.cb;
+        Best x{-INFINITY, 0x7fffffff};
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < kElems; ++k) {
+            const int i = k * kThreads + tid;
+            if (i < V && l[k] != -INFINITY) {
+                const float v = rbf(l[k] * invt) + gumbel_noise(sp.seed, sp.row0 + (uint32_t)b, draw, (uint32_t)i);
+                if (!any || v > x.v) x = Best{v, i};  // ascending i within a thread: first maximum kept
+                any = true;
+            }
+        }
+        if (!any) x = Best{-INFINITY, 0x7fffffff};
+        Best r = block_argmax(x, scratch);
+        tok = (r.i == 0x7fffffff) ? 0 : r.i;
+    }
+
+    // ---- bookkeeping ----
+    int used = tok;
+    if (a.forced && frame < a.forced_frames) used = a.forced[((size_t)b * a.forced_frames + frame) * 16 + a.cb];
+    if (tid == 0) {
+        if (a.sampled && frame < a.forced_frames) a.sampled[((size_t)b * a.forced_frames + frame) * 16 + a.cb] = tok;
+        a.cur_codes[(size_t)b * 16 + a.cb] = used;
+        if (a.is_talker) {
+            if (a.seen && used >= 0 && used < V) a.seen[(size_t)b * V + used] = 1;  // generatedTokens (:865)
+            if (a.advance && a.active[b]) a.kv_len[b] += 1;
+            if (used == a.eos_id) {  // :868-870: EOS ends the row before any code is stored
+                a.finished[b] = 1;
+                a.active[b] = 0;
+            } else if (frame < a.Fmax) {
+                a.codes[((size_t)b * a.Fmax + frame) * 16] = used;
+            }
+        } else {
+            if (a.advance && gate) a.kv_len[b] += 1;
+            if (frame < a.Fmax) a.codes[((size_t)b * a.Fmax + frame) * 16 + a.cb] = used;
+        }
+    }
+    if (a.next_x) {
+        const uint4* src = reinterpret_cast<const uint4*>(a.emb + (size_t)used * a.emb_ld);
+        uint4* dst = reinterpret_cast<uint4*>(a.next_x + (size_t)b * a.ld_next);
+        for (int i = tid; i < a.H / 8; i += kThreads) dst[i] = src[i];
+    }
+}
+
+}  // namespace
+
+void launch_sampler(const SamplerArgs& a, hipStream_t st) {
+    Q3_CHECK(a.V <= kMaxV, 3, "sampler: vocabulary larger than 4096 is not supported");
+    hipLaunchKernelGGL(sampler_kernel, dim3(a.B), dim3(kThreads), 0, st, a);
+}
+
+}  // namespace q3

@@ -1,0 +1,649 @@
+// model.cc -- checkpoint loader: restates the reference's load + sanitise steps and lays the
+// weights out in HBM for the HIP kernels. See model.h.
+#include "model.h"
+
+#include "kernels.h"
+
+#include <cmath>
+#include <functional>
+#include <map>
+
+namespace q3 {
+
+Model::~Model() {
+    if (arena) (void)hipFree(arena);
+    for (void* p : side_allocs) (void)hipFree(p);
+}
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// host tensors for the speech tokenizer (fp32, small enough to sanitise on the host)
+// ------------------------------------------------------------------------------------------------
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;  // empty when only the shape is known (skip_tensor_data)
+    int64_t numel() const {
+        int64_t n = 1;
+        for (auto s : shape) n *= s;
+        return n;
+    }
+};
+
+std::vector<float> to_f32(const TensorView& tv) {
+    std::vector<float> out((size_t)(tv.numel()));
+    if (tv.dtype == DType::F32) {
+        std::memcpy(out.data(), tv.data, out.size() * 4);
+    } else if (tv.dtype == DType::BF16) {
+        const uint16_t* p = reinterpret_cast<const uint16_t*>(tv.data);
+        for (size_t i = 0; i < out.size(); ++i) out[i] = bf16_to_f32_host(p[i]);
+    } else if (tv.dtype == DType::F16) {
+        const uint16_t* p = reinterpret_cast<const uint16_t*>(tv.data);
+        for (size_t i = 0; i < out.size(); ++i) {  // fp16 "lite" codecs (docs/paper.tex:207)
+            uint32_t h = p[i], sign = (h & 0x8000u) << 16, e = (h >> 10) & 0x1f, m = h & 0x3ff, u;
+            if (e == 0) {
+                if (m == 0) u = sign;
+                else {
+                    int sh = 0;
+                    while (!(m & 0x400)) { m <<= 1; ++sh; }
+                    u = sign | ((uint32_t)(113 - sh) << 23) | ((m & 0x3ff) << 13);
+                }
+            } else if (e == 31) u = sign | 0x7f800000u | (m << 13);
+            else u = sign | ((e + 112) << 23) | (m << 13);
+            std::memcpy(&out[i], &u, 4);
+        }
+    } else {
+        throw Error(6, "unsupported dtype for a float tensor");
+    }
+    return out;
+}
+
+// checkArrayShapeQwen3 (Qwen3.swift:1246-1260): "is this 3-D conv weight already in MLX layout?"
+bool is_mlx_conv_layout(const std::vector<int64_t>& s) {
+    const int64_t d2 = s[1], d3 = s[2];
+    if (d2 == 1) return d3 > 64;
+    if (d3 == 1) return d2 <= 64;
+    return d2 < d3;
+}
+
+HostTensor permute3(const HostTensor& t, int a, int b, int c) {
+    HostTensor o;
+    const int64_t s[3] = {t.shape[0], t.shape[1], t.shape[2]};
+    o.shape = {s[a], s[b], s[c]};
+    if (t.data.empty()) return o;
+    o.data.resize(t.data.size());
+    int64_t idx[3];
+    for (idx[0] = 0; idx[0] < s[0]; ++idx[0])
+        for (idx[1] = 0; idx[1] < s[1]; ++idx[1])
+            for (idx[2] = 0; idx[2] < s[2]; ++idx[2]) {
+                const int64_t src = (idx[0] * s[1] + idx[1]) * s[2] + idx[2];
+                const int64_t dst = (idx[a] * s[b] + idx[b]) * s[c] + idx[c];
+                o.data[size_t(dst)] = t.data[size_t(src)];
+            }
+    return o;
+}
+
+void replace_all(std::string& s, const std::string& a, const std::string& b) {
+    size_t pos = 0;
+    while ((pos = s.find(a, pos)) != std::string::npos) {
+        s.replace(pos, a.size(), b);
+        pos += b.size();
+    }
+}
+bool contains(const std::string& s, const std::string& a) { return s.find(a) != std::string::npos; }
+bool starts_with(const std::string& s, const std::string& a) { return s.rfind(a, 0) == 0; }
+
+// Decoder half of sanitizeSpeechTokenizerWeights (Qwen3.swift:1498-1750). Encoder tensors are
+// left alone (voice-clone front end, SURVEY.md rows V1-V3, not built yet).
+std::map<std::string, HostTensor> sanitize_speech_tokenizer(const SafetensorsDir& st, bool with_data) {
+    static const std::pair<const char*, const char*> kIndex[] = {
+        {"decoder.decoder.0", "decoder.decoder.initConv"}, {"decoder.decoder.1", "decoder.decoder.block0"},
+        {"decoder.decoder.2", "decoder.decoder.block1"},   {"decoder.decoder.3", "decoder.decoder.block2"},
+        {"decoder.decoder.4", "decoder.decoder.block3"},   {"decoder.decoder.5", "decoder.decoder.outSnake"},
+        {"decoder.decoder.6", "decoder.decoder.outConv"}};
+    std::map<std::string, HostTensor> out;
+    std::map<std::string, std::pair<const TensorView*, const TensorView*>> cb;  // base -> (usage, sum)
+    for (auto& kv : st.all()) {
+        const std::string& key = kv.first;
+        const TensorView& tv = kv.second;
+        if (contains(key, "._codebook.cluster_usage") || contains(key, "._codebook.embedding_sum")) {  // :1532-1543
+            std::string base = key.substr(0, key.find("._codebook."));
+            if (contains(key, "cluster_usage")) cb[base].first = &tv;
+            else cb[base].second = &tv;
+            continue;
+        }
+        if (starts_with(key, "encoder.")) continue;
+        std::string nk = key;
+        for (auto& m : kIndex) {  // :1573-1578
+            std::string pre = std::string(m.first) + ".";
+            if (starts_with(key, pre)) {
+                nk = std::string(m.second) + key.substr(pre.size() - 1);
+                break;
+            }
+        }
+        if (starts_with(nk, "decoder.")) {  // :1581-1588
+            replace_all(nk, ".block.0.", ".snake.");
+            replace_all(nk, ".block.1.", ".upsample.");
+            replace_all(nk, ".block.2.", ".res1.");
+            replace_all(nk, ".block.3.", ".res2.");
+            replace_all(nk, ".block.4.", ".res3.");
+        }
+        HostTensor t;
+        t.shape = tv.shape;
+        if (with_data) t.data = to_f32(tv);
+        const bool is_proj = (contains(nk, "input_proj.weight") || contains(nk, "output_proj.weight")) && contains(nk, "quantizer");
+        HostTensor nv;
+        bool changed = false;
+        if (is_proj && t.shape.size() == 3) {  // :1688-1692
+            nv = permute3(t, 0, 2, 1);
+            changed = true;
+        }
+        if (contains(nk, "conv.weight") && t.shape.size() == 3 && !is_proj) {  // :1696-1700
+            if (!is_mlx_conv_layout(t.shape)) {
+                nv = permute3(t, 0, 2, 1);
+                changed = true;
+            }
+        }
+        const bool is_tr = (contains(nk, "upsample") && contains(nk, ".0.conv.weight")) ||
+                           (contains(nk, "decoder.decoder.block") && contains(nk, "upsample.conv.weight"));  // :1704-1711
+        if (is_tr && t.shape.size() == 3 && !is_mlx_conv_layout(t.shape)) {
+            nv = permute3(t, 1, 2, 0);
+            changed = true;
+        }
+        out[nk] = changed ? std::move(nv) : std::move(t);
+    }
+    for (auto& kv : cb) {  // codebook = embedding_sum / clip(cluster_usage, 1e-5) (:1716-1724)
+        if (!kv.second.first || !kv.second.second) continue;
+        HostTensor e;
+        e.shape = kv.second.second->shape;
+        if (with_data) {
+            std::vector<float> usage = to_f32(*kv.second.first), sum = to_f32(*kv.second.second);
+            const int64_t rows = e.shape[0], dim = e.shape[1];
+            e.data.resize(sum.size());
+            for (int64_t r = 0; r < rows; ++r) {
+                const float u = std::max(usage[size_t(r)], 1e-5f);
+                for (int64_t d = 0; d < dim; ++d) e.data[size_t(r * dim + d)] = sum[size_t(r * dim + d)] / u;
+            }
+        }
+        out[kv.first + ".codebook.embed.weight"] = std::move(e);
+    }
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// arena builder: the same construction code runs twice (size pass, then fill pass)
+// ------------------------------------------------------------------------------------------------
+struct Builder {
+    bool dry = true;
+    bool fill = true;  // false: allocate only (weights arrive by broadcast)
+    uint8_t* base = nullptr;
+    size_t off = 0;
+    uint16_t* staging = nullptr;  // device staging for raw bf16 matrices before tiling
+    size_t staging_elems = 0;
+    size_t max_staging = 0;       // collected in the dry pass
+
+    template <class T>
+    T* alloc(size_t n) {
+        off = align_up(off, 256);
+        T* p = dry ? nullptr : reinterpret_cast<T*>(base + off);
+        off += n * sizeof(T);
+        return p;
+    }
+    template <class T>
+    const T* put(const T* host, size_t n) {
+        T* p = alloc<T>(n);
+        if (!dry && fill && host) Q3_HIP(hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice));
+        return p;
+    }
+    // pointer tables hold absolute device addresses, so they stay outside the broadcastable arena
+    std::vector<void*>* side = nullptr;
+    template <class T>
+    const T* put_side(const T* host, size_t n) {
+        if (dry) return nullptr;
+        T* p = nullptr;
+        Q3_HIP(hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T)));
+        side->push_back(p);
+        Q3_HIP(hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice));
+        return p;
+    }
+    const float* put_f32(const HostTensor& t) {
+        return put<float>(t.data.empty() ? nullptr : t.data.data(), size_t(t.numel()));
+    }
+};
+
+struct MainTensors {
+    const SafetensorsDir& st;
+    const TensorView& bf16(const std::string& k, std::vector<int64_t> shape) const {
+        const TensorView& tv = st.at(k);
+        Q3_CHECK(tv.dtype == DType::BF16, 6, "tensor '" + k + "' must be bf16 (quantised checkpoints: int4 path not built yet)");
+        Q3_CHECK(tv.shape == shape, 6, "tensor '" + k + "' has an unexpected shape");
+        return tv;
+    }
+};
+
+const uint16_t* put_bf16(Builder& b, const TensorView& tv) {
+    return b.put<uint16_t>(reinterpret_cast<const uint16_t*>(tv.data), size_t(tv.numel()));
+}
+
+// rows of several [N_i][K] matrices -> one tiled weight (tile index = tile_off + tile_stride * j)
+struct RowSrc {
+    const TensorView* tv;
+    int tile_off, tile_stride;
+};
+LinearW put_linear(Builder& b, const std::vector<RowSrc>& srcs, int N, int K, int total_tiles, const TensorView* bias) {
+    LinearW L;
+    L.N = N;
+    L.K = K;
+    L.Kp = int(align_up(size_t(K), 128));
+    L.Np = total_tiles * 16;
+    const size_t elems = size_t(L.Np) * L.Kp;
+    uint16_t* dst = b.alloc<uint16_t>(elems);
+    for (auto& s : srcs) b.max_staging = std::max(b.max_staging, size_t(s.tv->numel()));
+    if (!b.dry && b.fill) {
+        Q3_HIP(hipMemsetAsync(dst, 0, elems * 2, nullptr));
+        for (auto& s : srcs) {
+            const int n = int(s.tv->shape[0]);
+            Q3_CHECK(int(s.tv->shape[1]) == K, 6, "linear weight with unexpected inner size");
+            Q3_HIP(hipMemcpyAsync(b.staging, s.tv->data, size_t(n) * K * 2, hipMemcpyHostToDevice, nullptr));
+            launch_tile_weights(b.staging, n, K, dst, L.Kp / 128, s.tile_off, s.tile_stride, nullptr);
+            Q3_HIP(hipStreamSynchronize(nullptr));
+        }
+    }
+    L.w = dst;
+    if (bias) {
+        // bias padded to Np so the epilogue may read any row of a padded tile
+        std::vector<uint16_t> tmp((size_t)(L.Np), 0);
+        std::memcpy(tmp.data(), bias->data, size_t(bias->numel()) * 2);
+        L.bias = b.put<uint16_t>(tmp.data(), tmp.size());
+    }
+    return L;
+}
+
+void build_stack(Builder& b, const MainTensors& mt, const std::string& prefix, StackW& s, int hidden,
+                 const std::vector<int>& inter, int n_heads, int n_kv, int head_dim, float eps, float base, int max_pos) {
+    s.hidden = hidden;
+    s.n_heads = n_heads;
+    s.n_kv = n_kv;
+    s.head_dim = head_dim;
+    s.eps = eps;
+    s.rope_base = base;
+    s.max_pos = max_pos;
+    s.layers.resize(inter.size());
+    const int qd = n_heads * head_dim, kd = n_kv * head_dim;
+    for (size_t l = 0; l < inter.size(); ++l) {
+        LayerW& L = s.layers[l];
+        const std::string p = prefix + ".layers." + std::to_string(l);
+        const int I = inter[l];
+        L.inter = I;
+        L.inter_p = int(align_up(size_t(I), 128));  // down_proj reads it as K
+        s.max_inter_p = std::max(s.max_inter_p, L.inter_p);
+        L.ln1 = put_bf16(b, mt.bf16(p + ".input_layernorm.weight", {hidden}));
+        L.ln2 = put_bf16(b, mt.bf16(p + ".post_attention_layernorm.weight", {hidden}));
+        L.qn = put_bf16(b, mt.bf16(p + ".self_attn.q_norm.weight", {head_dim}));
+        L.kn = put_bf16(b, mt.bf16(p + ".self_attn.k_norm.weight", {head_dim}));
+        const TensorView& q = mt.bf16(p + ".self_attn.q_proj.weight", {qd, hidden});
+        const TensorView& k = mt.bf16(p + ".self_attn.k_proj.weight", {kd, hidden});
+        const TensorView& v = mt.bf16(p + ".self_attn.v_proj.weight", {kd, hidden});
+        L.qkv = put_linear(b, {{&q, 0, 1}, {&k, qd / 16, 1}, {&v, (qd + kd) / 16, 1}}, qd + 2 * kd, hidden,
+                           (qd + 2 * kd) / 16, nullptr);
+        const TensorView& o = mt.bf16(p + ".self_attn.o_proj.weight", {hidden, qd});
+        L.o = put_linear(b, {{&o, 0, 1}}, hidden, qd, hidden / 16, nullptr);
+        const TensorView& g = mt.bf16(p + ".mlp.gate_proj.weight", {I, hidden});
+        const TensorView& u = mt.bf16(p + ".mlp.up_proj.weight", {I, hidden});
+        const int it = L.inter_p / 16;  // gate/up tile pairs, padded so that act has inter_p columns
+        L.gateup = put_linear(b, {{&g, 0, 2}, {&u, 1, 2}}, I, hidden, 2 * it, nullptr);
+        L.gateup.Np = L.inter_p;  // logical output columns (pairs of tiles)
+        const TensorView& d = mt.bf16(p + ".mlp.down_proj.weight", {hidden, I});
+        L.down = put_linear(b, {{&d, 0, 1}}, hidden, I, hidden / 16, nullptr);
+    }
+    s.final_norm = put_bf16(b, mt.bf16(prefix + ".norm.weight", {hidden}));
+    // RoPE tables (Talker.swift:42-44,103-117; CodePredictor.swift:38-39,44-56): fp32 angles,
+    // cos/sin rounded to bf16; computed with the host libm exactly like the oracle.
+    std::vector<uint16_t> cs((size_t)(max_pos) * head_dim), sn((size_t)(max_pos) * head_dim);
+    if (!b.dry && b.fill) {
+        const int half = head_dim / 2;
+        for (int p = 0; p < max_pos; ++p)
+            for (int i = 0; i < half; ++i) {
+                const float inv = 1.0f / powf(base, float(2 * i) / float(head_dim));
+                const float ang = float(p) * inv;
+                const uint16_t c = f32_to_bf16_host(cosf(ang)), sv = f32_to_bf16_host(sinf(ang));
+                cs[size_t(p) * head_dim + i] = c;
+                cs[size_t(p) * head_dim + half + i] = c;
+                sn[size_t(p) * head_dim + i] = sv;
+                sn[size_t(p) * head_dim + half + i] = sv;
+            }
+    }
+    s.rope_cos = b.put<uint16_t>(cs.data(), cs.size());
+    s.rope_sin = b.put<uint16_t>(sn.data(), sn.size());
+}
+
+// ---- codec helpers -----------------------------------------------------------------------------
+using TMap = std::map<std::string, HostTensor>;
+const HostTensor& need(const TMap& t, const std::string& k) {
+    auto it = t.find(k);
+    Q3_CHECK(it != t.end(), 6, "missing speech tokenizer tensor '" + k + "'");
+    return it->second;
+}
+const HostTensor* maybe(const TMap& t, const std::string& k) {
+    auto it = t.find(k);
+    return it == t.end() ? nullptr : &it->second;
+}
+
+ConvW put_conv(Builder& b, const TMap& t, const std::string& name, int dil = 1) {
+    const HostTensor& w = need(t, name + ".weight");
+    ConvW c;
+    if (w.shape.size() == 3) {
+        c.N = int(w.shape[0]);
+        c.K = int(w.shape[1]);
+        c.Cin = int(w.shape[2]);
+    } else {
+        c.N = int(w.shape[0]);
+        c.K = 1;
+        c.Cin = int(w.shape[1]);
+    }
+    c.dil = dil;
+    c.w = b.put_f32(w);
+    if (const HostTensor* bias = maybe(t, name + ".bias")) c.bias = b.put_f32(*bias);
+    return c;
+}
+
+// rows of several [N_i][K] fp32 matrices stacked
+ConvW put_linear_concat(Builder& b, const TMap& t, const std::vector<std::string>& names) {
+    HostTensor cat;
+    int K = 0, N = 0;
+    bool have = true;
+    for (auto& n : names) {
+        const HostTensor& w = need(t, n + ".weight");
+        K = int(w.shape[1]);
+        N += int(w.shape[0]);
+        have = have && !w.data.empty();
+    }
+    cat.shape = {N, K};
+    if (have)
+        for (auto& n : names) {
+            const HostTensor& w = need(t, n + ".weight");
+            cat.data.insert(cat.data.end(), w.data.begin(), w.data.end());
+        }
+    ConvW c;
+    c.N = N;
+    c.K = 1;
+    c.Cin = K;
+    c.w = b.put_f32(cat);
+    return c;
+}
+
+// ConvTransposed1d [Cout][K][Cin] (K = taps*stride) -> causal conv with N = stride*Cout, taps = K/stride:
+// y[t*s + r][co] = sum_ci x[t][ci] W[co][r][ci] + x[t-1][ci] W[co][r+s][ci]  (SpeechTokenizer.swift:330-352)
+ConvW put_tconv(Builder& b, const TMap& t, const std::string& name, int stride) {
+    const HostTensor& w = need(t, name + ".weight");
+    const int Cout = int(w.shape[0]), K = int(w.shape[1]), Cin = int(w.shape[2]);
+    Q3_CHECK(K % stride == 0 && (K / stride == 1 || K / stride == 2), 6, "unsupported transposed conv geometry: " + name);
+    const int taps = K / stride;
+    HostTensor p;
+    p.shape = {int64_t(stride) * Cout, taps, Cin};
+    if (!w.data.empty()) {
+        p.data.resize(size_t(p.numel()));
+        for (int r = 0; r < stride; ++r)
+            for (int co = 0; co < Cout; ++co)
+                for (int tap = 0; tap < taps; ++tap) {
+                    // causal tap index `tap` reads x[t - (taps-1-tap)]; the current sample pairs with kernel tap r
+                    const int k = r + (taps - 1 - tap) * stride;
+                    const float* src = &w.data[(size_t(co) * K + k) * Cin];
+                    float* dst = &p.data[((size_t(r) * Cout + co) * taps + tap) * Cin];
+                    std::memcpy(dst, src, size_t(Cin) * 4);
+                }
+    }
+    ConvW c;
+    c.N = stride * Cout;
+    c.K = taps;
+    c.Cin = Cin;
+    c.dil = 1;
+    c.w = b.put_f32(p);
+    if (const HostTensor* bias = maybe(t, name + ".bias")) {
+        HostTensor bb;
+        bb.shape = {int64_t(stride) * Cout};
+        if (!bias->data.empty()) {
+            bb.data.resize(size_t(stride) * Cout);
+            for (int r = 0; r < stride; ++r) std::memcpy(&bb.data[size_t(r) * Cout], bias->data.data(), size_t(Cout) * 4);
+        }
+        c.bias = b.put_f32(bb);
+    }
+    return c;
+}
+
+SnakeW put_snake(Builder& b, const TMap& t, const std::string& name) {
+    const HostTensor& al = need(t, name + ".alpha");
+    const HostTensor& be = need(t, name + ".beta");
+    HostTensor ea, ib;
+    ea.shape = al.shape;
+    ib.shape = be.shape;
+    if (!al.data.empty()) {
+        ea.data.resize(al.data.size());
+        ib.data.resize(be.data.size());
+        for (size_t i = 0; i < al.data.size(); ++i) {  // SnakeBeta, SpeechTokenizer.swift:246-253
+            ea.data[i] = expf(al.data[i]);
+            ib.data[i] = 1.0f / (expf(be.data[i]) + 1e-9f);
+        }
+    }
+    SnakeW s;
+    s.C = int(al.shape[0]);
+    s.ea = b.put_f32(ea);
+    s.ib = b.put_f32(ib);
+    return s;
+}
+
+void build_codec(Builder& b, const TMap& t, const CodecDecoderConfig& dc, CodecW& c) {
+    const std::string q = "decoder.quantizer.";
+    const HostTensor& cb0 = need(t, q + "rvq_first.vq.layers.0.codebook.embed.weight");
+    c.inner = int(cb0.shape[1]);
+    Q3_CHECK(dc.num_semantic_quantizers == 1, 6, "only one semantic quantizer is supported");
+    c.cb_first = b.put_f32(cb0);
+    const int nrest = dc.num_quantizers - dc.num_semantic_quantizers;
+    c.cb_rest.resize(size_t(nrest));
+    for (int i = 0; i < nrest; ++i)
+        c.cb_rest[size_t(i)] = b.put_f32(need(t, q + "rvq_rest.vq.layers." + std::to_string(i) + ".codebook.embed.weight"));
+    c.cb_rest_dev = b.put_side<const float*>(c.cb_rest.data(), c.cb_rest.size());
+    {  // fused output projection: [cd][1][inner] x2 -> [cd][1][2*inner]
+        const HostTensor& w1 = need(t, q + "rvq_first.output_proj.weight");
+        const HostTensor& w2 = need(t, q + "rvq_rest.output_proj.weight");
+        const int cd = int(w1.shape[0]), in = int(w1.shape[2]);
+        HostTensor f;
+        f.shape = {cd, 1, 2 * in};
+        if (!w1.data.empty()) {
+            f.data.resize(size_t(cd) * 2 * in);
+            for (int n = 0; n < cd; ++n) {
+                std::memcpy(&f.data[size_t(n) * 2 * in], &w1.data[size_t(n) * in], size_t(in) * 4);
+                std::memcpy(&f.data[size_t(n) * 2 * in + in], &w2.data[size_t(n) * in], size_t(in) * 4);
+            }
+        }
+        c.rvq_out.N = cd;
+        c.rvq_out.K = 1;
+        c.rvq_out.Cin = 2 * in;
+        c.rvq_out.w = b.put_f32(f);
+    }
+    c.pre_conv = put_conv(b, t, "decoder.pre_conv.conv");
+    const std::string pt = "decoder.pre_transformer";
+    c.t_in = put_conv(b, t, pt + ".input_proj");
+    c.t_out = put_conv(b, t, pt + ".output_proj");
+    c.tlayers.resize(size_t(dc.num_hidden_layers));
+    for (int l = 0; l < dc.num_hidden_layers; ++l) {
+        auto& L = c.tlayers[size_t(l)];
+        const std::string p = pt + ".layers." + std::to_string(l);
+        L.ln1 = b.put_f32(need(t, p + ".input_layernorm.weight"));
+        L.ln2 = b.put_f32(need(t, p + ".post_attention_layernorm.weight"));
+        L.qkv = put_linear_concat(b, t, {p + ".self_attn.q_proj", p + ".self_attn.k_proj", p + ".self_attn.v_proj"});
+        L.o = put_conv(b, t, p + ".self_attn.o_proj");
+        L.o.scale = b.put_f32(need(t, p + ".self_attn_layer_scale.scale"));
+        L.gateup = put_linear_concat(b, t, {p + ".mlp.gate_proj", p + ".mlp.up_proj"});
+        L.down = put_conv(b, t, p + ".mlp.down_proj");
+        L.down.scale = b.put_f32(need(t, p + ".mlp_layer_scale.scale"));
+    }
+    c.t_norm = b.put_f32(need(t, pt + ".norm.weight"));
+    c.ups.resize(dc.upsampling_ratios.size());
+    for (size_t i = 0; i < dc.upsampling_ratios.size(); ++i) {
+        auto& U = c.ups[i];
+        U.stride = dc.upsampling_ratios[i];
+        const std::string p = "decoder.upsample." + std::to_string(i);
+        U.tconv = put_tconv(b, t, p + ".0.conv", U.stride);
+        const HostTensor& dw = need(t, p + ".1.dwconv.conv.weight");  // [C][7][1]
+        Q3_CHECK(dw.shape.size() == 3 && dw.shape[1] == 7 && dw.shape[2] == 1, 6, "unexpected depthwise conv shape");
+        U.dw_w = b.put_f32(dw);
+        U.dw_b = b.put_f32(need(t, p + ".1.dwconv.conv.bias"));
+        U.ln_w = b.put_f32(need(t, p + ".1.norm.weight"));
+        U.ln_b = b.put_f32(need(t, p + ".1.norm.bias"));
+        U.pw1 = put_conv(b, t, p + ".1.pwconv1");
+        U.pw2 = put_conv(b, t, p + ".1.pwconv2");
+        U.pw2.scale = b.put_f32(need(t, p + ".1.gamma"));
+    }
+    c.init_conv = put_conv(b, t, "decoder.decoder.initConv.conv");
+    c.blocks.resize(dc.upsample_rates.size());
+    for (size_t i = 0; i < dc.upsample_rates.size(); ++i) {
+        auto& B = c.blocks[i];
+        const std::string p = "decoder.decoder.block" + std::to_string(i);
+        B.stride = dc.upsample_rates[i];
+        B.snake = put_snake(b, t, p + ".snake");
+        B.tconv = put_tconv(b, t, p + ".upsample.conv", B.stride);
+        B.Cout = B.tconv.N / B.stride;
+        const int dils[3] = {1, 3, 9};  // SpeechTokenizer.swift:468-470
+        for (int j = 0; j < 3; ++j) {
+            const std::string rp = p + ".res" + std::to_string(j + 1);
+            B.res[j].act1 = put_snake(b, t, rp + ".act1");
+            B.res[j].conv1 = put_conv(b, t, rp + ".conv1.conv", dils[j]);
+            B.res[j].act2 = put_snake(b, t, rp + ".act2");
+            B.res[j].conv2 = put_conv(b, t, rp + ".conv2.conv");
+        }
+    }
+    c.out_snake = put_snake(b, t, "decoder.decoder.outSnake");
+    const HostTensor& ow = need(t, "decoder.decoder.outConv.conv.weight");
+    Q3_CHECK(ow.shape.size() == 3 && ow.shape[0] == 1, 6, "unexpected output conv shape");
+    c.out_C = int(ow.shape[2]);
+    c.out_w = b.put_f32(ow);
+    c.out_b = b.put_f32(need(t, "decoder.decoder.outConv.conv.bias"));
+}
+
+int64_t linear_bytes(const LinearW& L) { return int64_t(L.N) * L.K * 2; }
+
+void build_all(Builder& b, Model& m, const SafetensorsDir& main, const TMap* codec_t, const LoadOptions& opt) {
+    const ModelConfig& cfg = m.cfg;
+    const TalkerConfig& t = cfg.talker;
+    MainTensors mt{main};
+    Q3_CHECK(t.head_dim == kHeadDim && t.cp.head_dim == kHeadDim, 6, "head_dim must be 128");
+    const int H = t.hidden_size, TH = t.text_hidden_size;
+    m.codec_emb = put_bf16(b, mt.bf16("talker.model.codec_embedding.weight", {t.vocab_size, H}));
+    {
+        const TensorView& te = main.at("talker.model.text_embedding.weight");
+        Q3_CHECK(te.dtype == DType::BF16 && te.shape.size() == 2 && te.shape[1] == TH, 6, "unexpected text_embedding");
+        m.text_emb_rows = te.shape[0];  // fewer rows than text_vocab_size when the vocabulary is pruned
+        m.text_emb = put_bf16(b, te);
+    }
+    if (main.has("talker.model.text_token_map")) {  // Qwen3.swift:1434-1444
+        const TensorView& tm = main.at("talker.model.text_token_map");
+        Q3_CHECK(tm.dtype == DType::I32, 6, "text_token_map must be int32");
+        m.token_map = b.put<int32_t>(reinterpret_cast<const int32_t*>(tm.data), size_t(tm.numel()));
+    }
+    std::vector<int> inter;
+    for (int l = 0; l < t.num_hidden_layers; ++l) inter.push_back(t.inter(l));
+    build_stack(b, mt, "talker.model", m.talker, H, inter, t.num_attention_heads, t.num_key_value_heads, t.head_dim,
+                t.rms_norm_eps, t.rope_theta, opt.max_pos_talker);
+    const TensorView& f1 = mt.bf16("talker.text_projection.linear_fc1.weight", {TH, TH});
+    const TensorView& f1b = mt.bf16("talker.text_projection.linear_fc1.bias", {TH});
+    const TensorView& f2 = mt.bf16("talker.text_projection.linear_fc2.weight", {H, TH});
+    const TensorView& f2b = mt.bf16("talker.text_projection.linear_fc2.bias", {H});
+    m.fc1 = put_linear(b, {{&f1, 0, 1}}, TH, TH, TH / 16, &f1b);
+    m.fc2 = put_linear(b, {{&f2, 0, 1}}, H, TH, H / 16, &f2b);
+    const TensorView& ch = mt.bf16("talker.codec_head.weight", {t.vocab_size, H});
+    m.codec_head = put_linear(b, {{&ch, 0, 1}}, t.vocab_size, H, t.vocab_size / 16, nullptr);
+    Q3_CHECK(t.has_code_predictor, 6, "code_predictor_config is required");
+    const CodePredictorConfig& cp = t.cp;
+    const int CH = cp.hidden_size;
+    m.has_cp_proj = (CH != H);  // CodePredictor.swift:295-299
+    if (m.has_cp_proj) {
+        const TensorView& pw = mt.bf16("talker.code_predictor.small_to_mtp_projection.weight", {CH, H});
+        const TensorView& pb = mt.bf16("talker.code_predictor.small_to_mtp_projection.bias", {CH});
+        m.cp_proj = put_linear(b, {{&pw, 0, 1}}, CH, H, CH / 16, &pb);
+    }
+    const int ng = cp.num_code_groups - 1;
+    m.cp_emb.resize(size_t(ng));
+    m.lm_head.resize(size_t(ng));
+    for (int i = 0; i < ng; ++i) {
+        m.cp_emb[size_t(i)] = put_bf16(b, mt.bf16("talker.code_predictor.model.codec_embedding." + std::to_string(i) + ".weight",
+                                                   {cp.vocab_size, H}));
+        const TensorView& lh = mt.bf16("talker.code_predictor.lm_head." + std::to_string(i) + ".weight", {cp.vocab_size, CH});
+        m.lm_head[size_t(i)] = put_linear(b, {{&lh, 0, 1}}, cp.vocab_size, CH, cp.vocab_size / 16, nullptr);
+    }
+    m.cp_emb_dev = b.put_side<const uint16_t*>(m.cp_emb.data(), m.cp_emb.size());
+    std::vector<int> cp_inter((size_t)(cp.num_hidden_layers), cp.intermediate_size);
+    build_stack(b, mt, "talker.code_predictor.model", m.cp, CH, cp_inter, cp.num_attention_heads, cp.num_key_value_heads,
+                cp.head_dim, cp.rms_norm_eps, cp.rope_theta, 64);
+    if (codec_t) {
+        build_codec(b, *codec_t, cfg.codec, m.codec);
+        m.has_codec = true;
+    }
+    // distinct weight bytes of one frame step
+    int64_t wb = linear_bytes(m.codec_head);
+    for (auto& L : m.talker.layers) wb += linear_bytes(L.qkv) + linear_bytes(L.o) + 2 * int64_t(L.inter) * H * 2 + linear_bytes(L.down);
+    for (auto& L : m.cp.layers) wb += linear_bytes(L.qkv) + linear_bytes(L.o) + 2 * int64_t(L.inter) * CH * 2 + linear_bytes(L.down);
+    for (auto& L : m.lm_head) wb += linear_bytes(L);
+    if (m.has_cp_proj) wb += linear_bytes(m.cp_proj);
+    m.step_weight_bytes = wb;
+}
+
+}  // namespace
+
+std::unique_ptr<Model> load_model(const std::string& dir, const LoadOptions& opt) {
+    auto m = std::make_unique<Model>();
+    m->device = opt.device;
+    Q3_HIP(hipSetDevice(opt.device));
+    {
+        std::string txt = read_file(dir + "/config.json");  // Qwen3.swift:1386-1388
+        Json j = JsonParser(txt.data(), txt.size()).parse();
+        m->cfg.parse(j);
+    }
+    Q3_CHECK(m->cfg.has_talker, 1, "Talker config is required");  // fatalError at Qwen3.swift:48-50
+    Q3_CHECK(!m->cfg.has_quantization, 6,
+             "quantised (int4) checkpoints are not supported by this build yet (SURVEY.md row A14)");
+    SafetensorsDir main;
+    main.open_dir(dir);  // Qwen3.swift:1391-1399
+    SafetensorsDir st;
+    TMap codec_t;
+    const std::string st_dir = dir + "/speech_tokenizer";
+    const bool have_codec = file_exists(st_dir + "/config.json");  // Qwen3.swift:1462-1463
+    if (have_codec) {
+        std::string txt = read_file(st_dir + "/config.json");
+        Json j = JsonParser(txt.data(), txt.size()).parse();
+        m->cfg.parse_speech_tokenizer(j);
+        Q3_CHECK(m->cfg.has_codec, 1, "Decoder config is required");  // fatalError at SpeechTokenizer.swift:804
+        st.open_dir(st_dir);
+        codec_t = sanitize_speech_tokenizer(st, !opt.skip_tensor_data);
+    }
+    Builder dry;
+    dry.dry = true;
+    {
+        Model scratch;
+        scratch.cfg = m->cfg;
+        build_all(dry, scratch, main, have_codec ? &codec_t : nullptr, opt);
+    }
+    m->arena_bytes = align_up(dry.off, 256);
+    Q3_HIP(hipMalloc(reinterpret_cast<void**>(&m->arena), m->arena_bytes));
+    Builder real;
+    real.dry = false;
+    real.fill = !opt.skip_tensor_data;
+    real.base = m->arena;
+    real.side = &m->side_allocs;
+    if (real.fill) {
+        Q3_HIP(hipMalloc(reinterpret_cast<void**>(&real.staging), dry.max_staging * 2));
+        real.staging_elems = dry.max_staging;
+    }
+    try {
+        build_all(real, *m, main, have_codec ? &codec_t : nullptr, opt);
+    } catch (...) {
+        if (real.staging) (void)hipFree(real.staging);
+        throw;
+    }
+    Q3_HIP(hipDeviceSynchronize());
+    if (real.staging) Q3_HIP(hipFree(real.staging));
+    Q3_CHECK(real.off == dry.off, 7, "internal error: arena passes disagree");
+    return m;
+}
+
+}  // namespace q3

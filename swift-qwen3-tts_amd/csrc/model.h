@@ -1,0 +1,139 @@
+// model.h -- device-resident model: one contiguous weight arena in HBM plus typed views.
+//
+// Load path = Qwen3TTSModel.fromPretrained + sanitize + postLoadHook + sanitizeSpeechTokenizerWeights
+// (/root/reference/Sources/Qwen3TTS/Models/Qwen3.swift:1382-1495, 1219-1260, 1498-1750), re-hosted:
+// host mmap -> (GPU repack kernels) -> arena. The arena layout is a pure function of the config, so
+// replicas can receive it by one RCCL broadcast (q3tts_model_arena).
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "config.h"
+#include "safetensors.h"
+
+namespace q3 {
+
+struct LinearW {          // bf16 Linear in the streaming tile layout (gemm_decode.hip)
+    const uint16_t* w = nullptr;
+    const uint16_t* bias = nullptr;  // [N] or nullptr
+    int N = 0, K = 0;                // logical sizes
+    int Np = 0, Kp = 0;              // padded to 16 / 128
+};
+
+struct LayerW {
+    const uint16_t* ln1 = nullptr;
+    const uint16_t* ln2 = nullptr;
+    const uint16_t* qn = nullptr;
+    const uint16_t* kn = nullptr;
+    LinearW qkv;     // rows: q | k | v
+    LinearW o;
+    LinearW gateup;  // 16-row tiles interleaved: gate tile j, up tile j; N = intermediate
+    LinearW down;
+    int inter = 0, inter_p = 0;
+};
+
+struct StackW {
+    int hidden = 0, n_heads = 0, n_kv = 0, head_dim = 0;
+    float eps = 1e-6f, rope_base = 1e6f;
+    std::vector<LayerW> layers;
+    const uint16_t* final_norm = nullptr;
+    const uint16_t* rope_cos = nullptr;  // [max_pos][128] bf16
+    const uint16_t* rope_sin = nullptr;
+    int max_pos = 0;
+    int max_inter_p = 0;
+};
+
+struct ConvW {  // fp32 conv as GEMM: w[N][K][Cin]; transposed convs are stored in polyphase form
+    const float* w = nullptr;
+    const float* bias = nullptr;   // [N] or nullptr
+    const float* scale = nullptr;  // per-output-channel scale (LayerScale / ConvNeXt gamma) or nullptr
+    int Cin = 0, N = 0, K = 1, dil = 1;
+};
+struct SnakeW {
+    const float* ea = nullptr;  // exp(alpha)
+    const float* ib = nullptr;  // 1 / (exp(beta) + 1e-9)
+    int C = 0;
+};
+
+struct CodecW {
+    // RVQ (SpeechTokenizer.swift:175-227): codebooks [size][inner], output projections fused
+    const float* cb_first = nullptr;               // [semantic_size][inner]
+    std::vector<const float*> cb_rest;             // 15 x [codebook_size][inner]
+    const float* const* cb_rest_dev = nullptr;     // device array of the pointers above
+    int inner = 0;
+    ConvW rvq_out;   // [codebook_dim][1][2*inner]  (semantic | acoustic)
+    ConvW pre_conv;
+    ConvW t_in, t_out;
+    struct TLayer {
+        const float* ln1 = nullptr;
+        const float* ln2 = nullptr;
+        ConvW qkv, o, gateup, down;  // o and down carry the LayerScale as `scale`
+    };
+    std::vector<TLayer> tlayers;
+    const float* t_norm = nullptr;
+    struct Up {
+        ConvW tconv;                  // polyphase k=s transposed conv: N = s*C, K = 1
+        const float* dw_w = nullptr;  // depthwise [C][7]
+        const float* dw_b = nullptr;
+        const float* ln_w = nullptr;
+        const float* ln_b = nullptr;
+        ConvW pw1, pw2;               // pw2.scale = gamma
+        int stride = 2;
+    };
+    std::vector<Up> ups;
+    ConvW init_conv;
+    struct Res {
+        SnakeW act1, act2;
+        ConvW conv1, conv2;
+    };
+    struct Block {
+        SnakeW snake;
+        ConvW tconv;  // polyphase: N = s*Cout, K = 2
+        int stride = 1, Cout = 0;
+        Res res[3];
+    };
+    std::vector<Block> blocks;
+    SnakeW out_snake;
+    const float* out_w = nullptr;  // [1][7][C]
+    const float* out_b = nullptr;
+    int out_C = 0;
+};
+
+struct Model {
+    ModelConfig cfg;
+    int device = 0;
+    uint8_t* arena = nullptr;
+    size_t arena_bytes = 0;
+
+    StackW talker, cp;
+    const uint16_t* codec_emb = nullptr;  // [V][H]
+    const uint16_t* text_emb = nullptr;   // [TV'][TH]
+    const int32_t* token_map = nullptr;   // [text_vocab] or nullptr (pruned vocabulary)
+    int64_t text_emb_rows = 0;
+    LinearW fc1, fc2, codec_head, cp_proj;
+    bool has_cp_proj = false;
+    std::vector<LinearW> lm_head;           // 15
+    std::vector<const uint16_t*> cp_emb;    // 15 x [Vcp][H]
+    const uint16_t* const* cp_emb_dev = nullptr;
+    bool has_codec = false;
+    CodecW codec;
+    int64_t step_weight_bytes = 0;  // distinct weight bytes read by one frame step (roofline)
+    std::vector<void*> side_allocs; // pointer tables (absolute addresses; not part of the arena)
+
+    ~Model();
+};
+
+struct LoadOptions {
+    int device = 0;
+    int max_pos_talker = 4096;
+    bool skip_tensor_data = false;  // weights_from_broadcast
+};
+
+std::unique_ptr<Model> load_model(const std::string& dir, const LoadOptions& opt);
+
+// GPU repack helpers (repack.hip)
+void launch_tile_weights(const uint16_t* src, int N, int K, uint16_t* dst, int KC, int tile_off, int tile_stride,
+                         hipStream_t st);
+
+}  // namespace q3

@@ -1,0 +1,130 @@
+// safetensors.h -- mmap reader for *.safetensors directories (replaces MLX.loadArrays at
+// /root/reference/Sources/Qwen3TTS/Models/Qwen3.swift:1391-1399, 1473-1480). Header-only.
+#pragma once
+#include <dirent.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "json.h"
+
+namespace q3 {
+
+enum class DType { F32, BF16, F16, I32, U32, I64, U8, Unknown };
+
+inline size_t dtype_size(DType d) {
+    switch (d) {
+        case DType::F32: case DType::I32: case DType::U32: return 4;
+        case DType::BF16: case DType::F16: return 2;
+        case DType::I64: return 8;
+        case DType::U8: return 1;
+        default: return 0;
+    }
+}
+
+struct TensorView {
+    DType dtype = DType::Unknown;
+    std::vector<int64_t> shape;
+    const uint8_t* data = nullptr;
+    size_t nbytes = 0;
+    int64_t numel() const {
+        int64_t n = 1;
+        for (auto s : shape) n *= s;
+        return n;
+    }
+};
+
+class SafetensorsDir {
+  public:
+    SafetensorsDir() = default;
+    SafetensorsDir(const SafetensorsDir&) = delete;
+    SafetensorsDir& operator=(const SafetensorsDir&) = delete;
+    ~SafetensorsDir() {
+        for (auto& m : maps_) {
+            munmap(m.base, m.size);
+        }
+    }
+
+    // Loads every *.safetensors in `dir` (sorted by name; later files override earlier keys, like
+    // the reference's weights.merge(...) { _, new in new }).
+    void open_dir(const std::string& dir) {
+        std::vector<std::string> files;
+        DIR* d = opendir(dir.c_str());
+        Q3_CHECK(d != nullptr, 6, "cannot open directory " + dir);
+        while (dirent* e = readdir(d)) {
+            std::string n = e->d_name;
+            if (n.size() > 12 && n.substr(n.size() - 12) == ".safetensors") files.push_back(dir + "/" + n);
+        }
+        closedir(d);
+        std::sort(files.begin(), files.end());
+        for (auto& f : files) open_file(f);
+    }
+
+    bool has(const std::string& k) const { return t_.count(k) != 0; }
+    const TensorView& at(const std::string& k) const {
+        auto it = t_.find(k);
+        Q3_CHECK(it != t_.end(), 6, "missing tensor '" + k + "' in checkpoint");
+        return it->second;
+    }
+    const std::map<std::string, TensorView>& all() const { return t_; }
+
+  private:
+    struct Map { void* base; size_t size; };
+    std::vector<Map> maps_;
+    std::map<std::string, TensorView> t_;
+
+    static DType parse_dtype(const std::string& s) {
+        if (s == "F32") return DType::F32;
+        if (s == "BF16") return DType::BF16;
+        if (s == "F16") return DType::F16;
+        if (s == "I32") return DType::I32;
+        if (s == "U32") return DType::U32;
+        if (s == "I64") return DType::I64;
+        if (s == "U8") return DType::U8;
+        return DType::Unknown;
+    }
+
+    void open_file(const std::string& path) {
+        int fd = ::open(path.c_str(), O_RDONLY);
+        Q3_CHECK(fd >= 0, 6, "cannot open " + path);
+        struct stat st;
+        fstat(fd, &st);
+        size_t size = size_t(st.st_size);
+        Q3_CHECK(size >= 8, 6, "truncated safetensors file " + path);
+        void* base = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+        ::close(fd);
+        Q3_CHECK(base != MAP_FAILED, 6, "mmap failed for " + path);
+        maps_.push_back({base, size});
+        const uint8_t* p = static_cast<const uint8_t*>(base);
+        uint64_t hlen;
+        std::memcpy(&hlen, p, 8);
+        Q3_CHECK(8 + hlen <= size, 6, "bad safetensors header in " + path);
+        Json hdr = JsonParser(reinterpret_cast<const char*>(p + 8), size_t(hlen)).parse();
+        const uint8_t* data = p + 8 + hlen;
+        for (auto& kv : hdr.obj) {
+            if (kv.first == "__metadata__") continue;
+            TensorView tv;
+            tv.dtype = parse_dtype(kv.second.s("dtype", ""));
+            const Json* sh = kv.second.get("shape");
+            if (sh)
+                for (auto& e : sh->arr) tv.shape.push_back(int64_t(e.num));
+            const Json* off = kv.second.get("data_offsets");
+            Q3_CHECK(off && off->arr.size() == 2, 6, "bad data_offsets for " + kv.first);
+            uint64_t a = uint64_t(off->arr[0].num), b = uint64_t(off->arr[1].num);
+            Q3_CHECK(8 + hlen + b <= size && a <= b, 6, "tensor out of file bounds: " + kv.first);
+            tv.data = data + a;
+            tv.nbytes = size_t(b - a);
+            Q3_CHECK(tv.dtype == DType::Unknown || size_t(tv.numel()) * dtype_size(tv.dtype) == tv.nbytes, 6,
+                     "shape/bytes mismatch for " + kv.first);
+            t_[kv.first] = tv;
+        }
+    }
+};
+
+}  // namespace q3

@@ -1,0 +1,322 @@
+"""Host-side mirror of the reference's public surface on top of the C ABI.
+
+Names and argument meaning follow /root/reference/Sources/Qwen3TTS/Models/Qwen3.swift
+(`Qwen3TTSModel.fromPretrained` :1382, `generate` :1291-1301, `supportedSpeakers` :965-971) and
+Qwen3+Streaming.swift (`generateStream` :8-18) with the event enum of
+Core/GenerationTypes.swift:51-58. Tokenisation stays outside the engine like in the reference
+(swift-transformers there): callers pass token ids, or a `tokenizer` callable text -> ids.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Callable, Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib as L
+
+
+class Qwen3TTSError(RuntimeError):
+    """AudioGenerationError (GenerationTypes.swift:63-84); `.status` is the q3tts_status code."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(message)
+        self.status = status
+
+
+@dataclass
+class AudioGenerationInfo:  # GenerationTypes.swift:15-21
+    prompt_token_count: int
+    generation_token_count: int
+    prefill_time: float
+    generate_time: float
+    tokens_per_second: float
+    peak_memory_usage: float
+
+
+@dataclass
+class GenerationRequest:
+    """One utterance after tokenisation (see q3tts_request in include/q3tts.h)."""
+    text_ids: Sequence[int]
+    target_token_count: int
+    instruct_ids: Optional[Sequence[int]] = None
+    speaker: Optional[str] = None
+    language: str = "auto"
+    max_tokens: int = 2048
+
+
+@dataclass
+class GenerationResult:
+    audio: np.ndarray  # float32 [n_samples] @ 24 kHz
+    codes: np.ndarray  # int32 [n_frames][16]
+    info: AudioGenerationInfo
+    status: int = 0
+
+
+def chat_template_ids(tokenizer: Callable[[str], List[int]], text: str, instruct: Optional[str] = None) -> dict:
+    """The three tokenisations the reference performs (Qwen3.swift:274-275, 364-365, 822)."""
+    out = {"text_ids": tokenizer(f"<|im_start|>assistant\n{text}<|im_end|>\n<|im_start|>assistant\n"),
+           "target_token_count": len(tokenizer(text))}
+    if instruct:
+        out["instruct_ids"] = tokenizer(f"<|im_start|>user\n{instruct}<|im_end|>\n")
+    return out
+
+
+class Qwen3TTSModel:
+    def __init__(self, handle: C.c_void_p, lib):
+        self._h = handle
+        self._lib = lib
+        info = L.ModelInfo()
+        self._check(lib.q3tts_model_get_info(self._h, C.byref(info)))
+        self.info = info
+        self.tokenizer: Optional[Callable[[str], List[int]]] = None
+
+    # -- loading ---------------------------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, model_path: str, device: int = 0, max_batch: int = 1, max_frames: int = 2048,
+                        max_prompt: int = 512, use_graph: bool = True,
+                        weights_from_broadcast: bool = False) -> "Qwen3TTSModel":
+        lib = L.lib()
+        o = L.LoadOpts()
+        lib.q3tts_default_load_opts(C.byref(o))
+        o.device, o.max_batch, o.max_frames, o.max_prompt = device, max_batch, max_frames, max_prompt
+        o.use_graph = 1 if use_graph else 0
+        o.weights_from_broadcast = 1 if weights_from_broadcast else 0
+        h = C.c_void_p()
+        st = lib.q3tts_model_load(model_path.encode(), C.byref(o), C.byref(h))
+        if st != 0:
+            raise Qwen3TTSError(st, (lib.q3tts_last_error(None) or b"").decode())
+        return cls(h, lib)
+
+    def close(self):
+        if self._h:
+            self._lib.q3tts_model_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st: int):
+        if st != 0:
+            raise Qwen3TTSError(st, (self._lib.q3tts_last_error(self._h) or b"").decode())
+
+    # -- properties (Qwen3.swift:1262-1271, 965-971, 1210-1214) -----------------------------------
+    @property
+    def sample_rate(self) -> int:
+        return self.info.sample_rate
+
+    @property
+    def tts_model_type(self) -> str:
+        return self.info.tts_model_type.decode()
+
+    @property
+    def supported_speakers(self) -> List[str]:
+        n = self._lib.q3tts_model_num_speakers(self._h)
+        return [self._lib.q3tts_model_speaker_name(self._h, i).decode() for i in range(n)]
+
+    @property
+    def supports_voice_cloning(self) -> bool:
+        return bool(self.info.supports_voice_cloning)
+
+    def arena(self) -> Tuple[int, int]:
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self._lib.q3tts_model_arena(self._h, C.byref(p), C.byref(n)))
+        return int(p.value), int(n.value)
+
+    def last_timing(self) -> L.Timing:
+        t = L.Timing()
+        self._lib.q3tts_last_timing(self._h, C.byref(t))
+        return t
+
+    # -- generation --------------------------------------------------------------------------------
+    def _marshal(self, reqs: Sequence[GenerationRequest]):
+        arr = (L.Request * len(reqs))()
+        keep = []
+        for i, r in enumerate(reqs):
+            t = np.ascontiguousarray(r.text_ids, np.int32)
+            keep.append(t)
+            arr[i].text_ids = t.ctypes.data_as(L.i32p)
+            arr[i].n_text_ids = t.size
+            if r.instruct_ids is not None and len(r.instruct_ids):
+                ii = np.ascontiguousarray(r.instruct_ids, np.int32)
+                keep.append(ii)
+                arr[i].instruct_ids = ii.ctypes.data_as(L.i32p)
+                arr[i].n_instruct_ids = ii.size
+            arr[i].target_token_count = int(r.target_token_count)
+            arr[i].speaker = r.speaker.encode() if r.speaker is not None else None
+            arr[i].language = (r.language or "auto").encode()
+            arr[i].max_tokens = int(r.max_tokens)
+        return arr, keep
+
+    @staticmethod
+    def _sampling(temperature, top_k, top_p, repetition_penalty, seed, force_frames) -> L.Sampling:
+        s = L.Sampling()
+        s.temperature, s.top_k, s.top_p = temperature, top_k, top_p
+        s.repetition_penalty, s.seed, s.force_frames = repetition_penalty, seed, force_frames
+        return s
+
+    def generate_batch(self, reqs: Sequence[GenerationRequest], temperature: float = 0.9, top_k: int = 50,
+                       top_p: float = 1.0, repetition_penalty: float = 1.05, seed: int = 0, force_frames: int = 0,
+                       on_event: Optional[Callable[[int, str, object], None]] = None) -> List[GenerationResult]:
+        """n utterances in one call (row-independent). `on_event(request_index, kind, payload)` receives
+        ("token", id) / ("info", AudioGenerationInfo) / ("audio", ndarray) in the reference's order."""
+        arr, keep = self._marshal(reqs)
+        s = self._sampling(temperature, top_k, top_p, repetition_penalty, seed, force_frames)
+        res = (L.Result * len(reqs))()
+
+        def _cb(_user, evp):
+            ev = evp.contents
+            if ev.kind == 0:
+                on_event(ev.request_index, "token", int(ev.token))
+            elif ev.kind == 1:
+                i = ev.info.contents
+                on_event(ev.request_index, "info", AudioGenerationInfo(
+                    i.prompt_token_count, i.generation_token_count, i.prefill_time, i.generate_time,
+                    i.tokens_per_second, i.peak_memory_usage))
+            else:
+                on_event(ev.request_index, "audio", np.ctypeslib.as_array(ev.pcm, shape=(ev.n_samples,)).copy())
+
+        cb = L.EVENT_CB(_cb) if on_event else C.cast(None, L.EVENT_CB)
+        st = self._lib.q3tts_generate(self._h, arr, len(reqs), C.byref(s), cb, None, res)
+        try:
+            self._check(st)
+            out = []
+            for i in range(len(reqs)):
+                r = res[i]
+                inf = r.info
+                info = AudioGenerationInfo(inf.prompt_token_count, inf.generation_token_count, inf.prefill_time,
+                                           inf.generate_time, inf.tokens_per_second, inf.peak_memory_usage)
+                if r.status != 0:
+                    out.append(GenerationResult(np.zeros(0, np.float32), np.zeros((0, 16), np.int32), info, r.status))
+                    continue
+                audio = np.ctypeslib.as_array(r.pcm, shape=(r.n_samples,)).copy()
+                codes = np.ctypeslib.as_array(r.codes, shape=(r.n_frames, 16)).copy()
+                out.append(GenerationResult(audio, codes, info, 0))
+            return out
+        finally:
+            self._lib.q3tts_result_free(res, len(reqs))
+            del keep
+
+    def _request_from_text(self, text, speaker, instruct, language, max_tokens, text_ids, instruct_ids,
+                           target_token_count) -> GenerationRequest:
+        if text_ids is None:
+            if self.tokenizer is None:
+                raise Qwen3TTSError(1, "Model not initialized: Tokenizer not loaded")  # Qwen3.swift:265-267
+            t = chat_template_ids(self.tokenizer, text, instruct)
+            text_ids, target_token_count = t["text_ids"], t["target_token_count"]
+            instruct_ids = t.get("instruct_ids")
+        return GenerationRequest(text_ids, int(target_token_count or 0), instruct_ids, speaker, language, max_tokens)
+
+    def generate(self, text: Optional[str] = None, speaker: Optional[str] = None, instruct: Optional[str] = None,
+                 language: str = "auto", temperature: float = 0.9, top_k: int = 50, top_p: float = 1.0,
+                 repetition_penalty: float = 1.05, max_tokens: int = 2048, *, seed: int = 0,
+                 text_ids: Optional[Sequence[int]] = None, instruct_ids: Optional[Sequence[int]] = None,
+                 target_token_count: Optional[int] = None) -> np.ndarray:
+        """generate(text:speaker:instruct:language:temperature:topK:topP:repetitionPenalty:maxTokens:)
+        (Qwen3.swift:1291-1301). Returns float32 samples at 24 kHz."""
+        req = self._request_from_text(text, speaker, instruct, language, max_tokens, text_ids, instruct_ids,
+                                      target_token_count)
+        r = self.generate_batch([req], temperature, top_k, top_p, repetition_penalty, seed)[0]
+        if r.status != 0:
+            raise Qwen3TTSError(r.status, "Generation failed: No tokens generated")
+        return r.audio
+
+    def generate_stream(self, text: Optional[str] = None, speaker: Optional[str] = None,
+                        instruct: Optional[str] = None, language: str = "auto", temperature: float = 0.9,
+                        top_k: int = 50, top_p: float = 1.0, repetition_penalty: float = 1.05,
+                        max_tokens: int = 2048, *, seed: int = 0, text_ids=None, instruct_ids=None,
+                        target_token_count=None) -> Iterator[Tuple[str, object]]:
+        """generateStream (Qwen3+Streaming.swift:8-125): yields ("token", id)..., ("info", info), ("audio", pcm)."""
+        req = self._request_from_text(text, speaker, instruct, language, max_tokens, text_ids, instruct_ids,
+                                      target_token_count)
+        events: List[Tuple[str, object]] = []
+        res = self.generate_batch([req], temperature, top_k, top_p, repetition_penalty, seed,
+                                  on_event=lambda i, k, p: events.append((k, p)))
+        if res[0].status != 0:
+            raise Qwen3TTSError(res[0].status, "Generation failed: No tokens generated")
+        yield from events
+
+    # -- codec only ------------------------------------------------------------------------------
+    def codec_decode(self, codes: np.ndarray, n_frames: Optional[Sequence[int]] = None):
+        """Qwen3TTSSpeechTokenizer.decode (SpeechTokenizer.swift:823-836). codes [B][F][16] int32."""
+        codes = np.ascontiguousarray(codes, np.int32)
+        if codes.ndim == 2:
+            codes = codes[None]
+        B, F, _ = codes.shape
+        nf = np.ascontiguousarray(n_frames if n_frames is not None else [F] * B, np.int32)
+        up = self.info.samples_per_frame
+        pcm = np.zeros((B, F * up), np.float32)
+        lens = np.zeros(B, np.int64)
+        self._check(self._lib.q3tts_codec_decode(self._h, codes.ctypes.data_as(L.i32p), nf.ctypes.data_as(L.i32p), B, F,
+                                                 pcm.ctypes.data_as(L.f32p), lens.ctypes.data_as(C.POINTER(C.c_int64))))
+        return pcm, lens
+
+    # -- test hooks -------------------------------------------------------------------------------
+    def debug_prepare_inputs(self, req: GenerationRequest):
+        arr, keep = self._marshal([req])
+        H = self.info.hidden_size
+        cap = 1024
+        ie = np.zeros((cap, H), np.uint16)
+        tr = np.zeros((cap, H), np.uint16)
+        pad = np.zeros((H,), np.uint16)
+        n1, n2 = C.c_int32(), C.c_int32()
+        self._check(self._lib.q3tts_debug_prepare_inputs(self._h, arr, ie.ctypes.data_as(L.u16p), cap, C.byref(n1),
+                                                         tr.ctypes.data_as(L.u16p), cap, C.byref(n2),
+                                                         pad.ctypes.data_as(L.u16p)))
+        del keep
+        return ie[: n1.value].copy(), tr[: n2.value].copy(), pad
+
+    def debug_generate_forced(self, reqs: Sequence[GenerationRequest], forced_codes: np.ndarray, temperature=0.0,
+                              top_k=50, top_p=1.0, repetition_penalty=1.05, seed=0):
+        arr, keep = self._marshal(reqs)
+        n = len(reqs)
+        forced = np.ascontiguousarray(forced_codes, np.int32).reshape(n, -1, 16)
+        F = forced.shape[1]
+        V, Vc, G = self.info.vocab_size, self.info.cp_vocab_size, self.info.num_code_groups
+        tl = np.zeros((n, F, V), np.uint16)
+        cl = np.zeros((n, F, G - 1, Vc), np.uint16)
+        sampled = np.zeros((n, F, 16), np.int32)
+        s = self._sampling(temperature, top_k, top_p, repetition_penalty, seed, 0)
+        self._check(self._lib.q3tts_debug_generate_forced(
+            self._h, arr, n, C.byref(s), forced.ctypes.data_as(L.i32p), F, tl.ctypes.data_as(L.u16p),
+            cl.ctypes.data_as(L.u16p), sampled.ctypes.data_as(L.i32p)))
+        del keep
+        return tl, cl, sampled
+
+    def debug_sample(self, logits: np.ndarray, temperature=0.9, top_k=50, top_p=1.0, repetition_penalty=1.0,
+                     seed=0, seen: Optional[np.ndarray] = None, suppress=(0, 0), eos_id=-1, row0=0, draw=0,
+                     mask_eos=False):
+        logits = np.ascontiguousarray(logits, np.uint16)
+        rows, V = logits.shape
+        s = self._sampling(temperature, top_k, top_p, repetition_penalty, seed, 1 if mask_eos else 0)
+        toks = np.zeros(rows, np.int32)
+        sp = np.ascontiguousarray(seen, np.uint8).ctypes.data_as(L.u8p) if seen is not None else None
+        self._check(self._lib.q3tts_debug_sample(self._h, logits.ctypes.data_as(L.u16p), rows, V, C.byref(s), sp,
+                                                 suppress[0], suppress[1], eos_id, row0, draw,
+                                                 toks.ctypes.data_as(L.i32p)))
+        return toks
+
+    def debug_linear(self, x: np.ndarray, W: np.ndarray, bias: Optional[np.ndarray] = None) -> np.ndarray:
+        x = np.ascontiguousarray(x, np.uint16)
+        W = np.ascontiguousarray(W, np.uint16)
+        M, K = x.shape
+        N = W.shape[0]
+        y = np.zeros((M, N), np.uint16)
+        bp = np.ascontiguousarray(bias, np.uint16).ctypes.data_as(L.u16p) if bias is not None else None
+        self._check(self._lib.q3tts_debug_linear(self._h, x.ctypes.data_as(L.u16p), W.ctypes.data_as(L.u16p), bp, M, K, N,
+                                                 y.ctypes.data_as(L.u16p)))
+        return y
+
+    def debug_codec_stage(self, codes: np.ndarray, stage: str) -> np.ndarray:
+        codes = np.ascontiguousarray(codes, np.int32).reshape(-1, 16)
+        F = codes.shape[0]
+        cap = F * self.info.samples_per_frame * 128
+        out = np.zeros(cap, np.float32)
+        T, Cc = C.c_int32(), C.c_int32()
+        self._check(self._lib.q3tts_debug_codec_stage(self._h, codes.ctypes.data_as(L.i32p), F, stage.encode(),
+                                                      out.ctypes.data_as(L.f32p), cap, C.byref(T), C.byref(Cc)))
+        return out[: T.value * Cc.value].reshape(T.value, Cc.value).copy()
