@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: codec tokens/s + real-time factor @24 kHz (BASELINE.json).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[2], the config the metric is quoted on): Qwen3-TTS-1.7B-VoiceDesign
+bf16, batch 32 fixed-length synthetic prompts per GPU, 200 codec frames per utterance (EOS masked),
+reference sampling defaults (T=0.9, top-k 50, rep-penalty 1.05), prompt assembly + prefill + AR
+decode (hipGraph frame step) + codec decode to 24 kHz PCM. One "step" = one such batch end to end.
+Utterances are batch-sharded: every rank holds a full replica (weights broadcast over RCCL at load)
+and decodes its own 32 rows; there is no data-path collective, scaling "weak".
+
+Prints ONE JSON line on rank 0. `roofline` describes the hipGraph-captured frame step (the unit the
+AR loop launches): algorithmic bytes = distinct weight bytes + KV bytes read, over the average
+frame-step duration measured with HIP events on the engine's stream. `cpu_baseline` times the oracle
+(oracle/, a C restatement -- kind "port") on the host cores for a bounded sample of the same
+workload (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "swift-qwen3-tts_amd"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FRAME_SECONDS = 0.08   # 1 codec frame = 1920 samples @ 24 kHz
+
+
+def shard_rows(total_rows: int, rank: int, world: int):
+    """Contiguous batch shard of `total_rows` utterances for `rank`."""
+    per = total_rows // world
+    rem = total_rows % world
+    lo = rank * per + min(rank, rem)
+    return lo, lo + per + (1 if rank < rem else 0)
+
+
+def broadcast_weights(dist, arena_tensor, src: int = 0) -> None:
+    """The only collective of the whole job: rank `src` holds the loaded weight arena, replicas receive
+    it in one broadcast (RCCL over xGMI on the GPU box, gloo in the CPU tests). No per-step collectives."""
+    dist.broadcast(arena_tensor, src=src)
+
+
+def reduce_job_stats(dist, elapsed_s: float, frames_done: int, device):
+    """Timing contract: elapsed = MAX over ranks, frames = SUM over ranks."""
+    import torch
+    t = torch.tensor([elapsed_s], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    f = torch.tensor([frames_done], device=device, dtype=torch.int64)
+    dist.all_reduce(f, op=dist.ReduceOp.SUM)
+    return float(t.item()), int(f.item())
+
+
+def build_requests(preset: str, lo: int, hi: int, n_text: int, n_instruct: int):
+    from qwen3tts import GenerationRequest, synth
+    reqs = []
+    for row in range(lo, hi):
+        p = synth.synthetic_prompt(row, n_text=n_text, n_instruct=n_instruct)
+        reqs.append(GenerationRequest(p["text_ids"], p["target_token_count"], p.get("instruct_ids"),
+                                      "aiden" if preset == "0.6b" else None, "english"))
+    return reqs
+
+
+def ensure_checkpoint(preset: str, rank: int, dist) -> str:
+    from qwen3tts import synth
+    d = os.environ.get("Q3TTS_BENCH_CKPT", f"/tmp/q3tts_synth_{preset}_seed1234")
+    marker = os.path.join(d, ".complete")
+    if rank == 0 and not os.path.exists(marker):
+        synth.write_checkpoint(d, preset, seed=1234)
+        open(marker, "w").write("ok")
+    if dist is not None:
+        dist.barrier()
+    return d
+
+
+def cpu_baseline(ckpt: str, preset: str, n_text: int, n_instruct: int, frames: int) -> dict:
+    """Oracle (CPU restatement, OpenMP) on a bounded sample: batch 1, same prompt shape, `frames`
+    frames, greedy, end to end (prompt assembly + prefill + AR loop + codec decode)."""
+    from oracle import oracle as O
+    from qwen3tts import synth
+    om = O.OracleModel(ckpt)
+    p = synth.synthetic_prompt(0, n_text=n_text, n_instruct=n_instruct)
+    req = O.Request(text_ids=p["text_ids"], target_token_count=p["target_token_count"],
+                    instruct_ids=p.get("instruct_ids"), speaker="aiden" if preset == "0.6b" else None,
+                    language="english")
+    t0 = time.time()
+    tr = om.generate_codes(req, O.Sampling(temperature=0.0, force_frames=frames))
+    t1 = time.time()
+    om.codec_decode(tr.codes)
+    t2 = time.time()
+    return {"value": frames / (t2 - t0), "unit": "frames/s", "cores": int(O.lib().o_num_threads()), "kind": "port",
+            "sample": f"oracle (C restatement, OpenMP), batch 1, {frames} frames greedy end-to-end: "
+                      f"AR {t1 - t0:.1f}s + codec {t2 - t1:.1f}s; MLX-CPU reference unavailable offline"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--preset", default="1.7b", choices=["1.7b", "0.6b"])
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--frames", type=int, default=200)
+    ap.add_argument("--n-text", type=int, default=32)
+    ap.add_argument("--cpu-frames", type=int, default=6)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--greedy", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (profiling)")
+    ap.add_argument("--streams", type=int, default=0, help="lanes per GPU (0 = engine default)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        torch.cuda.set_device(local)
+        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist = dist_mod
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for N > 1"
+
+    from qwen3tts import Qwen3TTSModel
+    n_instruct = 16 if args.preset == "1.7b" else 0
+    ckpt = ensure_checkpoint(args.preset, rank, dist)
+    B = args.batch
+    # rank 0 reads the checkpoint; replicas receive the weight arena by one RCCL broadcast over xGMI
+    model = Qwen3TTSModel.from_pretrained(ckpt, device=local, max_batch=B, max_frames=args.frames + 8, max_prompt=128,
+                                          use_graph=not args.no_graph, n_streams=args.streams,
+                                          weights_from_broadcast=(world > 1 and rank != 0))
+    if world > 1:
+        import torch
+        ptr, nbytes = model.arena()
+
+        class _Arena:  # zero-copy view of the engine's weight arena for torch.distributed
+            __cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+        arena = torch.as_tensor(_Arena(), device=torch.device("cuda", local))
+        broadcast_weights(dist, arena, src=0)
+        torch.cuda.synchronize()
+    lo, hi = shard_rows(B * world, rank, world)
+    reqs = build_requests(args.preset, lo, hi, args.n_text, n_instruct)
+    temp = 0.0 if args.greedy else 0.9
+
+    def step():
+        return model.generate_batch(reqs, temperature=temp, top_k=50, top_p=1.0, repetition_penalty=1.05, seed=1234,
+                                    force_frames=args.frames)
+
+    def sync_all():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    dec_ms = pre_ms = codec_ms = 0.0
+    frame_steps = 0
+    kv_bytes = 0
+    frames_done = 0
+    for _ in range(args.steps):
+        res = step()  # generate_batch returns after the PCM is on the host (stream-synchronised)
+        tm = model.last_timing()
+        pre_ms += tm.prefill_ms
+        dec_ms += tm.decode_ms
+        codec_ms += tm.codec_ms
+        frame_steps += tm.frame_steps
+        kv_bytes += tm.kv_bytes_read
+        frames_done += sum(r.codes.shape[0] for r in res)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        elapsed, frames_done = reduce_job_stats(dist, elapsed, frames_done, torch.device("cuda", local))
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    value = frames_done / elapsed
+    step_ms = dec_ms / max(frame_steps, 1)
+    algo_bytes = model.info.weight_bytes + kv_bytes / max(frame_steps, 1)
+    achieved = algo_bytes / (step_ms * 1e-3) / 1e9
+    out = {
+        "metric": "codec_tokens_per_s", "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"Qwen3-TTS-{args.preset.upper()} bf16, batch {B}/GPU x {args.frames} frames, "
+                               f"{args.n_text} text + {n_instruct} instruct tokens, T={temp} top-k 50, "
+                               "prompt assembly + prefill + hipGraph AR decode + fp32 codec decode -> 24 kHz PCM",
+                   "batch_per_gpu": B, "frames_per_utterance": args.frames, "parallelism": f"batch-shard x{world}"},
+        "rtf_audio_s_per_wall_s": value * FRAME_SECONDS, "rtf_wall_s_per_audio_s": 1.0 / (value * FRAME_SECONDS),
+        "rtf_per_utterance": value * FRAME_SECONDS / (B * world),
+        "phase_ms_per_step": {"prefill": pre_ms / args.steps, "ar_decode": dec_ms / args.steps,
+                              "codec_decode": codec_ms / args.steps},
+        "roofline": {"bound": "hbm", "kernel": "frame_step (hipGraph: talker step + 16 code-predictor passes + samplers)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": step_ms},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(ckpt, args.preset, args.n_text, n_instruct, args.cpu_frames)
+    if dist is not None:
+        dist.destroy_process_group()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -49,6 +49,8 @@ typedef struct {
     int32_t weights_from_broadcast; /* 1: allocate the weight arena but do not read tensor data from
                                        disk; the caller fills it (RCCL broadcast from rank 0) via
                                        q3tts_model_arena before the first generate */
+    int32_t n_streams;  /* lanes the batch is split over (own HIP stream + hipGraph + host thread each);
+                           0 = default (1). Results do not depend on it (rows are independent) */
 } q3tts_load_opts;
 
 void q3tts_default_load_opts(q3tts_load_opts* o);

@@ -4,10 +4,10 @@
 
 #include "engine.h"
 
-using q3::Engine;
+using q3::EngineGroup;
 
 struct q3tts_model {
-    std::unique_ptr<Engine> eng;
+    std::unique_ptr<EngineGroup> eng;
 };
 
 namespace {
@@ -40,6 +40,7 @@ void q3tts_default_load_opts(q3tts_load_opts* o) {
     o->max_prompt = 512;
     o->use_graph = 1;
     o->weights_from_broadcast = 0;
+    o->n_streams = 0;
 }
 
 void q3tts_default_sampling(q3tts_sampling* s) {  // Qwen3.swift:1296-1299
@@ -70,7 +71,7 @@ q3tts_status q3tts_model_load(const char* model_dir, const q3tts_load_opts* opts
         lo.skip_tensor_data = o.weights_from_broadcast != 0;
         auto model = q3::load_model(model_dir, lo);
         auto h = std::make_unique<q3tts_model>();
-        h->eng = std::make_unique<Engine>(std::move(model), o);
+        h->eng = std::make_unique<EngineGroup>(std::move(model), o);
         *out = h.release();
     });
 }
@@ -151,7 +152,8 @@ q3tts_status q3tts_codec_decode(q3tts_model* m, const int32_t* codes, const int3
                                 int32_t max_frames, float* pcm, int64_t* audio_lengths) {
     return guarded(m, [&] {
         Q3_CHECK(m && codes && n_frames && pcm && audio_lengths, 3, "Invalid input: null argument");
-        m->eng->codec_decode(codes, n_frames, batch, max_frames, pcm, audio_lengths);
+        m->eng->lane0().codec_decode(codes, n_frames, batch, max_frames, pcm, audio_lengths);
+        m->eng->timing.codec_ms = m->eng->lane0().timing.codec_ms;
     });
 }
 
@@ -166,7 +168,7 @@ q3tts_status q3tts_debug_prepare_inputs(q3tts_model* m, const q3tts_request* req
                                         int32_t* n_trailing, uint16_t* tts_pad) {
     return guarded(m, [&] {
         Q3_CHECK(m && req && input_embeds && n_prompt && trailing && n_trailing && tts_pad, 3, "Invalid input: null argument");
-        m->eng->debug_prepare_inputs(*req, input_embeds, cap_prompt, n_prompt, trailing, cap_trailing, n_trailing, tts_pad);
+        m->eng->lane0().debug_prepare_inputs(*req, input_embeds, cap_prompt, n_prompt, trailing, cap_trailing, n_trailing, tts_pad);
     });
 }
 
@@ -195,7 +197,7 @@ q3tts_status q3tts_debug_sample(q3tts_model* m, const uint16_t* logits, int32_t 
                                 int32_t suppress_hi, int32_t eos_id, uint32_t row0, uint32_t draw, int32_t* tokens) {
     return guarded(m, [&] {
         Q3_CHECK(m && logits && sampling && tokens, 3, "Invalid input: null argument");
-        m->eng->debug_sample(logits, rows, V, *sampling, seen, suppress_lo, suppress_hi, eos_id, row0, draw, tokens);
+        m->eng->lane0().debug_sample(logits, rows, V, *sampling, seen, suppress_lo, suppress_hi, eos_id, row0, draw, tokens);
     });
 }
 
@@ -203,7 +205,7 @@ q3tts_status q3tts_debug_linear(q3tts_model* m, const uint16_t* x, const uint16_
                                 int32_t K, int32_t N, uint16_t* y) {
     return guarded(m, [&] {
         Q3_CHECK(m && x && W && y, 3, "Invalid input: null argument");
-        m->eng->debug_linear(x, W, bias, M, K, N, y);
+        m->eng->lane0().debug_linear(x, W, bias, M, K, N, y);
     });
 }
 
@@ -211,7 +213,7 @@ q3tts_status q3tts_debug_codec_stage(q3tts_model* m, const int32_t* codes, int32
                                      float* out, int64_t cap_floats, int32_t* T, int32_t* C) {
     return guarded(m, [&] {
         Q3_CHECK(m && codes && stage && out && T && C && n_frames > 0, 3, "Invalid input: null argument");
-        m->eng->debug_codec_stage(codes, n_frames, stage, out, cap_floats, T, C);
+        m->eng->lane0().debug_codec_stage(codes, n_frames, stage, out, cap_floats, T, C);
     });
 }
 

@@ -46,6 +46,17 @@ inline bf16_t f32_to_bf16_host(float f) {
 }
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Fragment-major ("tiled") activation layout. Every GEMM x operand [rows][K] (K % 128 == 0) is
+// stored so that the 64 lanes of a wave read one MFMA B fragment as 1 KiB contiguous:
+//   block (kc = k/128, mb = m/16, i = (k/8)%4) holds [lane = ((k/32)%4)*16 + m%16][k%8].
+// MBL = row blocks of the allocation (padded batch / 16). Element offset of (m, k):
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline size_t act_tiled_offset(int m, int k, int MBL) {
+    return (((size_t(k >> 7) * MBL + (m >> 4)) * 4 + ((k >> 3) & 3)) * 64 + (((k >> 5) & 3) * 16 + (m & 15))) * 8 + (k & 7);
+}
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 }  // namespace q3

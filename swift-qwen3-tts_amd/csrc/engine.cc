@@ -5,6 +5,7 @@
 #include <cctype>
 #include <chrono>
 #include <cmath>
+#include <thread>
 
 #include "codec.h"
 
@@ -32,7 +33,7 @@ struct Bump {
 };
 }  // namespace
 
-Engine::Engine(std::unique_ptr<Model> model, const q3tts_load_opts& opts) : m_(std::move(model)), opts_(opts) {
+Engine::Engine(Model* model, const q3tts_load_opts& opts) : m_(model), opts_(opts) {
     Q3_HIP(hipSetDevice(m_->device));
     Q3_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
     for (auto& e : ev_) Q3_HIP(hipEventCreate(&e));
@@ -137,19 +138,22 @@ int Engine::pick_split(int tiles, int chunks) const {
     return best;
 }
 
-void Engine::gemm(const LinearW& L, const uint16_t* x, int ldx, int M, int epi, uint16_t* y, int ldy, bool silu, int S) {
+void Engine::gemm(const LinearW& L, const uint16_t* x, int xMB, int M, int epi, uint16_t* y, int ldy, int yMB, bool silu,
+                  int S) {
     GemmArgs a{};
     a.W = L.w;
     a.x = x;
-    a.ldx = ldx;
+    a.xMB = xMB;
     a.M = M;
     a.Mpad = int(align_up(size_t(M), 16));
-    a.N = (epi == 2) ? L.Np : L.Np;
+    a.N = L.Np;
     a.K = L.Kp;
     a.S = S;
     a.epi = epi;
     a.y = y;
     a.ldy = ldy;
+    a.y_tiled = yMB > 0 ? 1 : 0;  // yMB > 0: fragment-major output (it feeds another GEMM)
+    a.yMB = yMB;
     a.bias = L.bias;
     a.act_silu = silu ? 1 : 0;
     a.part = part_;
@@ -160,37 +164,37 @@ void Engine::enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, 
                             const int32_t* block_table, int max_pages, const int32_t* kv_len, const uint8_t* active,
                             const uint16_t* final_w, bool need_final) {
     const int H = s.hidden, Mp = int(align_up(size_t(B), 16));
-    const int qd = s.n_heads * kHeadDim;
+    const int MBL = Mp_ / 16;  // row blocks of every fragment-major activation buffer of this lane
     int prevS = 0;  // splits of the pending down_proj partials
     for (size_t l = 0; l < s.layers.size(); ++l) {
         const LayerW& L = s.layers[l];
         ResidNormArgs n1{};
         n1.h = w.h; n1.ldh = H; n1.part = prevS ? part_ : nullptr; n1.S = prevS; n1.Mpad = Mp;
-        n1.w = L.ln1; n1.eps = s.eps; n1.xn = w.xn; n1.ldxn = H; n1.M = B; n1.H = H;
+        n1.w = L.ln1; n1.eps = s.eps; n1.xn = w.xn; n1.xnMB = MBL; n1.M = B; n1.H = H;
         launch_resid_norm(n1, st_);
-        gemm(L.qkv, w.xn, H, B, 0, w.qkv, w.ld_qkv, false, 1);
+        gemm(L.qkv, w.xn, MBL, B, 0, w.qkv, w.ld_qkv, 0, false, 1);
         AttnArgs at{};
         at.qkv = w.qkv; at.ld = w.ld_qkv; at.qn_w = L.qn; at.kn_w = L.kn; at.eps = s.eps;
         at.rope_cos = s.rope_cos; at.rope_sin = s.rope_sin;
         at.kpool = kpool + l * layer_stride; at.vpool = vpool + l * layer_stride;
         at.block_table = block_table; at.max_pages = max_pages; at.kv_len = kv_len; at.active = active;
-        at.out = w.ao; at.ldo = qd; at.n_heads = s.n_heads; at.n_kv = s.n_kv; at.B = B;
+        at.out = w.ao; at.outMB = MBL; at.n_heads = s.n_heads; at.n_kv = s.n_kv; at.B = B;
         at.scale = powf(float(kHeadDim), -0.5f);  // Talker.swift:179
         launch_attn_decode(at, st_);
         const int So = pick_split(L.o.Np / 16, L.o.Kp / 128);
-        gemm(L.o, w.ao, qd, B, 1, nullptr, 0, false, So);
+        gemm(L.o, w.ao, MBL, B, 1, nullptr, 0, 0, false, So);
         ResidNormArgs n2 = n1;
         n2.part = part_; n2.S = So; n2.w = L.ln2;
         launch_resid_norm(n2, st_);
-        gemm(L.gateup, w.xn, H, B, 2, w.act, w.ld_act, false, 1);
+        gemm(L.gateup, w.xn, MBL, B, 2, w.act, 0, MBL, false, 1);
         const int Sd = pick_split(L.down.Np / 16, L.down.Kp / 128);
-        gemm(L.down, w.act, w.ld_act, B, 1, nullptr, 0, false, Sd);
+        gemm(L.down, w.act, MBL, B, 1, nullptr, 0, 0, false, Sd);
         prevS = Sd;
     }
     if (need_final) {
         ResidNormArgs nf{};
         nf.h = w.h; nf.ldh = H; nf.part = part_; nf.S = prevS; nf.Mpad = Mp;
-        nf.w = final_w; nf.eps = s.eps; nf.xn = w.hidden; nf.ldxn = H; nf.M = B; nf.H = H;
+        nf.w = final_w; nf.eps = s.eps; nf.xn = w.hidden; nf.xnMB = MBL; nf.M = B; nf.H = H;
         launch_resid_norm(nf, st_);
     }
 }
@@ -200,12 +204,12 @@ void Engine::enqueue_talker_step(int B, bool need_hidden) {
                    m_->talker.final_norm, need_hidden);
 }
 
-void Engine::enqueue_cp_pass(int B, const uint16_t* x, int ldx) {
+void Engine::enqueue_cp_pass(int B, const uint16_t* x) {
     const int CH = m_->cp.hidden;
     if (m_->has_cp_proj)  // small_to_mtp_projection, CodePredictor.swift:327-330
-        gemm(m_->cp_proj, x, ldx, B, 0, cp_.h, CH, false, 1);
+        gemm(m_->cp_proj, x, Mp_ / 16, B, 0, cp_.h, CH, 0, false, 1);
     else
-        launch_copy_rows(x, ldx, cp_.h, CH, B, CH, st_);
+        launch_untile_rows(x, Mp_ / 16, cp_.h, CH, B, CH, st_);
     enqueue_layers(m_->cp, cp_, B, cp_kpool_, cp_vpool_, cp_kv_layer_stride_, cp_block_table_, 1, cp_len_, nullptr,
                    m_->cp.final_norm, true);
 }
@@ -215,7 +219,7 @@ void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
     const int H = t.hidden_size, V = t.vocab_size, Vc = t.cp.vocab_size, CH = t.cp.hidden_size;
     const int groups = t.num_code_groups;
     enqueue_talker_step(B, true);
-    gemm(m_->codec_head, tk_.hidden, H, B, 0, tk_.logits, tk_.ld_logits, false, 1);
+    gemm(m_->codec_head, tk_.hidden, Mp_ / 16, B, 0, tk_.logits, tk_.ld_logits, 0, false, 1);
     SamplerArgs sa{};
     sa.logits = tk_.logits; sa.ldl = tk_.ld_logits; sa.V = V; sa.sp = sp_dev_; sa.is_talker = 1;
     sa.suppress_lo = V - 1024; sa.suppress_hi = V; sa.eos_id = t.codec_eos_token_id;  // Qwen3.swift:829-835
@@ -224,15 +228,15 @@ void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
     sa.cur_codes = cur_codes_; sa.codes = codes_; sa.Fmax = Fcap_;
     sa.forced = dbg ? forced_dev_ : nullptr; sa.forced_frames = dbg ? dbg->frames : 0;
     sa.sampled = dbg ? sampled_dev_ : nullptr;
-    sa.emb = m_->codec_emb; sa.emb_ld = H; sa.next_x = cp_x_; sa.ld_next = H; sa.H = H; sa.B = B;
+    sa.emb = m_->codec_emb; sa.emb_ld = H; sa.next_x = cp_x_; sa.next_MB = Mp_ / 16; sa.H = H; sa.B = B;
     sa.logits_dump = (dbg && dbg->talker_logits) ? tl_dump_ : nullptr; sa.dump_ld = V; sa.dump_off = 0;
     launch_sampler(sa, st_);
     // code predictor, step 0 = [hidden, embed(code0)] (Qwen3.swift:884-887) run as two positions
-    enqueue_cp_pass(B, tk_.hidden, H);
+    enqueue_cp_pass(B, tk_.hidden);
     launch_advance_len(cp_len_, nullptr, B, st_);
     for (int i = 0; i < groups - 1; ++i) {
-        enqueue_cp_pass(B, cp_x_, H);
-        gemm(m_->lm_head[size_t(i)], cp_.hidden, CH, B, 0, cp_.logits, cp_.ld_logits, false, 1);
+        enqueue_cp_pass(B, cp_x_);
+        gemm(m_->lm_head[size_t(i)], cp_.hidden, Mp_ / 16, B, 0, cp_.logits, cp_.ld_logits, 0, false, 1);
         SamplerArgs sc{};
         sc.logits = cp_.logits; sc.ldl = cp_.ld_logits; sc.V = Vc; sc.sp = sp_dev_; sc.is_talker = 0;
         sc.eos_id = -1; sc.cb = i + 1; sc.n_frames = n_frames_; sc.max_frames = max_frames_;
@@ -241,7 +245,7 @@ void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
         sc.forced = dbg ? forced_dev_ : nullptr; sc.forced_frames = dbg ? dbg->frames : 0;
         sc.sampled = dbg ? sampled_dev_ : nullptr;
         if (i + 1 < groups - 1) {  // embedding of this code feeds the next pass (Qwen3.swift:889-892)
-            sc.emb = m_->cp_emb[size_t(i)]; sc.emb_ld = H; sc.next_x = cp_x_; sc.ld_next = H;
+            sc.emb = m_->cp_emb[size_t(i)]; sc.emb_ld = H; sc.next_x = cp_x_; sc.next_MB = Mp_ / 16;
         }
         sc.H = H; sc.B = B;
         sc.logits_dump = (dbg && dbg->cp_logits) ? cl_dump_ : nullptr; sc.dump_ld = (groups - 1) * Vc; sc.dump_off = i * Vc;
@@ -340,9 +344,9 @@ void Engine::project_rows(const std::vector<int32_t>& ids, int rows) {
     Q3_HIP(hipMemcpyAsync(ids_dev_, ids.data(), size_t(rows) * 4, hipMemcpyHostToDevice, st_));
     for (int r0 = 0; r0 < rows; r0 += 64) {
         const int n = std::min(64, rows - r0);
-        launch_gather_rows(m_->text_emb, TH, ids_dev_ + r0, m_->token_map, n, TH, proj_in_, TH, st_);
-        gemm(m_->fc1, proj_in_, TH, n, 0, proj_mid_, TH, true, 1);
-        gemm(m_->fc2, proj_mid_, TH, n, 0, proj_out_ + size_t(r0) * H, H, false, 1);
+        launch_gather_rows(m_->text_emb, TH, ids_dev_ + r0, m_->token_map, n, TH, proj_in_, TH, 4, st_);
+        gemm(m_->fc1, proj_in_, 4, n, 0, proj_mid_, 0, 4, true, 1);
+        gemm(m_->fc2, proj_mid_, 4, n, 0, proj_out_ + size_t(r0) * H, H, 0, false, 1);
     }
 }
 
@@ -446,6 +450,7 @@ void Engine::generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp
                       q3tts_result* results, const DebugOpts* dbg) {
     const TalkerConfig& t = m_->cfg.talker;
     const int H = t.hidden_size, V = t.vocab_size, Vc = t.cp.vocab_size, groups = t.num_code_groups;
+    Q3_HIP(hipSetDevice(m_->device));  // lanes run on their own host threads
     Q3_CHECK(n >= 1 && n <= Bm_, 3, "Invalid input: batch size must be between 1 and max_batch");
     Q3_CHECK(groups == 16, 3, "Invalid input: num_code_groups must be 16");
     const double t_start = now_s();
@@ -484,7 +489,7 @@ void Engine::generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp
     Q3_HIP(hipMemsetAsync(finished_, 0, size_t(n), st_));
     Q3_HIP(hipMemsetAsync(seen_, 0, size_t(n) * V, st_));
     Q3_HIP(hipMemsetAsync(codes_, 0, size_t(n) * Fcap_ * 16 * 4, st_));
-    SamplingParams sph{sp.temperature, sp.top_k, sp.top_p, sp.repetition_penalty, sp.seed, 0u, sp.force_frames > 0 ? 1 : 0};
+    SamplingParams sph{sp.temperature, sp.top_k, sp.top_p, sp.repetition_penalty, sp.seed, row_offset, sp.force_frames > 0 ? 1 : 0};
     Q3_HIP(hipMemcpyAsync(sp_dev_, &sph, sizeof(sph), hipMemcpyHostToDevice, st_));
     int frames_cap = 0;
     for (int f : maxf) frames_cap = std::max(frames_cap, f);
@@ -531,9 +536,17 @@ void Engine::generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp
     bool done = false;
     while (!done && launched < frames_cap) {
         const int burst = (fixed_len && !cb) ? (frames_cap - launched) : std::min(poll, frames_cap - launched);
+        const double t_host0 = now_s();
         for (int i = 0; i < burst; ++i) {
             if (use_graph) Q3_HIP(hipGraphLaunch(ge, st_));
             else enqueue_frame(n, dbg);
+        }
+        if (getenv("Q3TTS_DEBUG_TIMING")) {
+            const double t_host1 = now_s();
+            Q3_HIP(hipStreamSynchronize(st_));
+            const double t_host2 = now_s();
+            fprintf(stderr, "[q3tts] lane rows=%d burst=%d host-enqueue %.3f ms/frame, drain after enqueue %.3f ms total\n", n, burst,
+                    (t_host1 - t_host0) * 1e3 / burst, (t_host2 - t_host1) * 1e3);
         }
         launched += burst;
         if (fixed_len && !cb) break;
@@ -549,10 +562,12 @@ void Engine::generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp
                     std::vector<int32_t> tmp((size_t)(nf - reported[size_t(b)]) * 16);
                     Q3_HIP(hipMemcpy(tmp.data(), codes_ + (size_t(b) * Fcap_ + reported[size_t(b)]) * 16, tmp.size() * 4,
                                      hipMemcpyDeviceToHost));
+                    std::unique_lock<std::mutex> lk;
+                    if (cb_mutex) lk = std::unique_lock<std::mutex>(*cb_mutex);
                     for (int f = 0; f < nf - reported[size_t(b)]; ++f) {
                         q3tts_event ev{};
                         ev.kind = Q3TTS_EVENT_TOKEN;
-                        ev.request_index = b;
+                        ev.request_index = request_base + b;
                         ev.token = tmp[size_t(f) * 16];
                         cb(user, &ev);
                     }
@@ -631,11 +646,13 @@ void Engine::generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp
         r.status = Q3TTS_OK;
     }
     if (cb) {
+        std::unique_lock<std::mutex> lk;
+        if (cb_mutex) lk = std::unique_lock<std::mutex>(*cb_mutex);
         for (int b = 0; b < n; ++b) {
             if (results[b].status != Q3TTS_OK) continue;
             q3tts_event ev{};
             ev.kind = Q3TTS_EVENT_INFO;
-            ev.request_index = b;
+            ev.request_index = request_base + b;
             ev.info = &results[b].info;
             cb(user, &ev);
             ev.kind = Q3TTS_EVENT_AUDIO;
@@ -693,28 +710,33 @@ void Engine::debug_linear(const uint16_t* x, const uint16_t* W, const uint16_t* 
     Q3_HIP(hipMemset(dx, 0, size_t(Mp) * Kp * 2));
     Q3_HIP(hipMemset(db, 0, size_t(Np) * 2));
     Q3_HIP(hipMemcpy(dW, W, size_t(N) * K * 2, hipMemcpyHostToDevice));
-    Q3_HIP(hipMemcpy2D(dx, size_t(Kp) * 2, x, size_t(K) * 2, size_t(K) * 2, size_t(M), hipMemcpyHostToDevice));
+    uint16_t* dxl = nullptr;  // row-major staging, converted to the fragment-major operand layout
+    Q3_HIP(hipMalloc(reinterpret_cast<void**>(&dxl), size_t(Mp) * Kp * 2));
+    Q3_HIP(hipMemset(dxl, 0, size_t(Mp) * Kp * 2));
+    Q3_HIP(hipMemcpy2D(dxl, size_t(Kp) * 2, x, size_t(K) * 2, size_t(K) * 2, size_t(M), hipMemcpyHostToDevice));
+    launch_tile_rows(dxl, Kp, dx, Mp / 16, Mp, Kp, st_);
     if (bias) Q3_HIP(hipMemcpy(db, bias, size_t(N) * 2, hipMemcpyHostToDevice));
     launch_tile_weights(dW, N, K, dWt, Kp / 128, 0, 1, st_);
     LinearW L;
     L.w = dWt; L.bias = bias ? db : nullptr; L.N = N; L.K = K; L.Np = Np; L.Kp = Kp;
     // exercise both code paths: direct bf16 epilogue when it fills the chip, split-K + resid_norm fold otherwise
     const int S = pick_split(Np / 16, Kp / 128);
-    if (S == 1 || bias) {
-        gemm(L, dx, Kp, M, 0, dy, Np, false, 1);
+    if (S == 1 || bias || Np % 128 != 0) {
+        gemm(L, dx, Mp / 16, M, 0, dy, Np, 0, false, 1);
     } else {
         Q3_HIP(hipMalloc(reinterpret_cast<void**>(&dpart), size_t(S) * Mp * Np * 4));
         Q3_HIP(hipMemsetAsync(dy, 0, size_t(Mp) * Np * 2, st_));  // residual stream = 0, so h <- bf16(0 + bf16(sum))
         GemmArgs a{};
-        a.W = dWt; a.x = dx; a.ldx = Kp; a.M = M; a.Mpad = Mp; a.N = Np; a.K = Kp; a.S = S; a.epi = 1; a.part = dpart;
+        a.W = dWt; a.x = dx; a.xMB = Mp / 16; a.M = M; a.Mpad = Mp; a.N = Np; a.K = Kp; a.S = S; a.epi = 1; a.part = dpart;
         launch_gemm_skinny(a, st_);
         ResidNormArgs rn{};
         rn.h = dy; rn.ldh = Np; rn.part = dpart; rn.S = S; rn.Mpad = Mp; rn.w = nullptr; rn.M = M; rn.H = Np;
+        Q3_CHECK(Np % 128 == 0, 3, "debug_linear: split-K path needs N % 128 == 0");
         launch_resid_norm(rn, st_);
     }
     Q3_HIP(hipStreamSynchronize(st_));
     Q3_HIP(hipMemcpy2D(y, size_t(N) * 2, dy, size_t(Np) * 2, size_t(N) * 2, size_t(M), hipMemcpyDeviceToHost));
-    for (void* p : {(void*)dW, (void*)dWt, (void*)dx, (void*)dy, (void*)db, (void*)dpart})
+    for (void* p : {(void*)dW, (void*)dWt, (void*)dx, (void*)dxl, (void*)dy, (void*)db, (void*)dpart})
         if (p) (void)hipFree(p);
 }
 
@@ -774,6 +796,87 @@ void Engine::debug_codec_stage(const int32_t* codes, int n_frames, const char* s
     (void)hipFree(dcodes);
     Q3_CHECK(int64_t(so.size()) <= cap, 3, "debug_codec_stage: output buffer too small");
     std::memcpy(out, so.data(), so.size() * 4);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// EngineGroup
+// ------------------------------------------------------------------------------------------------
+EngineGroup::EngineGroup(std::unique_ptr<Model> model, const q3tts_load_opts& opts) : model_(std::move(model)), opts_(opts) {
+    int lanes = opts.n_streams;
+    // measured on MI355X / ROCm 7.2: with >= 2 lanes the aggregate node-enqueue rate of
+    // hipGraphLaunch (~3.2 us per kernel node) caps throughput, so one lane is the default
+    if (lanes <= 0) lanes = 1;
+    lanes = std::max(1, std::min(lanes, opts.max_batch));
+    q3tts_load_opts lo = opts;
+    lo.max_batch = ceil_div(opts.max_batch, lanes);
+    for (int i = 0; i < lanes; ++i) {
+        lanes_.push_back(std::make_unique<Engine>(model_.get(), lo));
+        lanes_.back()->cb_mutex = &cb_mutex_;
+    }
+    speakers = lanes_[0]->speakers;
+}
+
+void EngineGroup::generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3tts_event_cb cb, void* user,
+                           q3tts_result* results, const DebugOpts* dbg) {
+    Q3_CHECK(n >= 1 && n <= opts_.max_batch, 3, "Invalid input: batch size must be between 1 and max_batch");
+    const int L = int(lanes_.size());
+    // contiguous split: lane i takes rows [lo_i, hi_i)
+    std::vector<int> lo((size_t)(L + 1), 0);
+    const int per = n / L, rem = n % L;
+    for (int i = 0; i < L; ++i) lo[size_t(i) + 1] = lo[size_t(i)] + per + (i < rem ? 1 : 0);
+    std::vector<std::string> errs((size_t)(L));
+    std::vector<int> codes((size_t)(L), 0);
+    auto run = [&](int i) {
+        const int a = lo[size_t(i)], b = lo[size_t(i) + 1];
+        if (b <= a) return;
+        Engine& e = *lanes_[size_t(i)];
+        e.row_offset = uint32_t(a);
+        e.request_base = a;
+        try {
+            DebugOpts d;
+            const DebugOpts* dp = nullptr;
+            if (dbg) {  // slice the per-row debug arrays
+                const TalkerConfig& t = model_->cfg.talker;
+                d = *dbg;
+                const size_t fr = size_t(dbg->frames);
+                if (d.forced_codes) d.forced_codes += size_t(a) * fr * 16;
+                if (d.sampled) d.sampled += size_t(a) * fr * 16;
+                if (d.talker_logits) d.talker_logits += size_t(a) * fr * t.vocab_size;
+                if (d.cp_logits) d.cp_logits += size_t(a) * fr * (t.num_code_groups - 1) * t.cp.vocab_size;
+                dp = &d;
+            }
+            e.generate(reqs + a, b - a, sp, cb, user, results + a, dp);
+        } catch (const Error& ex) {
+            errs[size_t(i)] = ex.what();
+            codes[size_t(i)] = ex.status;
+        } catch (const std::exception& ex) {
+            errs[size_t(i)] = ex.what();
+            codes[size_t(i)] = 7;
+        }
+    };
+    if (L == 1 || n == 1) {
+        run(0);
+        for (int i = 1; i < L; ++i) run(i);
+    } else {
+        std::vector<std::thread> th;
+        for (int i = 0; i < L; ++i) th.emplace_back(run, i);
+        for (auto& t : th) t.join();
+    }
+    for (int i = 0; i < L; ++i)
+        if (codes[size_t(i)]) throw Error(codes[size_t(i)], errs[size_t(i)]);
+    // aggregate timing: lanes run concurrently, so spans are maxima and volumes are sums
+    timing = q3tts_timing{};
+    for (int i = 0; i < L; ++i) {
+        if (lo[size_t(i) + 1] <= lo[size_t(i)]) continue;
+        const q3tts_timing& t = lanes_[size_t(i)]->timing;
+        timing.prefill_ms = std::max(timing.prefill_ms, t.prefill_ms);
+        timing.decode_ms = std::max(timing.decode_ms, t.decode_ms);
+        timing.codec_ms = std::max(timing.codec_ms, t.codec_ms);
+        timing.frame_steps = std::max(timing.frame_steps, t.frame_steps);
+        timing.rows += t.rows;
+        timing.kv_bytes_read += t.kv_bytes_read;
+    }
 }
 
 }  // namespace q3

@@ -7,6 +7,7 @@
 #pragma once
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -36,7 +37,8 @@ class CodecRunner;
 
 class Engine {
   public:
-    Engine(std::unique_ptr<Model> model, const q3tts_load_opts& opts);
+    // One lane: a slice of the batch with its own stream, workspace, KV pool and frame graph.
+    Engine(Model* model, const q3tts_load_opts& opts);
     ~Engine();
 
     Model& model() { return *m_; }
@@ -58,7 +60,12 @@ class Engine {
     std::vector<std::string> speakers;  // sorted (Qwen3.swift:965-971)
 
   private:
-    std::unique_ptr<Model> m_;
+    Model* m_;
+  public:
+    uint32_t row_offset = 0;       // global index of this lane's first row (RNG stream id)
+    std::mutex* cb_mutex = nullptr;  // serialises event callbacks across lanes
+    int request_base = 0;          // added to request_index in events
+  private:
     q3tts_load_opts opts_;
     hipStream_t st_ = nullptr;
     hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -103,11 +110,36 @@ class Engine {
                         const int32_t* block_table, int max_pages, const int32_t* kv_len, const uint8_t* active,
                         const uint16_t* final_w, bool need_final);
     void enqueue_talker_step(int B, bool need_hidden);
-    void enqueue_cp_pass(int B, const uint16_t* x, int ldx);
+    void enqueue_cp_pass(int B, const uint16_t* x);  // x: fragment-major [B][H]
     void enqueue_frame(int B, const DebugOpts* dbg);
     hipGraphExec_t frame_graph(int B);
     int pick_split(int tiles, int chunks) const;
-    void gemm(const LinearW& L, const uint16_t* x, int ldx, int M, int epi, uint16_t* y, int ldy, bool silu, int S);
+    void gemm(const LinearW& L, const uint16_t* x, int xMB, int M, int epi, uint16_t* y, int ldy, int yMB, bool silu, int S);
+};
+
+
+// The object behind q3tts_model: the model plus `n_lanes` engines. q3tts_generate splits its rows
+// contiguously over the lanes; each lane is driven by its own host thread on its own HIP stream, so
+// the latency-bound frame steps of independent rows overlap on the GPU (the frame step is a chain
+// of ~800 short dependent kernels; one chain cannot fill 256 CUs, several chains can).
+class EngineGroup {
+  public:
+    EngineGroup(std::unique_ptr<Model> model, const q3tts_load_opts& opts);
+    Model& model() { return *model_; }
+    Engine& lane0() { return *lanes_[0]; }
+    int n_lanes() const { return int(lanes_.size()); }
+    const q3tts_load_opts& opts() const { return opts_; }
+    void generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3tts_event_cb cb, void* user,
+                  q3tts_result* results, const DebugOpts* dbg);
+    std::string last_error;
+    q3tts_timing timing{};
+    std::vector<std::string> speakers;
+
+  private:
+    std::unique_ptr<Model> model_;
+    q3tts_load_opts opts_;
+    std::vector<std::unique_ptr<Engine>> lanes_;
+    std::mutex cb_mutex_;
 };
 
 }  // namespace q3

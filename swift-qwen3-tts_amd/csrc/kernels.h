@@ -14,13 +14,14 @@ constexpr int kHeadDim = 128;    // Qwen3-TTS talker / code predictor head_dim (
 // ---- skinny GEMM (gemm_decode.hip) -------------------------------------------------------------
 struct GemmArgs {
     const uint16_t* W;  // tiled weights (weights.cc: tile_weights)
-    const uint16_t* x;  // [Mpad][ldx] bf16, rows >= M are zero/ignored
-    int ldx;
+    const uint16_t* x;  // fragment-major activations (common.h: act_tiled_offset), rows >= M ignored
+    int xMB;            // row blocks of the x allocation
     int M, Mpad, N, K;  // N, K are the padded (tiled) sizes
     int S;              // K splits across workgroups (epi 1 only when > 1)
     int epi;            // 0: y=bf16(acc+bias) (+silu)   1: fp32 partial slab   2: gate/up -> silu(g)*u
-    uint16_t* y;
+    uint16_t* y;        // epi 0: row-major [M][ldy], or fragment-major when y_tiled; epi 2: fragment-major
     int ldy;
+    int y_tiled, yMB;
     const uint16_t* bias;
     int act_silu;
     float* part;        // [S][Mpad][N]
@@ -35,8 +36,8 @@ struct ResidNormArgs {
     int S, Mpad;
     const uint16_t* w;  // norm weight [H]; nullptr: only fold the partials into h
     float eps;
-    uint16_t* xn;       // [M][ldxn]
-    int ldxn;
+    uint16_t* xn;       // fragment-major (next GEMM's x operand)
+    int xnMB;
     int M, H;
 };
 void launch_resid_norm(const ResidNormArgs& a, hipStream_t st);
@@ -56,8 +57,8 @@ struct AttnArgs {
     int max_pages;
     const int32_t* kv_len;       // [B] tokens already cached (= position of the new token)
     const uint8_t* active;       // [B] or nullptr (always): append this token to the cache
-    uint16_t* out;               // [B][n_heads*128]
-    int ldo;
+    uint16_t* out;               // fragment-major [B][n_heads*128] (o_proj's x operand)
+    int outMB;
     int n_heads, n_kv, B;
     float scale;
 };
@@ -97,8 +98,8 @@ struct SamplerArgs {
     int32_t* sampled;        // [B][forced_frames][16] what the sampler chose (tests) or nullptr
     const uint16_t* emb;     // embedding table of the sampled id -> next code-predictor input
     int emb_ld;
-    uint16_t* next_x;        // [B][ld_next] or nullptr
-    int ld_next;
+    uint16_t* next_x;        // fragment-major [B][H] or nullptr
+    int next_MB;
     int H;
     int B;
     uint16_t* logits_dump;   // [B][forced_frames][dump_ld] (tests) or nullptr
@@ -108,8 +109,12 @@ void launch_sampler(const SamplerArgs& a, hipStream_t st);
 
 // ---- embedding plumbing (lm_misc.hip) ----------------------------------------------------------
 // gather rows of a bf16 table: out[i] = table[ids[i]] (optionally through a token map)
+// out_MB > 0: out is fragment-major with that many row blocks (ldo ignored)
 void launch_gather_rows(const uint16_t* table, int ld, const int32_t* ids, const int32_t* token_map,
-                        int n, int dim, uint16_t* out, int ldo, hipStream_t st);
+                        int n, int dim, uint16_t* out, int ldo, int out_MB, hipStream_t st);
+// row-major <-> fragment-major conversions (rows x dim, dim % 128 == 0)
+void launch_tile_rows(const uint16_t* src, int lds, uint16_t* dst, int dstMB, int rows, int dim, hipStream_t st);
+void launch_untile_rows(const uint16_t* src, int srcMB, uint16_t* dst, int ldd, int rows, int dim, hipStream_t st);
 // out = a + b (bf16, one rounding), rows x dim; b_stride 0 broadcasts one row
 void launch_add_rows(const uint16_t* a, int lda, const uint16_t* b, int ldb, int rows, int dim,
                      uint16_t* out, int ldo, hipStream_t st);

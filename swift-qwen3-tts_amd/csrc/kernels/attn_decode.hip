@@ -35,7 +35,7 @@ __device__ __forceinline__ void norm_rope(float x0, float x1, const uint16_t* w,
 
 template <int REP>
 __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
-    __shared__ float q_s[REP][D];
+    __shared__ __attribute__((aligned(16))) float q_s[REP][D];
     __shared__ float k_s[D];
     __shared__ float v_s[D];
     __shared__ float m_s[16][REP];
@@ -154,7 +154,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     }
     __syncthreads();
 
-    // ---- merge the 16 groups: thread -> (head, dim) ----
+    // ---- merge the 16 groups: thread -> (head, dim); results staged in LDS for 16-byte stores ----
+    uint16_t* out_s = reinterpret_cast<uint16_t*>(&q_s[0][0]);  // q_s is dead: every wave passed the barrier above
     for (int o = tid; o < REP * D; o += 256) {
         const int h = o / D, d = o % D;
         float M = -INFINITY;
@@ -167,7 +168,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
             num += acc_s[gg][h][d] * w;
             den += l_s[gg][h] * w;
         }
-        a.out[(size_t)b * a.ldo + (size_t)(kvh * REP + h) * D + d] = f2bf(num / den);
+        out_s[o] = f2bf(num / den);
+    }
+    __syncthreads();
+    for (int p = tid; p < REP * D / 8; p += 256) {  // fragment-major store (x operand of o_proj)
+        const int col = (kvh * REP) * D + 8 * p;
+        *reinterpret_cast<uint4*>(a.out + act_tiled_offset(b, col, a.outMB)) = *reinterpret_cast<const uint4*>(out_s + 8 * p);
     }
 }
 

@@ -12,6 +12,9 @@
 //     v_mfma_f32_16x16x32_bf16 (no LDS round trip: cdna_hip_programming.md, "GEMV / M <= 16" row).
 //     The k index inside a tile is permuted (k = 32*(lane>>4) + 8*i + j); x fragments use the same
 //     permutation, and a dot product does not care about the order of its terms.
+//   * x (the <= 64 activation rows) is kept in the same fragment-major order by its producers
+//     (common.h: act_tiled_offset), so the B-fragment loads are 1 KiB contiguous too. Row-major x
+//     costs as much L2->CU time as streaming the weights (16 rows x 64 B per wave-instruction).
 //   * out^T tile = W(16 x K) . x^T(K x 16*MB): W rows are the MFMA M dimension, batch rows the N
 //     dimension, so one weight fragment feeds MB MFMAs.
 //   * a workgroup = 8 waves that split K (chunk-interleaved) for one 16-row weight tile and
@@ -27,8 +30,6 @@ namespace q3 {
 
 namespace {
 
-constexpr int kWaves = 8;
-
 __device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, f32x4 c) {
     bf16x8 av, bv;
     __builtin_memcpy(&av, &a, 16);
@@ -39,10 +40,14 @@ __device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, f32x4 c)
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
 
 // EPI: 0 = bf16 store (+bias, +optional silu), 1 = fp32 partial slab, 2 = gate/up -> silu(g)*u
-template <int MB, int EPI>
-__global__ __launch_bounds__(kWaves * 64) void gemm_skinny_kernel(GemmArgs a) {
+// NW : waves per workgroup (they split the K slice chunk-interleaved)
+// CH : 128-wide k chunks per wave (compile time, so every weight load of the wave is issued before
+//      the first MFMA: a wave sees ONE exposed HBM latency however long its K range is);
+//      CH == 0 is the generic runtime loop for shapes the launcher cannot unroll.
+template <int MB, int EPI, int NW, int CH>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
     constexpr int NT = (EPI == 2) ? 2 : 1;  // weight tiles per workgroup
-    __shared__ float red[kWaves][NT][MB][4][64];
+    __shared__ float red[NW][NT][MB][4][64];
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -50,8 +55,6 @@ __global__ __launch_bounds__(kWaves * 64) void gemm_skinny_kernel(GemmArgs a) {
     const int s = blockIdx.y;
     const int KC = a.K >> 7;             // 128-wide k chunks in total
     const int cps = KC / a.S;            // chunks per K slice
-    const int r = lane & 15, h = lane >> 4;
-
     f32x4 acc[NT][MB];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -59,25 +62,72 @@ __global__ __launch_bounds__(kWaves * 64) void gemm_skinny_kernel(GemmArgs a) {
         for (int mb = 0; mb < MB; ++mb) acc[t][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const uint4* Wt = reinterpret_cast<const uint4*>(a.W);
-    for (int kl = wave; kl < cps; kl += kWaves) {
-        const int kc = s * cps + kl;
-        uint4 wf[NT][4];
+    const uint4* Xt = reinterpret_cast<const uint4*>(a.x);
+    if constexpr (CH > 0) {
+        uint4 wf[CH][NT][4];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const uint4* wp = Wt + ((size_t)(tile * NT + t) * KC + kc) * 256 + lane;
+        for (int c = 0; c < CH; ++c) {
+            const int kl = wave + c * NW;
+            const int kc = s * cps + (kl < cps ? kl : 0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wf[t][i] = wp[i * 64];
+            for (int t = 0; t < NT; ++t) {
+                const uint4* wp = Wt + ((size_t)(tile * NT + t) * KC + kc) * 256 + lane;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#if defined(Q3_GEMM_ABLATE) && Q3_GEMM_ABLATE == 2
+                    wf[c][t][i] = make_uint4(lane, i, t, c);
+#else
+                    wf[c][t][i] = wp[i * 64];
+#endif
+                }
+            }
         }
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            const uint4* xp = reinterpret_cast<const uint4*>(a.x + (size_t)(16 * mb + r) * a.ldx + kc * 128 + 32 * h);
-            uint4 xf[4];
+        for (int c = 0; c < CH; ++c) {
+            const int kl = wave + c * NW;
+            if (kl < cps) {  // wave-uniform
+                const int kc = s * cps + kl;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) xf[i] = xp[i];
+                for (int mb = 0; mb < MB; ++mb) {
+                    const uint4* xp = Xt + ((size_t)(kc * a.xMB + mb) * 4) * 64 + lane;
+                    uint4 xf[4];
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
+                    for (int i = 0; i < 4; ++i) {
+#if defined(Q3_GEMM_ABLATE) && Q3_GEMM_ABLATE == 1
+                        xf[i] = make_uint4(lane, i, mb, c);
+                        (void)xp;
+#else
+                        xf[i] = xp[i * 64];
+#endif
+                    }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[t][mb] = mfma16(wf[t][i], xf[i], acc[t][mb]);
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[t][mb] = mfma16(wf[c][t][i], xf[i], acc[t][mb]);
+                }
+            }
+        }
+    } else {
+        for (int kl = wave; kl < cps; kl += NW) {
+            const int kc = s * cps + kl;
+            uint4 wf[NT][4];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const uint4* wp = Wt + ((size_t)(tile * NT + t) * KC + kc) * 256 + lane;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wf[t][i] = wp[i * 64];
+            }
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const uint4* xp = Xt + ((size_t)(kc * a.xMB + mb) * 4) * 64 + lane;
+                uint4 xf[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xf[i] = xp[i * 64];
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[t][mb] = mfma16(wf[t][i], xf[i], acc[t][mb]);
+            }
         }
     }
 
@@ -89,8 +139,9 @@ __global__ __launch_bounds__(kWaves * 64) void gemm_skinny_kernel(GemmArgs a) {
             for (int q = 0; q < 4; ++q) red[wave][t][mb][q][lane] = acc[t][mb][q];
     __syncthreads();
 
-    // 256*MB outputs per tile: thread -> (mb, batch row b, feature f); f fastest for coalesced stores
-    for (int o = threadIdx.x; o < 256 * MB; o += kWaves * 64) {
+    // 256*MB outputs per tile: thread -> (mb, batch row b, feature f)
+    __shared__ uint16_t ys[MB][16][16];
+    for (int o = threadIdx.x; o < 256 * MB; o += NW * 64) {
         const int mb = o >> 8, rem = o & 255;
         const int b = rem >> 4, f = rem & 15;
         const int src_lane = (f >> 2) * 16 + b, q = f & 3;
@@ -100,39 +151,72 @@ __global__ __launch_bounds__(kWaves * 64) void gemm_skinny_kernel(GemmArgs a) {
         for (int t = 0; t < NT; ++t) {
             float sum = 0.f;
 #pragma unroll
-            for (int w = 0; w < kWaves; ++w) sum += red[w][t][mb][q][src_lane];
+            for (int w = 0; w < NW; ++w) sum += red[w][t][mb][q][src_lane];
             v[t] = sum;
         }
         const int n = tile * 16 + f;
         if constexpr (EPI == 1) {
             // padded rows are written too (zeros from zero-padded x), the consumer ignores them
             a.part[((size_t)s * a.Mpad + m) * a.N + n] = v[0];
-        } else if (m < a.M) {
-            if constexpr (EPI == 0) {
-                float y = v[0];
-                if (a.bias) y += bf2f(a.bias[n]);
-                uint16_t yb = f2bf(y);
-                if (a.act_silu) yb = f2bf(silu_f(bf2f(yb)));
-                a.y[(size_t)m * a.ldy + n] = yb;
-            } else {
-                float g = rbf(v[0]), u = rbf(v[1]);
-                float sg = rbf(silu_f(g));
-                a.y[(size_t)m * a.ldy + n] = f2bf(sg * u);
-            }
+        } else if constexpr (EPI == 0) {
+            float y = v[0];
+            if (a.bias) y += bf2f(a.bias[n]);
+            uint16_t yb = f2bf(y);
+            if (a.act_silu) yb = f2bf(silu_f(bf2f(yb)));
+            ys[mb][b][f] = yb;
+        } else {
+            float g = rbf(v[0]), u = rbf(v[1]);
+            float sg = rbf(silu_f(g));
+            ys[mb][b][f] = f2bf(sg * u);
+        }
+    }
+    if constexpr (EPI != 1) {
+        __syncthreads();
+        // 16-byte stores: thread -> (mb, row b, 8-feature piece p)
+        for (int o = threadIdx.x; o < 32 * MB; o += NW * 64) {
+            const int mb = o >> 5, b = (o >> 1) & 15, p = o & 1;
+            const int m = 16 * mb + b;
+            if (m >= a.M) continue;
+            const uint4 v = *reinterpret_cast<const uint4*>(&ys[mb][b][8 * p]);
+            const int n = tile * 16 + 8 * p;
+            if (EPI == 2 || a.y_tiled)
+                *reinterpret_cast<uint4*>(a.y + act_tiled_offset(m, n, a.yMB)) = v;
+            else
+                *reinterpret_cast<uint4*>(a.y + (size_t)m * a.ldy + n) = v;
         }
     }
 }
 
+template <int MB, int EPI>
+void launch_mb(const GemmArgs& a, hipStream_t st) {
+    const int cps = (a.K / 128) / a.S;
+    // waves: 4 when the slice has <= 4 chunks (no idle waves), else 8; CH chunks per wave (<= 3 unrolled)
+    const int nw = cps <= 4 ? 4 : 8;
+    const int ch = (cps + nw - 1) / nw;
+    dim3 grid(a.N / 16, a.S);
+#define Q3_GEMM(NWv, CHv) \
+    hipLaunchKernelGGL((gemm_skinny_kernel<MB, EPI, NWv, CHv>), grid, dim3(NWv * 64), 0, st, a)
+    if (nw == 4) {
+        Q3_GEMM(4, 1);
+    } else {
+        switch (ch) {
+            case 1: Q3_GEMM(8, 1); break;
+            case 2: Q3_GEMM(8, 2); break;
+            case 3: Q3_GEMM(8, 3); break;
+            default: Q3_GEMM(8, 0); break;
+        }
+    }
+#undef Q3_GEMM
+}
+
 template <int EPI>
 void launch_epi(const GemmArgs& a, hipStream_t st) {
-    const int tiles = (EPI == 2) ? a.N / 16 : a.N / 16;  // for EPI 2, a.N is the intermediate size
-    dim3 grid(tiles, a.S), block(kWaves * 64);
     const int MB = (a.Mpad + 15) / 16;
     switch (MB) {
-        case 1: hipLaunchKernelGGL((gemm_skinny_kernel<1, EPI>), grid, block, 0, st, a); break;
-        case 2: hipLaunchKernelGGL((gemm_skinny_kernel<2, EPI>), grid, block, 0, st, a); break;
-        case 3: hipLaunchKernelGGL((gemm_skinny_kernel<3, EPI>), grid, block, 0, st, a); break;
-        case 4: hipLaunchKernelGGL((gemm_skinny_kernel<4, EPI>), grid, block, 0, st, a); break;
+        case 1: launch_mb<1, EPI>(a, st); break;
+        case 2: launch_mb<2, EPI>(a, st); break;
+        case 3: launch_mb<3, EPI>(a, st); break;
+        case 4: launch_mb<4, EPI>(a, st); break;
         default: throw Error(3, "gemm_skinny: M > 64 is not supported");
     }
 }
@@ -143,7 +227,7 @@ void launch_gemm_skinny(const GemmArgs& a, hipStream_t st) {
     Q3_CHECK(a.K % 128 == 0 && a.N % 16 == 0, 3, "gemm_skinny: K must be a multiple of 128 and N of 16");
     Q3_CHECK(a.S >= 1 && (a.K / 128) % a.S == 0, 3, "gemm_skinny: K chunks must divide by the split");
     Q3_CHECK(a.Mpad % 16 == 0 && a.M <= a.Mpad && a.Mpad <= 64, 3, "gemm_skinny: bad M padding");
-    Q3_CHECK(a.ldx % 8 == 0, 3, "gemm_skinny: x rows must be 16-byte aligned");
+    Q3_CHECK(a.xMB * 16 >= a.Mpad, 3, "gemm_skinny: x allocation has fewer row blocks than the batch");
     switch (a.epi) {
         case 0: Q3_CHECK(a.S == 1, 3, "gemm_skinny: bf16 epilogue needs S == 1"); launch_epi<0>(a, st); break;
         case 1: launch_epi<1>(a, st); break;

@@ -15,37 +15,44 @@ namespace {
 // order, so the projection's rounding point (bf16 of the full fp32 sum) is the reference's.
 __global__ __launch_bounds__(256) void resid_norm_kernel(ResidNormArgs a) {
     __shared__ float wsum[4];
+    constexpr int kTrips = 2;  // H <= 4096
     const int m = blockIdx.x;
     const int tid = threadIdx.x;
     uint16_t* hrow = a.h + (size_t)m * a.ldh;
+    float v[kTrips][8];
+    uint4 wv[kTrips];
     float ss = 0.f;
-    // each thread owns elements tid*8 .. tid*8+7 (+2048 per trip)
-    for (int i0 = tid * 8; i0 < a.H; i0 += 256 * 8) {
-        uint4 hv = *reinterpret_cast<const uint4*>(hrow + i0);
-        uint32_t hw[4] = {hv.x, hv.y, hv.z, hv.w};
-        float v[8];
+    // each thread owns elements tid*8 .. tid*8+7 (+2048 per trip); everything is loaded up front
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            v[2 * j] = lo_bf(hw[j]);
-            v[2 * j + 1] = hi_bf(hw[j]);
-        }
-        if (a.part) {
-            float y[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int s = 0; s < a.S; ++s) {
-                const float4* pp = reinterpret_cast<const float4*>(a.part + ((size_t)s * a.Mpad + m) * a.H + i0);
-                float4 p0 = pp[0], p1 = pp[1];
-                y[0] += p0.x; y[1] += p0.y; y[2] += p0.z; y[3] += p0.w;
-                y[4] += p1.x; y[5] += p1.y; y[6] += p1.z; y[7] += p1.w;
+    for (int tr = 0; tr < kTrips; ++tr) {
+        const int i0 = tid * 8 + tr * 2048;
+        if (i0 < a.H) {
+            const uint4 hv = *reinterpret_cast<const uint4*>(hrow + i0);
+            if (a.w) wv[tr] = *reinterpret_cast<const uint4*>(a.w + i0);
+            const uint32_t hw[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[tr][2 * j] = lo_bf(hw[j]);
+                v[tr][2 * j + 1] = hi_bf(hw[j]);
+            }
+            if (a.part) {
+                float y[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int s = 0; s < a.S; ++s) {
+                    const float4* pp = reinterpret_cast<const float4*>(a.part + ((size_t)s * a.Mpad + m) * a.H + i0);
+                    const float4 p0 = pp[0], p1 = pp[1];
+                    y[0] += p0.x; y[1] += p0.y; y[2] += p0.z; y[3] += p0.w;
+                    y[4] += p1.x; y[5] += p1.y; y[6] += p1.z; y[7] += p1.w;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[tr][j] = rbf(v[tr][j] + rbf(y[j]));
+                uint4 o;
+                o.x = pack_bf(v[tr][0], v[tr][1]); o.y = pack_bf(v[tr][2], v[tr][3]);
+                o.z = pack_bf(v[tr][4], v[tr][5]); o.w = pack_bf(v[tr][6], v[tr][7]);
+                *reinterpret_cast<uint4*>(hrow + i0) = o;
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = rbf(v[j] + rbf(y[j]));
-            uint4 o;
-            o.x = pack_bf(v[0], v[1]); o.y = pack_bf(v[2], v[3]);
-            o.z = pack_bf(v[4], v[5]); o.w = pack_bf(v[6], v[7]);
-            *reinterpret_cast<uint4*>(hrow + i0) = o;
+            for (int j = 0; j < 8; ++j) ss += v[tr][j] * v[tr][j];
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ss += v[j] * v[j];
     }
     if (!a.w) return;
     ss = wave_sum(ss);
@@ -53,28 +60,45 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(ResidNormArgs a) {
     __syncthreads();
     const float tot = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
     const float rstd = 1.0f / sqrtf(tot / (float)a.H + a.eps);
-    uint16_t* xrow = a.xn + (size_t)m * a.ldxn;
-    for (int i0 = tid * 8; i0 < a.H; i0 += 256 * 8) {
-        uint4 hv = *reinterpret_cast<const uint4*>(hrow + i0);
-        uint4 wv = *reinterpret_cast<const uint4*>(a.w + i0);
-        uint32_t hw[4] = {hv.x, hv.y, hv.z, hv.w}, ww[4] = {wv.x, wv.y, wv.z, wv.w}, ow[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float n0 = rbf(lo_bf(hw[j]) * rstd), n1 = rbf(hi_bf(hw[j]) * rstd);
-            ow[j] = pack_bf(n0 * lo_bf(ww[j]), n1 * hi_bf(ww[j]));
+    for (int tr = 0; tr < kTrips; ++tr) {
+        const int i0 = tid * 8 + tr * 2048;
+        if (i0 < a.H) {
+            const uint32_t ww[4] = {wv[tr].x, wv[tr].y, wv[tr].z, wv[tr].w};
+            uint32_t ow[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float n0 = rbf(v[tr][2 * j] * rstd), n1 = rbf(v[tr][2 * j + 1] * rstd);
+                ow[j] = pack_bf(n0 * lo_bf(ww[j]), n1 * hi_bf(ww[j]));
+            }
+            *reinterpret_cast<uint4*>(a.xn + act_tiled_offset(m, i0, a.xnMB)) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
         }
-        *reinterpret_cast<uint4*>(xrow + i0) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
     }
 }
 
 __global__ void gather_rows_kernel(const uint16_t* table, int ld, const int32_t* ids, const int32_t* token_map,
-                                   int dim, uint16_t* out, int ldo) {
+                                   int dim, uint16_t* out, int ldo, int out_MB) {
     const int r = blockIdx.x;
     int id = ids[r];
     if (token_map) id = token_map[id];  // embedText, Talker.swift:627-633
     const uint4* src = reinterpret_cast<const uint4*>(table + (size_t)id * ld);
-    uint4* dst = reinterpret_cast<uint4*>(out + (size_t)r * ldo);
-    for (int i = threadIdx.x; i < dim / 8; i += blockDim.x) dst[i] = src[i];
+    for (int i = threadIdx.x; i < dim / 8; i += blockDim.x) {
+        if (out_MB > 0) *reinterpret_cast<uint4*>(out + act_tiled_offset(r, 8 * i, out_MB)) = src[i];
+        else reinterpret_cast<uint4*>(out + (size_t)r * ldo)[i] = src[i];
+    }
+}
+
+__global__ void tile_rows_kernel(const uint16_t* src, int lds, uint16_t* dst, int dstMB, int dim) {
+    const int r = blockIdx.x;
+    const uint4* s = reinterpret_cast<const uint4*>(src + (size_t)r * lds);
+    for (int i = threadIdx.x; i < dim / 8; i += blockDim.x)
+        *reinterpret_cast<uint4*>(dst + act_tiled_offset(r, 8 * i, dstMB)) = s[i];
+}
+__global__ void untile_rows_kernel(const uint16_t* src, int srcMB, uint16_t* dst, int ldd, int dim) {
+    const int r = blockIdx.x;
+    uint4* d = reinterpret_cast<uint4*>(dst + (size_t)r * ldd);
+    for (int i = threadIdx.x; i < dim / 8; i += blockDim.x)
+        d[i] = *reinterpret_cast<const uint4*>(src + act_tiled_offset(r, 8 * i, srcMB));
 }
 
 __global__ void add_rows_kernel(const uint16_t* a, int lda, const uint16_t* b, int ldb, int dim, uint16_t* out,
@@ -137,9 +161,18 @@ __global__ __launch_bounds__(256) void frame_end_kernel(FrameEndArgs a) {
     const int ti = a.trailing_idx[b];
     const bool has_text = ti < a.n_trailing[b];
     const uint16_t* text = has_text ? a.trailing + ((size_t)b * a.Tmax + ti) * a.H : a.tts_pad;
+    const uint16_t* rows[16];
+    rows[0] = a.codec_emb + (size_t)cc[0] * a.H;
+#pragma unroll
+    for (int g = 1; g < 16; ++g) rows[g] = (g < a.groups) ? a.cp_emb[g - 1] + (size_t)cc[g] * a.H : rows[0];
     for (int i = threadIdx.x; i < a.H; i += blockDim.x) {
-        float ce = bf2f(a.codec_emb[(size_t)cc[0] * a.H + i]);
-        for (int g = 1; g < a.groups; ++g) ce = rbf(ce + bf2f(a.cp_emb[g - 1][(size_t)cc[g] * a.H + i]));
+        float e[16];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) e[g] = bf2f(rows[g][i]);  // 16 independent loads in flight
+        float ce = e[0];
+#pragma unroll
+        for (int g = 1; g < 16; ++g)
+            if (g < a.groups) ce = rbf(ce + e[g]);
         a.h[(size_t)b * a.ldh + i] = f2bf(bf2f(text[i]) + ce);
     }
     __syncthreads();  // every thread has read trailing_idx before it moves
@@ -158,13 +191,21 @@ __global__ __launch_bounds__(256) void frame_end_kernel(FrameEndArgs a) {
 }  // namespace
 
 void launch_resid_norm(const ResidNormArgs& a, hipStream_t st) {
-    Q3_CHECK(a.H % 8 == 0 && a.ldh % 8 == 0, 3, "resid_norm: H must be a multiple of 8");
+    Q3_CHECK(a.H % 128 == 0 && a.H <= 4096 && a.ldh % 8 == 0, 3, "resid_norm: H must be a multiple of 128, at most 4096");
     hipLaunchKernelGGL(resid_norm_kernel, dim3(a.M), dim3(256), 0, st, a);
 }
 void launch_gather_rows(const uint16_t* table, int ld, const int32_t* ids, const int32_t* token_map, int n,
-                        int dim, uint16_t* out, int ldo, hipStream_t st) {
+                        int dim, uint16_t* out, int ldo, int out_MB, hipStream_t st) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(n), dim3(256), 0, st, table, ld, ids, token_map, dim, out, ldo);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(n), dim3(256), 0, st, table, ld, ids, token_map, dim, out, ldo, out_MB);
+}
+void launch_tile_rows(const uint16_t* src, int lds, uint16_t* dst, int dstMB, int rows, int dim, hipStream_t st) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(tile_rows_kernel, dim3(rows), dim3(256), 0, st, src, lds, dst, dstMB, dim);
+}
+void launch_untile_rows(const uint16_t* src, int srcMB, uint16_t* dst, int ldd, int rows, int dim, hipStream_t st) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(untile_rows_kernel, dim3(rows), dim3(256), 0, st, src, srcMB, dst, ldd, dim);
 }
 void launch_add_rows(const uint16_t* a, int lda, const uint16_t* b, int ldb, int rows, int dim, uint16_t* out,
                      int ldo, hipStream_t st) {

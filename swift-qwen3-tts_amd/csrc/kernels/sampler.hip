@@ -326,8 +326,8 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(SamplerArgs a) {
     }
     if (a.next_x) {
         const uint4* src = reinterpret_cast<const uint4*>(a.emb + (size_t)used * a.emb_ld);
-        uint4* dst = reinterpret_cast<uint4*>(a.next_x + (size_t)b * a.ld_next);
-        for (int i = tid; i < a.H / 8; i += kThreads) dst[i] = src[i];
+        for (int i = tid; i < a.H / 8; i += kThreads)
+            *reinterpret_cast<uint4*>(a.next_x + act_tiled_offset(b, 8 * i, a.next_MB)) = src[i];
     }
 }
 

@@ -54,7 +54,7 @@ def save_safetensors(path: str, tensors: Dict[str, Tuple[str, np.ndarray]]) -> N
         f.write(struct.pack("<Q", len(hj)))
         f.write(hj)
         for k in order:
-            f.write(np.ascontiguousarray(tensors[k][1]).tobytes())
+            f.write(memoryview(np.ascontiguousarray(tensors[k][1])).cast("B"))
 
 
 # --------------------------------------------------------------------------------------------
@@ -133,19 +133,32 @@ class _Gen:
         self.rng = np.random.Generator(np.random.PCG64(seed))
         self.big = big
         self.tgen = None
+        self.dev = "cpu"
         if big:
             import torch
             self.torch = torch
-            self.tgen = torch.Generator().manual_seed(seed)
+            # the big presets are only used by bench.py; both the engine and the oracle read the
+            # files written here, so the generator does not need to be the same on every machine
+            self.dev = "cuda" if torch.cuda.is_available() else "cpu"
+            self.tgen = torch.Generator(device=self.dev).manual_seed(seed)
 
     def normal(self, shape, std: float, mean: float = 0.0) -> np.ndarray:
         n = int(np.prod(shape))
         if self.big and n >= (1 << 16):
-            t = self.torch.empty(tuple(shape), dtype=self.torch.float32)
+            t = self.torch.empty(tuple(shape), dtype=self.torch.float32, device=self.dev)
             t.normal_(mean, std, generator=self.tgen)
-            return t.numpy()
+            return t.cpu().numpy()
         return (self.rng.standard_normal(shape, dtype=np.float32) * np.float32(std)
                 + np.float32(mean)).astype(np.float32)
+
+    def normal_bf16(self, shape, std: float, mean: float = 0.0) -> Tuple[str, np.ndarray]:
+        """N(mean, std^2) rounded to bf16, returned as a safetensors ("BF16", uint16 bits) pair."""
+        n = int(np.prod(shape))
+        if self.big and n >= (1 << 16):
+            t = self.torch.empty(tuple(shape), dtype=self.torch.float32, device=self.dev)
+            t.normal_(mean, std, generator=self.tgen)
+            return ("BF16", t.to(self.torch.bfloat16).view(self.torch.int16).cpu().numpy().view(np.uint16))
+        return ("BF16", f32_to_bf16_bits(self.normal(shape, std, mean)))
 
     def uniform(self, shape, lo: float, hi: float) -> np.ndarray:
         return self.rng.uniform(lo, hi, size=shape).astype(np.float32)
@@ -169,13 +182,13 @@ def talker_tensors(cfg: dict, g: _Gen, std: float = 0.02) -> Dict[str, Tuple[str
     out: Dict[str, Tuple[str, np.ndarray]] = {}
 
     def lin(name, n, k, bias=False):
-        out[name + ".weight"] = _bf16(g.normal((n, k), std))
+        out[name + ".weight"] = g.normal_bf16((n, k), std)
         if bias:
-            out[name + ".bias"] = _bf16(g.normal((n,), std))
+            out[name + ".bias"] = g.normal_bf16((n,), std)
 
     def norm(name, d):
         # norm weights 1 with a small perturbation so a forgotten weight multiply is caught
-        out[name + ".weight"] = _bf16(g.normal((d,), 0.05, 1.0))
+        out[name + ".weight"] = g.normal_bf16((d,), 0.05, 1.0)
 
     def stack(prefix, hidden, inter_list, n_heads, n_kv, head_dim):
         for l, inter in enumerate(inter_list):
@@ -194,8 +207,8 @@ def talker_tensors(cfg: dict, g: _Gen, std: float = 0.02) -> Dict[str, Tuple[str
         norm(prefix + ".norm", hidden)
 
     inter = t.get("per_layer_intermediate_sizes") or [t["intermediate_size"]] * t["num_hidden_layers"]
-    out["talker.model.codec_embedding.weight"] = _bf16(g.normal((V, H), std))
-    out["talker.model.text_embedding.weight"] = _bf16(g.normal((TV, TH), std))
+    out["talker.model.codec_embedding.weight"] = g.normal_bf16((V, H), std)
+    out["talker.model.text_embedding.weight"] = g.normal_bf16((TV, TH), std)
     stack("talker.model", H, inter, nh, nkv, hd)
     lin("talker.text_projection.linear_fc1", TH, TH, bias=True)
     lin("talker.text_projection.linear_fc2", H, TH, bias=True)
@@ -204,8 +217,7 @@ def talker_tensors(cfg: dict, g: _Gen, std: float = 0.02) -> Dict[str, Tuple[str
     if ch != H:
         lin("talker.code_predictor.small_to_mtp_projection", ch, H, bias=True)
     for i in range(cp["num_code_groups"] - 1):
-        out[f"talker.code_predictor.model.codec_embedding.{i}.weight"] = _bf16(
-            g.normal((cp["vocab_size"], H), std))
+        out[f"talker.code_predictor.model.codec_embedding.{i}.weight"] = g.normal_bf16((cp["vocab_size"], H), std)
         lin(f"talker.code_predictor.lm_head.{i}", cp["vocab_size"], ch)
     stack("talker.code_predictor.model", ch, [cp["intermediate_size"]] * cp["num_hidden_layers"],
           cp["num_attention_heads"], cp["num_key_value_heads"], cp["head_dim"])
