@@ -68,18 +68,18 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 namespace q3 {
 
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(uint32_t(h) << 16); }
-// RNE with NaN kept quiet; integer form so that results are identical to the oracle's f2bf.
-__device__ __forceinline__ uint16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return uint16_t((u >> 16) | 0x0040u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return uint16_t(u >> 16);
-}
-__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
+// fp32 -> bf16, round to nearest even. A plain cast compiles to v_cvt_pk_bf16_f32 on gfx950 (one VALU op for
+// two values); an integer-arithmetic RNE costs ~10 ops per value and made the RMSNorm prologue VALU-bound.
+// Same results as the oracle's f2bf for every non-NaN input (NaN stays NaN).
+using bf16x2_t = __attribute__((ext_vector_type(2))) __bf16;
+using f32x2_t = __attribute__((ext_vector_type(2))) float;
+__device__ __forceinline__ uint16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, static_cast<__bf16>(f)); }
+__device__ __forceinline__ float rbf(float f) { return static_cast<float>(static_cast<__bf16>(f)); }
 __device__ __forceinline__ float lo_bf(uint32_t packed) { return __uint_as_float(packed << 16); }
 __device__ __forceinline__ float hi_bf(uint32_t packed) { return __uint_as_float(packed & 0xffff0000u); }
 __device__ __forceinline__ uint32_t pack_bf(float lo, float hi) {
-    return uint32_t(f2bf(lo)) | (uint32_t(f2bf(hi)) << 16);
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

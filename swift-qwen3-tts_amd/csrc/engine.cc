@@ -78,16 +78,18 @@ void Engine::alloc_workspace() {
             s.ld_logits = vocab;
             s.h = b.take<uint16_t>(size_t(Mp_) * hid);
             s.xn = b.take<uint16_t>(size_t(Mp_) * hid);
+            s.ss_a = b.take<float>(size_t(hid / 16) * Mp_);
+            s.ss_b = b.take<float>(size_t(hid / 16) * Mp_);
             s.qkv = b.take<uint16_t>(size_t(Mp_) * s.ld_qkv);
             s.ao = b.take<uint16_t>(size_t(Mp_) * q);
             s.act = b.take<uint16_t>(size_t(Mp_) * inter_p);
-            s.hidden = b.take<uint16_t>(size_t(Mp_) * hid);
             s.logits = b.take<uint16_t>(size_t(Mp_) * vocab);
         };
         stream(tk_, H, qd, kd, m_->talker.max_inter_p, t.vocab_size);
         stream(cp_, CH, cqd, ckd, m_->cp.max_inter_p, t.cp.vocab_size);
         cp_x_ = b.take<uint16_t>(size_t(Mp_) * H);
-        part_ = b.take<float>(size_t(8) * Mp_ * std::max(H, CH));
+        cp_x2_ = b.take<uint16_t>(size_t(Mp_) * H);
+        cp_ss2_ = b.take<float>(size_t(Mp_));
         kpool_ = b.take<uint16_t>(kv_layer_stride_ * L);
         vpool_ = b.take<uint16_t>(kv_layer_stride_ * L);
         cp_kpool_ = b.take<uint16_t>(cp_kv_layer_stride_ * CL);
@@ -127,52 +129,46 @@ void Engine::alloc_workspace() {
     Q3_HIP(hipMemcpy(cp_block_table_, cbt.data(), cbt.size() * 4, hipMemcpyHostToDevice));
 }
 
-int Engine::pick_split(int tiles, int chunks) const {
-    // smallest divisor S of `chunks` (<= 8) that gives >= 256 workgroups; else the largest one
-    int best = 1;
-    for (int s = 1; s <= 8; ++s) {
-        if (chunks % s) continue;
-        best = s;
-        if (tiles * s >= 256) break;
-    }
-    return best;
-}
-
-void Engine::gemm(const LinearW& L, const uint16_t* x, int xMB, int M, int epi, uint16_t* y, int ldy, int yMB, bool silu,
-                  int S) {
+GemmArgs Engine::gemm_args(const LinearW& L, const uint16_t* x, int M) const {
     GemmArgs a{};
     a.W = L.w;
     a.x = x;
-    a.xMB = xMB;
+    a.xMB = Mp_ / 16;
     a.M = M;
     a.Mpad = int(align_up(size_t(M), 16));
     a.N = L.Np;
     a.K = L.Kp;
-    a.S = S;
-    a.epi = epi;
-    a.y = y;
-    a.ldy = ldy;
-    a.y_tiled = yMB > 0 ? 1 : 0;  // yMB > 0: fragment-major output (it feeds another GEMM)
-    a.yMB = yMB;
     a.bias = L.bias;
-    a.act_silu = silu ? 1 : 0;
-    a.part = part_;
-    launch_gemm_skinny(a, st_);
+    a.ss_ld = Mp_;
+    return a;
 }
 
+// One pre-norm decoder layer = 5 launches (Talker.swift:451-469):
+//   qkv GEMM [RMSNorm prologue] -> attention -> o_proj GEMM [residual + sum(h^2) epilogue]
+//   -> gate/up GEMM [RMSNorm prologue, SwiGLU epilogue] -> down GEMM [residual + sum(h^2) epilogue]
+// w.h is the fragment-major residual stream; ss_a holds the per-tile sums of squares of the rows
+// entering a layer (`ss_count_in` partials for the first layer), ss_b those after o_proj.
 void Engine::enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, uint16_t* vpool, size_t layer_stride,
                             const int32_t* block_table, int max_pages, const int32_t* kv_len, const uint8_t* active,
-                            const uint16_t* final_w, bool need_final) {
-    const int H = s.hidden, Mp = int(align_up(size_t(B), 16));
-    const int MBL = Mp_ / 16;  // row blocks of every fragment-major activation buffer of this lane
-    int prevS = 0;  // splits of the pending down_proj partials
+                            int ss_count_in) {
+    const int H = s.hidden, MBL = Mp_ / 16, tiles = H / 16;
+    // The RMSNorm prologue re-normalises all of x in every workgroup: measured cheaper than a separate launch for
+    // K = 1024 (+2 us vs ~5 us) but not for K = 2048 (+5..10 us), so wide stacks keep a row-norm kernel.
+    const bool prologue = H <= 1024;
+    auto norm_into_xn = [&](const uint16_t* nw) {
+        NormRowsArgs n{};
+        n.h = w.h; n.hMB = MBL; n.w = nw; n.eps = s.eps; n.out = w.xn; n.outMB = MBL; n.M = B; n.H = H;
+        launch_norm_rows(n, st_);
+    };
     for (size_t l = 0; l < s.layers.size(); ++l) {
         const LayerW& L = s.layers[l];
-        ResidNormArgs n1{};
-        n1.h = w.h; n1.ldh = H; n1.part = prevS ? part_ : nullptr; n1.S = prevS; n1.Mpad = Mp;
-        n1.w = L.ln1; n1.eps = s.eps; n1.xn = w.xn; n1.xnMB = MBL; n1.M = B; n1.H = H;
-        launch_resid_norm(n1, st_);
-        gemm(L.qkv, w.xn, MBL, B, 0, w.qkv, w.ld_qkv, 0, false, 1);
+        if (!prologue) norm_into_xn(L.ln1);
+        GemmArgs q = gemm_args(L.qkv, prologue ? w.h : w.xn, B);
+        q.epi = 0; q.y = w.qkv; q.ldy = w.ld_qkv;
+        if (prologue) {
+            q.norm_w = L.ln1; q.ss_in = w.ss_a; q.ss_count = (l == 0) ? ss_count_in : tiles; q.norm_dim = H; q.norm_eps = s.eps;
+        }
+        launch_gemm_skinny(q, st_);
         AttnArgs at{};
         at.qkv = w.qkv; at.ld = w.ld_qkv; at.qn_w = L.qn; at.kn_w = L.kn; at.eps = s.eps;
         at.rope_cos = s.rope_cos; at.rope_sin = s.rope_sin;
@@ -181,45 +177,64 @@ void Engine::enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, 
         at.out = w.ao; at.outMB = MBL; at.n_heads = s.n_heads; at.n_kv = s.n_kv; at.B = B;
         at.scale = powf(float(kHeadDim), -0.5f);  // Talker.swift:179
         launch_attn_decode(at, st_);
-        const int So = pick_split(L.o.Np / 16, L.o.Kp / 128);
-        gemm(L.o, w.ao, MBL, B, 1, nullptr, 0, 0, false, So);
-        ResidNormArgs n2 = n1;
-        n2.part = part_; n2.S = So; n2.w = L.ln2;
-        launch_resid_norm(n2, st_);
-        gemm(L.gateup, w.xn, MBL, B, 2, w.act, 0, MBL, false, 1);
-        const int Sd = pick_split(L.down.Np / 16, L.down.Kp / 128);
-        gemm(L.down, w.act, MBL, B, 1, nullptr, 0, 0, false, Sd);
-        prevS = Sd;
-    }
-    if (need_final) {
-        ResidNormArgs nf{};
-        nf.h = w.h; nf.ldh = H; nf.part = part_; nf.S = prevS; nf.Mpad = Mp;
-        nf.w = final_w; nf.eps = s.eps; nf.xn = w.hidden; nf.xnMB = MBL; nf.M = B; nf.H = H;
-        launch_resid_norm(nf, st_);
+        GemmArgs o = gemm_args(L.o, w.ao, B);
+        o.epi = 3; o.y = w.h; o.yMB = MBL; o.resid = 1; o.ss_out = w.ss_b;
+        launch_gemm_skinny(o, st_);
+        if (!prologue) norm_into_xn(L.ln2);
+        GemmArgs g = gemm_args(L.gateup, prologue ? w.h : w.xn, B);
+        g.epi = 2; g.y = w.act; g.yMB = MBL;
+        if (prologue) {
+            g.norm_w = L.ln2; g.ss_in = w.ss_b; g.ss_count = tiles; g.norm_dim = H; g.norm_eps = s.eps;
+        }
+        launch_gemm_skinny(g, st_);
+        GemmArgs d = gemm_args(L.down, w.act, B);
+        d.epi = 3; d.y = w.h; d.yMB = MBL; d.resid = 1; d.ss_out = w.ss_a;
+        launch_gemm_skinny(d, st_);
     }
 }
 
-void Engine::enqueue_talker_step(int B, bool need_hidden) {
-    enqueue_layers(m_->talker, tk_, B, kpool_, vpool_, kv_layer_stride_, block_table_, max_pages_, kv_len_, active_,
-                   m_->talker.final_norm, need_hidden);
+void Engine::enqueue_talker_step(int B) {
+    enqueue_layers(m_->talker, tk_, B, kpool_, vpool_, kv_layer_stride_, block_table_, max_pages_, kv_len_, active_, 1);
 }
 
-void Engine::enqueue_cp_pass(int B, const uint16_t* x) {
-    const int CH = m_->cp.hidden;
-    if (m_->has_cp_proj)  // small_to_mtp_projection, CodePredictor.swift:327-330
-        gemm(m_->cp_proj, x, Mp_ / 16, B, 0, cp_.h, CH, 0, false, 1);
-    else
-        launch_untile_rows(x, Mp_ / 16, cp_.h, CH, B, CH, st_);
-    enqueue_layers(m_->cp, cp_, B, cp_kpool_, cp_vpool_, cp_kv_layer_stride_, cp_block_table_, 1, cp_len_, nullptr,
-                   m_->cp.final_norm, true);
+// One code-predictor pass (CodePredictor.swift:320-339 without the head). `from_talker`: the input is
+// the talker's final-normed hidden state (step 0, first position); otherwise it is the embedding the
+// previous sampler gathered (fragment-major in cp_x_ when a projection follows, else straight in cp_.h).
+void Engine::enqueue_cp_pass(int B, bool from_talker) {
+    const TalkerConfig& t = m_->cfg.talker;
+    const int H = t.hidden_size, CH = m_->cp.hidden, MBL = Mp_ / 16;
+    int ss_count = 1;
+    if (m_->has_cp_proj) {  // small_to_mtp_projection (biased), CodePredictor.swift:327-330
+        GemmArgs p = gemm_args(m_->cp_proj, from_talker ? tk_.h : cp_x_, B);
+        p.epi = 3; p.y = cp_.h; p.yMB = MBL; p.resid = 0; p.ss_out = cp_.ss_a;
+        if (from_talker) {  // talker final norm (Talker.swift:573) in the prologue
+            p.norm_w = m_->talker.final_norm; p.ss_in = tk_.ss_a; p.ss_count = H / 16; p.norm_dim = H; p.norm_eps = m_->talker.eps;
+        }
+        launch_gemm_skinny(p, st_);
+        ss_count = CH / 16;
+    } else if (from_talker) {
+        NormRowsArgs n{};
+        n.h = tk_.h; n.hMB = MBL; n.w = m_->talker.final_norm; n.eps = m_->talker.eps;
+        n.out = cp_.h; n.outMB = MBL; n.ss_out = cp_.ss_a; n.M = B; n.H = H;
+        launch_norm_rows(n, st_);
+    }  // else: the sampler wrote cp_.h and cp_.ss_a[0] itself
+    enqueue_layers(m_->cp, cp_, B, cp_kpool_, cp_vpool_, cp_kv_layer_stride_, cp_block_table_, 1, cp_len_, nullptr, ss_count);
 }
 
 void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
     const TalkerConfig& t = m_->cfg.talker;
     const int H = t.hidden_size, V = t.vocab_size, Vc = t.cp.vocab_size, CH = t.cp.hidden_size;
-    const int groups = t.num_code_groups;
-    enqueue_talker_step(B, true);
-    gemm(m_->codec_head, tk_.hidden, Mp_ / 16, B, 0, tk_.logits, tk_.ld_logits, 0, false, 1);
+    const int groups = t.num_code_groups, MBL = Mp_ / 16;
+    enqueue_talker_step(B);
+    {   // final norm (prologue) + codec_head (Talker.swift:573, 644)
+        GemmArgs hd = gemm_args(m_->codec_head, tk_.h, B);
+        hd.epi = 0; hd.y = tk_.logits; hd.ldy = tk_.ld_logits;
+        hd.norm_w = m_->talker.final_norm; hd.ss_in = tk_.ss_a; hd.ss_count = H / 16; hd.norm_dim = H; hd.norm_eps = m_->talker.eps;
+        launch_gemm_skinny(hd, st_);
+    }
+    // where the samplers put the next code-predictor input
+    uint16_t* next_x = m_->has_cp_proj ? cp_x_ : cp_.h;
+    float* next_ss = m_->has_cp_proj ? nullptr : cp_.ss_a;
     SamplerArgs sa{};
     sa.logits = tk_.logits; sa.ldl = tk_.ld_logits; sa.V = V; sa.sp = sp_dev_; sa.is_talker = 1;
     sa.suppress_lo = V - 1024; sa.suppress_hi = V; sa.eos_id = t.codec_eos_token_id;  // Qwen3.swift:829-835
@@ -228,15 +243,25 @@ void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
     sa.cur_codes = cur_codes_; sa.codes = codes_; sa.Fmax = Fcap_;
     sa.forced = dbg ? forced_dev_ : nullptr; sa.forced_frames = dbg ? dbg->frames : 0;
     sa.sampled = dbg ? sampled_dev_ : nullptr;
-    sa.emb = m_->codec_emb; sa.emb_ld = H; sa.next_x = cp_x_; sa.next_MB = Mp_ / 16; sa.H = H; sa.B = B;
+    // the embedding of code 0 is the SECOND position of predictor step 0 (Qwen3.swift:884-887). Without a projection a
+    // pass takes its input in cp_.h, which the first position (the talker hidden state) still needs: stage it in cp_x2_
+    sa.emb = m_->codec_emb; sa.emb_ld = H; sa.next_x = m_->has_cp_proj ? cp_x_ : cp_x2_; sa.next_MB = MBL;
+    sa.next_ss = m_->has_cp_proj ? nullptr : cp_ss2_; sa.H = H; sa.B = B;
     sa.logits_dump = (dbg && dbg->talker_logits) ? tl_dump_ : nullptr; sa.dump_ld = V; sa.dump_off = 0;
     launch_sampler(sa, st_);
-    // code predictor, step 0 = [hidden, embed(code0)] (Qwen3.swift:884-887) run as two positions
-    enqueue_cp_pass(B, tk_.hidden);
+    // code predictor, step 0 = [hidden, embed(code0)] run as two positions
+    enqueue_cp_pass(B, true);
     launch_advance_len(cp_len_, nullptr, B, st_);
+    if (!m_->has_cp_proj) {  // second position: move the staged embedding (and its sum of squares) into place
+        launch_copy_rows(cp_x2_, 0, cp_.h, 0, 1, Mp_ * H, st_);
+        launch_copy_rows(reinterpret_cast<const uint16_t*>(cp_ss2_), 0, reinterpret_cast<uint16_t*>(cp_.ss_a), 0, 1, Mp_ * 2, st_);
+    }
     for (int i = 0; i < groups - 1; ++i) {
-        enqueue_cp_pass(B, cp_x_);
-        gemm(m_->lm_head[size_t(i)], cp_.hidden, Mp_ / 16, B, 0, cp_.logits, cp_.ld_logits, 0, false, 1);
+        enqueue_cp_pass(B, false);
+        GemmArgs lh = gemm_args(m_->lm_head[size_t(i)], cp_.h, B);
+        lh.epi = 0; lh.y = cp_.logits; lh.ldy = cp_.ld_logits;
+        lh.norm_w = m_->cp.final_norm; lh.ss_in = cp_.ss_a; lh.ss_count = CH / 16; lh.norm_dim = CH; lh.norm_eps = m_->cp.eps;
+        launch_gemm_skinny(lh, st_);
         SamplerArgs sc{};
         sc.logits = cp_.logits; sc.ldl = cp_.ld_logits; sc.V = Vc; sc.sp = sp_dev_; sc.is_talker = 0;
         sc.eos_id = -1; sc.cb = i + 1; sc.n_frames = n_frames_; sc.max_frames = max_frames_;
@@ -245,7 +270,7 @@ void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
         sc.forced = dbg ? forced_dev_ : nullptr; sc.forced_frames = dbg ? dbg->frames : 0;
         sc.sampled = dbg ? sampled_dev_ : nullptr;
         if (i + 1 < groups - 1) {  // embedding of this code feeds the next pass (Qwen3.swift:889-892)
-            sc.emb = m_->cp_emb[size_t(i)]; sc.emb_ld = H; sc.next_x = cp_x_; sc.next_MB = Mp_ / 16;
+            sc.emb = m_->cp_emb[size_t(i)]; sc.emb_ld = H; sc.next_x = next_x; sc.next_MB = MBL; sc.next_ss = next_ss;
         }
         sc.H = H; sc.B = B;
         sc.logits_dump = (dbg && dbg->cp_logits) ? cl_dump_ : nullptr; sc.dump_ld = (groups - 1) * Vc; sc.dump_off = i * Vc;
@@ -254,7 +279,7 @@ void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
     FrameEndArgs fe{};
     fe.cur_codes = cur_codes_; fe.codec_emb = m_->codec_emb; fe.cp_emb = m_->cp_emb_dev;
     fe.trailing = trailing_; fe.n_trailing = n_trailing_; fe.trailing_idx = trailing_idx_; fe.Tmax = Tcap_;
-    fe.tts_pad = tts_pad_; fe.h = tk_.h; fe.ldh = H; fe.H = H; fe.B = B; fe.groups = groups;
+    fe.tts_pad = tts_pad_; fe.h = tk_.h; fe.hMB = MBL; fe.ss_out = tk_.ss_a; fe.H = H; fe.B = B; fe.groups = groups;
     fe.n_frames = n_frames_; fe.max_frames = max_frames_; fe.finished = finished_; fe.active = active_; fe.cp_len = cp_len_;
     launch_frame_end(fe, st_);
 }
@@ -345,8 +370,12 @@ void Engine::project_rows(const std::vector<int32_t>& ids, int rows) {
     for (int r0 = 0; r0 < rows; r0 += 64) {
         const int n = std::min(64, rows - r0);
         launch_gather_rows(m_->text_emb, TH, ids_dev_ + r0, m_->token_map, n, TH, proj_in_, TH, 4, st_);
-        gemm(m_->fc1, proj_in_, 4, n, 0, proj_mid_, 0, 4, true, 1);
-        gemm(m_->fc2, proj_mid_, 4, n, 0, proj_out_ + size_t(r0) * H, H, 0, false, 1);
+        GemmArgs f1 = gemm_args(m_->fc1, proj_in_, n);
+        f1.xMB = 4; f1.epi = 0; f1.y = proj_mid_; f1.y_tiled = 1; f1.yMB = 4; f1.act_silu = 1;
+        launch_gemm_skinny(f1, st_);
+        GemmArgs f2 = gemm_args(m_->fc2, proj_mid_, n);
+        f2.xMB = 4; f2.epi = 0; f2.y = proj_out_ + size_t(r0) * H; f2.ldy = H;
+        launch_gemm_skinny(f2, st_);
     }
 }
 
@@ -512,13 +541,14 @@ void Engine::generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp
     // ---- prefill: positions 0 .. Pmax-2 of the right-aligned prompts, then load the last one ----
     Q3_HIP(hipEventRecord(ev_[0], st_));
     PrefillLoadArgs pl{};
-    pl.prompt = prompt_; pl.n_prompt = n_prompt_; pl.Pmax = Pcap_; pl.H = H; pl.B = n; pl.h = tk_.h; pl.ldh = H; pl.active = active_;
+    pl.prompt = prompt_; pl.n_prompt = n_prompt_; pl.Pmax = Pcap_; pl.H = H; pl.B = n; pl.h = tk_.h; pl.hMB = Mp_ / 16;
+    pl.ss_out = tk_.ss_a; pl.active = active_;
     // prompt_ rows are laid out with stride Pcap_; right alignment is relative to the longest prompt
     for (int s = 0; s < Pmax; ++s) {
         pl.step = s + (Pcap_ - Pmax);
         launch_prefill_load(pl, st_);
         if (s + 1 < Pmax) {
-            enqueue_talker_step(n, false);
+            enqueue_talker_step(n);
             launch_advance_len(kv_len_, active_, n, st_);
         }
     }
@@ -700,7 +730,6 @@ void Engine::debug_linear(const uint16_t* x, const uint16_t* W, const uint16_t* 
     Q3_CHECK(M >= 1 && M <= 64 && K % 8 == 0 && N >= 1, 3, "debug_linear: unsupported shape");
     const int Kp = int(align_up(size_t(K), 128)), Np = int(align_up(size_t(N), 16)), Mp = int(align_up(size_t(M), 16));
     uint16_t *dW = nullptr, *dWt = nullptr, *dx = nullptr, *dy = nullptr, *db = nullptr;
-    float* dpart = nullptr;
     Q3_HIP(hipMalloc(reinterpret_cast<void**>(&dW), size_t(N) * K * 2));
     Q3_HIP(hipMalloc(reinterpret_cast<void**>(&dWt), size_t(Np) * Kp * 2));
     Q3_HIP(hipMalloc(reinterpret_cast<void**>(&dx), size_t(Mp) * Kp * 2));
@@ -719,24 +748,13 @@ void Engine::debug_linear(const uint16_t* x, const uint16_t* W, const uint16_t* 
     launch_tile_weights(dW, N, K, dWt, Kp / 128, 0, 1, st_);
     LinearW L;
     L.w = dWt; L.bias = bias ? db : nullptr; L.N = N; L.K = K; L.Np = Np; L.Kp = Kp;
-    // exercise both code paths: direct bf16 epilogue when it fills the chip, split-K + resid_norm fold otherwise
-    const int S = pick_split(Np / 16, Kp / 128);
-    if (S == 1 || bias || Np % 128 != 0) {
-        gemm(L, dx, Mp / 16, M, 0, dy, Np, 0, false, 1);
-    } else {
-        Q3_HIP(hipMalloc(reinterpret_cast<void**>(&dpart), size_t(S) * Mp * Np * 4));
-        Q3_HIP(hipMemsetAsync(dy, 0, size_t(Mp) * Np * 2, st_));  // residual stream = 0, so h <- bf16(0 + bf16(sum))
-        GemmArgs a{};
-        a.W = dWt; a.x = dx; a.xMB = Mp / 16; a.M = M; a.Mpad = Mp; a.N = Np; a.K = Kp; a.S = S; a.epi = 1; a.part = dpart;
-        launch_gemm_skinny(a, st_);
-        ResidNormArgs rn{};
-        rn.h = dy; rn.ldh = Np; rn.part = dpart; rn.S = S; rn.Mpad = Mp; rn.w = nullptr; rn.M = M; rn.H = Np;
-        Q3_CHECK(Np % 128 == 0, 3, "debug_linear: split-K path needs N % 128 == 0");
-        launch_resid_norm(rn, st_);
-    }
+    GemmArgs ga{};
+    ga.W = dWt; ga.x = dx; ga.xMB = Mp / 16; ga.M = M; ga.Mpad = Mp; ga.N = Np; ga.K = Kp; ga.epi = 0; ga.y = dy; ga.ldy = Np;
+    ga.bias = L.bias; ga.ss_ld = Mp;
+    launch_gemm_skinny(ga, st_);
     Q3_HIP(hipStreamSynchronize(st_));
     Q3_HIP(hipMemcpy2D(y, size_t(N) * 2, dy, size_t(Np) * 2, size_t(N) * 2, size_t(M), hipMemcpyDeviceToHost));
-    for (void* p : {(void*)dW, (void*)dWt, (void*)dx, (void*)dxl, (void*)dy, (void*)db, (void*)dpart})
+    for (void* p : {(void*)dW, (void*)dWt, (void*)dx, (void*)dxl, (void*)dy, (void*)db})
         if (p) (void)hipFree(p);
 }
 

@@ -76,11 +76,13 @@ class Engine {
     uint8_t* ws_ = nullptr;
     size_t ws_bytes_ = 0;
     struct Stream {  // activation buffers of one decoder stack
-        uint16_t *h, *xn, *qkv, *ao, *act, *hidden, *logits;
+        uint16_t *h, *xn, *qkv, *ao, *act, *logits;  // h, xn, ao, act: fragment-major; qkv, logits: row-major
+        float *ss_a, *ss_b;                     // per-tile sums of squares of h ([H/16][Mp])
         int ld_qkv, ld_act, ld_logits;
     } tk_{}, cp_{};
-    uint16_t* cp_x_ = nullptr;  // [Mp][H] code-predictor input before the projection
-    float* part_ = nullptr;
+    uint16_t* cp_x_ = nullptr;   // fragment-major [Mp][H] code-predictor input before the projection
+    uint16_t* cp_x2_ = nullptr;  // staged embedding of code 0 (second position of predictor step 0)
+    float* cp_ss2_ = nullptr;
     uint16_t *kpool_ = nullptr, *vpool_ = nullptr, *cp_kpool_ = nullptr, *cp_vpool_ = nullptr;
     size_t kv_layer_stride_ = 0, cp_kv_layer_stride_ = 0;
     int32_t *block_table_ = nullptr, *cp_block_table_ = nullptr;
@@ -108,13 +110,12 @@ class Engine {
     void project_rows(const std::vector<int32_t>& ids, int rows);  // ids -> proj_out_[rows][H]
     void enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, uint16_t* vpool, size_t layer_stride,
                         const int32_t* block_table, int max_pages, const int32_t* kv_len, const uint8_t* active,
-                        const uint16_t* final_w, bool need_final);
-    void enqueue_talker_step(int B, bool need_hidden);
-    void enqueue_cp_pass(int B, const uint16_t* x);  // x: fragment-major [B][H]
+                        int ss_count_in);
+    void enqueue_talker_step(int B);
+    void enqueue_cp_pass(int B, bool from_talker);
     void enqueue_frame(int B, const DebugOpts* dbg);
     hipGraphExec_t frame_graph(int B);
-    int pick_split(int tiles, int chunks) const;
-    void gemm(const LinearW& L, const uint16_t* x, int xMB, int M, int epi, uint16_t* y, int ldy, int yMB, bool silu, int S);
+    GemmArgs gemm_args(const LinearW& L, const uint16_t* x, int M) const;
 };
 
 

@@ -13,34 +13,41 @@ constexpr int kHeadDim = 128;    // Qwen3-TTS talker / code predictor head_dim (
 
 // ---- skinny GEMM (gemm_decode.hip) -------------------------------------------------------------
 struct GemmArgs {
-    const uint16_t* W;  // tiled weights (weights.cc: tile_weights)
+    const uint16_t* W;  // tiled weights (repack.hip)
     const uint16_t* x;  // fragment-major activations (common.h: act_tiled_offset), rows >= M ignored
     int xMB;            // row blocks of the x allocation
     int M, Mpad, N, K;  // N, K are the padded (tiled) sizes
-    int S;              // K splits across workgroups (epi 1 only when > 1)
-    int epi;            // 0: y=bf16(acc+bias) (+silu)   1: fp32 partial slab   2: gate/up -> silu(g)*u
-    uint16_t* y;        // epi 0: row-major [M][ldy], or fragment-major when y_tiled; epi 2: fragment-major
+    int epi;            // 0: y=bf16(acc+bias) (+silu)   2: gate/up -> silu(g)*u   3: hidden-state store (+residual)
+    uint16_t* y;        // epi 0: row-major [M][ldy], or fragment-major when y_tiled; epi 2/3: fragment-major
     int ldy;
     int y_tiled, yMB;
     const uint16_t* bias;
     int act_silu;
-    float* part;        // [S][Mpad][N]
+    // RMSNorm prologue (norm_w != nullptr): x is the raw residual stream
+    const uint16_t* norm_w;  // [K] row-major
+    const float* ss_in;      // [ss_count][ss_ld] per-tile sums of squares of x rows
+    int ss_count, ss_ld, norm_dim;
+    float norm_eps;
+    // epi 3
+    int resid;               // 1: y = bf16(y_old + bf16(acc+bias)); 0: y = bf16(acc+bias)
+    float* ss_out;           // [N/16][ss_ld] this tile's share of sum(y^2) per row, or nullptr
 };
 void launch_gemm_skinny(const GemmArgs& a, hipStream_t st);
 
-// ---- residual add + RMSNorm (lm_misc.hip) ------------------------------------------------------
-struct ResidNormArgs {
-    uint16_t* h;        // [M][ldh] residual stream, updated in place when part != nullptr
-    int ldh;
-    const float* part;  // [S][Mpad][H] partial slabs of the preceding projection, or nullptr
-    int S, Mpad;
-    const uint16_t* w;  // norm weight [H]; nullptr: only fold the partials into h
+// ---- RMSNorm of whole rows (lm_misc.hip): only where a normalised vector must be materialised --
+// (the code predictor's first input when there is no small_to_mtp_projection). In the layers the
+// norm lives in the consumer GEMM's prologue.
+struct NormRowsArgs {
+    const uint16_t* h;  // fragment-major [M][H]
+    int hMB;
+    const uint16_t* w;
     float eps;
-    uint16_t* xn;       // fragment-major (next GEMM's x operand)
-    int xnMB;
+    uint16_t* out;      // fragment-major
+    int outMB;
+    float* ss_out;      // [ss_ld]: sum(out^2) per row (first partial of the consumer's norm) or nullptr
     int M, H;
 };
-void launch_resid_norm(const ResidNormArgs& a, hipStream_t st);
+void launch_norm_rows(const NormRowsArgs& a, hipStream_t st);
 
 // ---- QK-norm + RoPE + KV append + paged decode attention (attn_decode.hip) ---------------------
 struct AttnArgs {
@@ -100,6 +107,7 @@ struct SamplerArgs {
     int emb_ld;
     uint16_t* next_x;        // fragment-major [B][H] or nullptr
     int next_MB;
+    float* next_ss;          // [B] sum of squares of the gathered row (norm prologue of the consumer) or nullptr
     int H;
     int B;
     uint16_t* logits_dump;   // [B][forced_frames][dump_ld] (tests) or nullptr
@@ -123,8 +131,9 @@ struct PrefillLoadArgs {
     const uint16_t* prompt;   // [B][Pmax][H]
     const int32_t* n_prompt;  // [B]
     int Pmax, step, H, B;
-    uint16_t* h;              // [B][ldh]
-    int ldh;
+    uint16_t* h;              // fragment-major [B][H]
+    int hMB;
+    float* ss_out;            // [B] sum of squares of the loaded row
     uint8_t* active;          // [B]
 };
 void launch_prefill_load(const PrefillLoadArgs& a, hipStream_t st);
@@ -139,8 +148,9 @@ struct FrameEndArgs {  // Qwen3.swift:919-935 + loop bookkeeping
     int32_t* trailing_idx;        // [B]
     int Tmax;
     const uint16_t* tts_pad;      // [H]
-    uint16_t* h;                  // [B][ldh] next talker input
-    int ldh, H, B, groups;
+    uint16_t* h;                  // fragment-major [B][H] next talker input
+    int hMB, H, B, groups;
+    float* ss_out;                // [B] sum of squares of the new input
     int32_t* n_frames;
     const int32_t* max_frames;
     uint8_t* finished;

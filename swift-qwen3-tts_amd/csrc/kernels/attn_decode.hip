@@ -33,14 +33,16 @@ __device__ __forceinline__ void norm_rope(float x0, float x1, const uint16_t* w,
     o1 = rbf(rbf(y1 * bf2f(cosr[lane + 64])) + rbf(y0 * bf2f(sinr[lane + 64])));
 }
 
-template <int REP>
-__global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
+template <int REP, int NTH>
+__global__ __launch_bounds__(NTH) void attn_decode_kernel(AttnArgs a) {
+    constexpr int NG = NTH / 16;  // 16-lane groups striding over cache positions
+    constexpr int NWV = NTH / 64;
     __shared__ __attribute__((aligned(16))) float q_s[REP][D];
     __shared__ float k_s[D];
     __shared__ float v_s[D];
-    __shared__ float m_s[16][REP];
-    __shared__ float l_s[16][REP];
-    __shared__ float acc_s[16][REP][D];
+    __shared__ float m_s[NG][REP];
+    __shared__ float l_s[NG][REP];
+    __shared__ float acc_s[NG][REP][D];
 
     const int kvh = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
     const size_t nslot = (((size_t)npage * a.n_kv + kvh) * kPageTokens + (len % kPageTokens)) * D;
 
     // ---- phase 1: q/k norm + rope, v copy; vectors round-robin over the 4 waves ----
-    for (int j = wave; j < REP + 2; j += 4) {
+    for (int j = wave; j < REP + 2; j += NWV) {
         if (j < REP) {
             const uint16_t* qp = row + (size_t)(kvh * REP + j) * D;
             float o0, o1;
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
         }
     };
 
-    for (int t = g; t < len; t += 16) {
+    for (int t = g; t < len; t += NG) {
         const int page = bt[t / kPageTokens];
         const size_t off = (((size_t)page * a.n_kv + kvh) * kPageTokens + (t % kPageTokens)) * D + 8 * c;
         const uint4 kr = *reinterpret_cast<const uint4*>(a.kpool + off);
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
         float vf[8] = {lo_bf(vr.x), hi_bf(vr.x), lo_bf(vr.y), hi_bf(vr.y), lo_bf(vr.z), hi_bf(vr.z), lo_bf(vr.w), hi_bf(vr.w)};
         step(kf, vf);
     }
-    if (g == (len & 15)) {  // the new token (kept in LDS: it may not be in the cache when !append)
+    if (g == (len % NG)) {  // the new token (kept in LDS: it may not be in the cache when !append)
         float kf[8], vf[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -156,14 +158,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
 
     // ---- merge the 16 groups: thread -> (head, dim); results staged in LDS for 16-byte stores ----
     uint16_t* out_s = reinterpret_cast<uint16_t*>(&q_s[0][0]);  // q_s is dead: every wave passed the barrier above
-    for (int o = tid; o < REP * D; o += 256) {
+    for (int o = tid; o < REP * D; o += NTH) {
         const int h = o / D, d = o % D;
         float M = -INFINITY;
 #pragma unroll
-        for (int gg = 0; gg < 16; ++gg) M = fmaxf(M, m_s[gg][h]);
+        for (int gg = 0; gg < NG; ++gg) M = fmaxf(M, m_s[gg][h]);
         float num = 0.f, den = 0.f;
 #pragma unroll
-        for (int gg = 0; gg < 16; ++gg) {
+        for (int gg = 0; gg < NG; ++gg) {
             const float w = (m_s[gg][h] == -INFINITY) ? 0.f : __expf(m_s[gg][h] - M);
             num += acc_s[gg][h][d] * w;
             den += l_s[gg][h] * w;
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
         out_s[o] = f2bf(num / den);
     }
     __syncthreads();
-    for (int p = tid; p < REP * D / 8; p += 256) {  // fragment-major store (x operand of o_proj)
+    for (int p = tid; p < REP * D / 8; p += NTH) {  // fragment-major store (x operand of o_proj)
         const int col = (kvh * REP) * D + 8 * p;
         *reinterpret_cast<uint4*>(a.out + act_tiled_offset(b, col, a.outMB)) = *reinterpret_cast<const uint4*>(out_s + 8 * p);
     }
@@ -182,13 +184,19 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
 void launch_attn_decode(const AttnArgs& a, hipStream_t st) {
     const int rep = a.n_heads / a.n_kv;
     Q3_CHECK(rep * a.n_kv == a.n_heads && rep >= 1 && rep <= kMaxRep, 3, "attn_decode: unsupported GQA ratio");
-    dim3 grid(a.n_kv, a.B), block(256);
+    dim3 grid(a.n_kv, a.B);
+    // short caches (the code predictor never holds more than 17 tokens): one wave per (row, kv head), so the
+    // workgroup barriers are free and nothing waits on other waves; long caches: 4 waves split the positions
+#define Q3_ATTN(R) \
+    if (a.max_pages == 1) hipLaunchKernelGGL((attn_decode_kernel<R, 64>), grid, dim3(64), 0, st, a); \
+    else hipLaunchKernelGGL((attn_decode_kernel<R, 256>), grid, dim3(256), 0, st, a)
     switch (rep) {
-        case 1: hipLaunchKernelGGL(attn_decode_kernel<1>, grid, block, 0, st, a); break;
-        case 2: hipLaunchKernelGGL(attn_decode_kernel<2>, grid, block, 0, st, a); break;
-        case 3: hipLaunchKernelGGL(attn_decode_kernel<3>, grid, block, 0, st, a); break;
-        case 4: hipLaunchKernelGGL(attn_decode_kernel<4>, grid, block, 0, st, a); break;
+        case 1: Q3_ATTN(1); break;
+        case 2: Q3_ATTN(2); break;
+        case 3: Q3_ATTN(3); break;
+        case 4: Q3_ATTN(4); break;
     }
+#undef Q3_ATTN
 }
 
 }  // namespace q3

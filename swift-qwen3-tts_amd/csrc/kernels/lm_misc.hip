@@ -8,58 +8,41 @@
 namespace q3 {
 namespace {
 
-// Residual add + RMSNorm. One workgroup per row.
-//   h  <- bf16(h + bf16(sum_s part[s]))          residual adds Talker.swift:461,466
-//   xn <- bf16( bf16(h * rstd) * w )             MLXNN.RMSNorm, Talker.swift:447-448,520
-// The split-K partial slabs of the preceding o_proj / down_proj GEMM are summed here in fixed
-// order, so the projection's rounding point (bf16 of the full fp32 sum) is the reference's.
-__global__ __launch_bounds__(256) void resid_norm_kernel(ResidNormArgs a) {
-    __shared__ float wsum[4];
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return ((sh[0] + sh[1]) + sh[2]) + sh[3];
+}
+
+// RMSNorm of whole rows, fragment-major in and out. One workgroup per row.
+//   out <- bf16( bf16(h * rstd) * w )            MLXNN.RMSNorm, Talker.swift:520,573
+__global__ __launch_bounds__(256) void norm_rows_kernel(NormRowsArgs a) {
+    __shared__ float sh[4];
     constexpr int kTrips = 2;  // H <= 4096
-    const int m = blockIdx.x;
-    const int tid = threadIdx.x;
-    uint16_t* hrow = a.h + (size_t)m * a.ldh;
+    const int m = blockIdx.x, tid = threadIdx.x;
     float v[kTrips][8];
     uint4 wv[kTrips];
     float ss = 0.f;
-    // each thread owns elements tid*8 .. tid*8+7 (+2048 per trip); everything is loaded up front
 #pragma unroll
     for (int tr = 0; tr < kTrips; ++tr) {
         const int i0 = tid * 8 + tr * 2048;
         if (i0 < a.H) {
-            const uint4 hv = *reinterpret_cast<const uint4*>(hrow + i0);
-            if (a.w) wv[tr] = *reinterpret_cast<const uint4*>(a.w + i0);
+            const uint4 hv = *reinterpret_cast<const uint4*>(a.h + act_tiled_offset(m, i0, a.hMB));
+            wv[tr] = *reinterpret_cast<const uint4*>(a.w + i0);
             const uint32_t hw[4] = {hv.x, hv.y, hv.z, hv.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 v[tr][2 * j] = lo_bf(hw[j]);
                 v[tr][2 * j + 1] = hi_bf(hw[j]);
+                ss += v[tr][2 * j] * v[tr][2 * j] + v[tr][2 * j + 1] * v[tr][2 * j + 1];
             }
-            if (a.part) {
-                float y[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                for (int s = 0; s < a.S; ++s) {
-                    const float4* pp = reinterpret_cast<const float4*>(a.part + ((size_t)s * a.Mpad + m) * a.H + i0);
-                    const float4 p0 = pp[0], p1 = pp[1];
-                    y[0] += p0.x; y[1] += p0.y; y[2] += p0.z; y[3] += p0.w;
-                    y[4] += p1.x; y[5] += p1.y; y[6] += p1.z; y[7] += p1.w;
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[tr][j] = rbf(v[tr][j] + rbf(y[j]));
-                uint4 o;
-                o.x = pack_bf(v[tr][0], v[tr][1]); o.y = pack_bf(v[tr][2], v[tr][3]);
-                o.z = pack_bf(v[tr][4], v[tr][5]); o.w = pack_bf(v[tr][6], v[tr][7]);
-                *reinterpret_cast<uint4*>(hrow + i0) = o;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) ss += v[tr][j] * v[tr][j];
         }
     }
-    if (!a.w) return;
-    ss = wave_sum(ss);
-    if ((tid & 63) == 0) wsum[tid >> 6] = ss;
-    __syncthreads();
-    const float tot = ((wsum[0] + wsum[1]) + wsum[2]) + wsum[3];
+    const float tot = block_sum_256(ss, sh);
     const float rstd = 1.0f / sqrtf(tot / (float)a.H + a.eps);
+    float so = 0.f;
 #pragma unroll
     for (int tr = 0; tr < kTrips; ++tr) {
         const int i0 = tid * 8 + tr * 2048;
@@ -68,11 +51,17 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(ResidNormArgs a) {
             uint32_t ow[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float n0 = rbf(v[tr][2 * j] * rstd), n1 = rbf(v[tr][2 * j + 1] * rstd);
-                ow[j] = pack_bf(n0 * lo_bf(ww[j]), n1 * hi_bf(ww[j]));
+                const float o0 = rbf(rbf(v[tr][2 * j] * rstd) * lo_bf(ww[j]));
+                const float o1 = rbf(rbf(v[tr][2 * j + 1] * rstd) * hi_bf(ww[j]));
+                so += o0 * o0 + o1 * o1;
+                ow[j] = pack_bf(o0, o1);
             }
-            *reinterpret_cast<uint4*>(a.xn + act_tiled_offset(m, i0, a.xnMB)) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+            *reinterpret_cast<uint4*>(a.out + act_tiled_offset(m, i0, a.outMB)) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
         }
+    }
+    if (a.ss_out) {
+        const float t2 = block_sum_256(so, sh);
+        if (tid == 0) a.ss_out[m] = t2;
     }
 }
 
@@ -133,14 +122,23 @@ __global__ void copy_rows_kernel(const uint16_t* src, int lds, uint16_t* dst, in
 
 // Right-aligned position-by-position prefill: row b starts at step Pmax - n_prompt[b], so every
 // row finishes its prompt at the same step and enters the frame loop together.
-__global__ void prefill_load_kernel(PrefillLoadArgs a) {
+__global__ __launch_bounds__(256) void prefill_load_kernel(PrefillLoadArgs a) {
+    __shared__ float sh[4];
     const int b = blockIdx.x;
     const int idx = a.step - (a.Pmax - a.n_prompt[b]);
     const bool on = idx >= 0;
     if (threadIdx.x == 0) a.active[b] = on ? 1 : 0;
     const uint4* src = reinterpret_cast<const uint4*>(a.prompt + ((size_t)b * a.Pmax + (on ? idx : 0)) * a.H);
-    uint4* dst = reinterpret_cast<uint4*>(a.h + (size_t)b * a.ldh);
-    for (int i = threadIdx.x; i < a.H / 8; i += blockDim.x) dst[i] = src[i];
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < a.H / 8; i += 256) {
+        const uint4 v = src[i];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ss += lo_bf(w[j]) * lo_bf(w[j]) + hi_bf(w[j]) * hi_bf(w[j]);
+        *reinterpret_cast<uint4*>(a.h + act_tiled_offset(b, 8 * i, a.hMB)) = v;
+    }
+    const float tot = block_sum_256(ss, sh);
+    if (threadIdx.x == 0) a.ss_out[b] = tot;
 }
 
 __global__ void advance_len_kernel(int32_t* kv_len, const uint8_t* active, int B) {
@@ -165,16 +163,34 @@ __global__ __launch_bounds__(256) void frame_end_kernel(FrameEndArgs a) {
     rows[0] = a.codec_emb + (size_t)cc[0] * a.H;
 #pragma unroll
     for (int g = 1; g < 16; ++g) rows[g] = (g < a.groups) ? a.cp_emb[g - 1] + (size_t)cc[g] * a.H : rows[0];
-    for (int i = threadIdx.x; i < a.H; i += blockDim.x) {
-        float e[16];
+    __shared__ float sh[4];
+    float ss = 0.f;
+    for (int i0 = threadIdx.x * 8; i0 < a.H; i0 += 256 * 8) {
+        uint4 e[16];
 #pragma unroll
-        for (int g = 0; g < 16; ++g) e[g] = bf2f(rows[g][i]);  // 16 independent loads in flight
-        float ce = e[0];
+        for (int g = 0; g < 16; ++g) e[g] = *reinterpret_cast<const uint4*>(rows[g] + i0);  // 16 independent loads
+        const uint4 tx = *reinterpret_cast<const uint4*>(text + i0);
+        const uint32_t tw[4] = {tx.x, tx.y, tx.z, tx.w};
+        uint32_t ow[4];
 #pragma unroll
-        for (int g = 1; g < 16; ++g)
-            if (g < a.groups) ce = rbf(ce + e[g]);
-        a.h[(size_t)b * a.ldh + i] = f2bf(bf2f(text[i]) + ce);
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t first = (&e[0].x)[j];
+            float c0 = lo_bf(first), c1 = hi_bf(first);
+#pragma unroll
+            for (int g = 1; g < 16; ++g)
+                if (g < a.groups) {
+                    const uint32_t w = (&e[g].x)[j];
+                    c0 = rbf(c0 + lo_bf(w));
+                    c1 = rbf(c1 + hi_bf(w));
+                }
+            const float h0 = rbf(lo_bf(tw[j]) + c0), h1 = rbf(hi_bf(tw[j]) + c1);
+            ss += h0 * h0 + h1 * h1;
+            ow[j] = pack_bf(h0, h1);
+        }
+        *reinterpret_cast<uint4*>(a.h + act_tiled_offset(b, i0, a.hMB)) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
     }
+    const float tot = block_sum_256(ss, sh);
+    if (threadIdx.x == 0) a.ss_out[b] = tot;
     __syncthreads();  // every thread has read trailing_idx before it moves
     if (threadIdx.x == 0) {
         if (has_text) a.trailing_idx[b] = ti + 1;
@@ -190,9 +206,9 @@ __global__ __launch_bounds__(256) void frame_end_kernel(FrameEndArgs a) {
 
 }  // namespace
 
-void launch_resid_norm(const ResidNormArgs& a, hipStream_t st) {
-    Q3_CHECK(a.H % 128 == 0 && a.H <= 4096 && a.ldh % 8 == 0, 3, "resid_norm: H must be a multiple of 128, at most 4096");
-    hipLaunchKernelGGL(resid_norm_kernel, dim3(a.M), dim3(256), 0, st, a);
+void launch_norm_rows(const NormRowsArgs& a, hipStream_t st) {
+    Q3_CHECK(a.H % 128 == 0 && a.H <= 4096, 3, "norm_rows: H must be a multiple of 128, at most 4096");
+    hipLaunchKernelGGL(norm_rows_kernel, dim3(a.M), dim3(256), 0, st, a);
 }
 void launch_gather_rows(const uint16_t* table, int ld, const int32_t* ids, const int32_t* token_map, int n,
                         int dim, uint16_t* out, int ldo, int out_MB, hipStream_t st) {

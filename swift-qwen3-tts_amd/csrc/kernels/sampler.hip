@@ -203,14 +203,33 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(SamplerArgs a) {
                         atomicAdd(&hist[level == 0 ? (key[k] >> 8) : (key[k] & 0xff)], 1u);
                 }
                 __syncthreads();
-                if (tid == 0) {
-                    int cum = 0, bin = 255;
-                    for (; bin > 0; --bin) {
-                        if (cum + (int)hist[bin] >= need) break;
-                        cum += (int)hist[bin];
+                if (tid < 64) {  // one wave: lane l owns bins 4l..4l+3; inclusive suffix sums by shuffles
+                    const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+                    const int own = (int)(h0 + h1 + h2 + h3);
+                    int suf = own;  // sum over lanes >= tid
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const int v = __shfl_down(suf, o, 64);
+                        if (tid + o < 64) suf += v;
                     }
-                    sel[0] = bin;
-                    sel[1] = need - cum;
+                    const int above = suf - own;  // elements in bins owned by higher lanes
+                    // the crossing bin is the highest bin whose cumulative count from the top reaches `need`
+                    const bool mine = above < need && suf >= need;
+                    const bool none = __ballot(mine) == 0ull;  // fewer than `need` elements in total: take bin 0
+                    if (mine) {
+                        int cum = above, bin = 4 * tid + 3;
+                        const int hh[4] = {(int)h0, (int)h1, (int)h2, (int)h3};
+                        for (; bin > 4 * tid; --bin) {
+                            if (cum + hh[bin & 3] >= need) break;
+                            cum += hh[bin & 3];
+                        }
+                        sel[0] = bin;
+                        sel[1] = need - cum;
+                    }
+                    if (none && tid == 0) {
+                        sel[0] = 0;
+                        sel[1] = need - (suf - (int)h0);
+                    }
                 }
                 __syncthreads();
                 if (level == 0) prefix = (uint32_t)sel[0];
@@ -326,8 +345,25 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(SamplerArgs a) {
     }
     if (a.next_x) {
         const uint4* src = reinterpret_cast<const uint4*>(a.emb + (size_t)used * a.emb_ld);
-        for (int i = tid; i < a.H / 8; i += kThreads)
-            *reinterpret_cast<uint4*>(a.next_x + act_tiled_offset(b, 8 * i, a.next_MB)) = src[i];
+        float ss = 0.f;
+        for (int i = tid; i < a.H / 8; i += kThreads) {
+            const uint4 v = src[i];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ss += lo_bf(w[j]) * lo_bf(w[j]) + hi_bf(w[j]) * hi_bf(w[j]);
+            *reinterpret_cast<uint4*>(a.next_x + act_tiled_offset(b, 8 * i, a.next_MB)) = v;
+        }
+        if (a.next_ss) {  // sum of squares of the row: first (and only) partial of the consumer's norm prologue
+            ss = wave_sum(ss);
+            __syncthreads();
+            if ((tid & 63) == 0) vals[tid >> 6] = ss;
+            __syncthreads();
+            if (tid == 0) {
+                float t = 0.f;
+                for (int w = 0; w < kThreads / 64; ++w) t += vals[w];
+                a.next_ss[b] = t;
+            }
+        }
     }
 }
 
