@@ -37,6 +37,7 @@ Engine::Engine(Model* model, const q3tts_load_opts& opts) : m_(model), opts_(opt
     Q3_HIP(hipSetDevice(m_->device));
     Q3_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
     for (auto& e : ev_) Q3_HIP(hipEventCreate(&e));
+    for (auto& e : burst_ev_) Q3_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     Bm_ = opts.max_batch;
     Mp_ = int(align_up(size_t(Bm_), 16));
     Pcap_ = opts.max_prompt;
@@ -57,6 +58,8 @@ Engine::~Engine() {
     for (void* p : {(void*)forced_dev_, (void*)sampled_dev_, (void*)tl_dump_, (void*)cl_dump_})
         if (p) (void)hipFree(p);
     for (auto& e : ev_)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& e : burst_ev_)
         if (e) (void)hipEventDestroy(e);
     if (st_) (void)hipStreamDestroy(st_);
 }
@@ -560,29 +563,31 @@ void Engine::generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp
     std::vector<int32_t> h_nframes((size_t)(n), 0), h_codes;
     std::vector<uint8_t> h_fin((size_t)(n), 0);
     std::vector<int> reported((size_t)(n), 0);
-    const int poll = 8;
     int launched = 0;
     const bool fixed_len = sp.force_frames > 0 || dbg;
+    // Frames are enqueued in bursts with at most two bursts in flight (event ring), so the AQL queue never fills:
+    // a host thread blocked on queue back-pressure starves the other lanes' submissions (measured: lanes gave no
+    // speed-up until the depth was bounded). Variable-length runs also poll the finished flags once per burst.
+    const int burst_frames = std::max(1, max_inflight_frames / 2);
+    hipEvent_t ring[2] = {burst_ev_[0], burst_ev_[1]};
+    int bursts = 0;
     bool done = false;
     while (!done && launched < frames_cap) {
-        const int burst = (fixed_len && !cb) ? (frames_cap - launched) : std::min(poll, frames_cap - launched);
-        const double t_host0 = now_s();
+        if (bursts >= 2) Q3_HIP(hipEventSynchronize(ring[bursts & 1]));  // burst (bursts-2) has drained
+        const int burst = std::min(burst_frames, frames_cap - launched);
         for (int i = 0; i < burst; ++i) {
             if (use_graph) Q3_HIP(hipGraphLaunch(ge, st_));
             else enqueue_frame(n, dbg);
         }
-        if (getenv("Q3TTS_DEBUG_TIMING")) {
-            const double t_host1 = now_s();
-            Q3_HIP(hipStreamSynchronize(st_));
-            const double t_host2 = now_s();
-            fprintf(stderr, "[q3tts] lane rows=%d burst=%d host-enqueue %.3f ms/frame, drain after enqueue %.3f ms total\n", n, burst,
-                    (t_host1 - t_host0) * 1e3 / burst, (t_host2 - t_host1) * 1e3);
-        }
         launched += burst;
-        if (fixed_len && !cb) break;
-        Q3_HIP(hipMemcpyAsync(h_nframes.data(), n_frames_, size_t(n) * 4, hipMemcpyDeviceToHost, st_));
-        Q3_HIP(hipMemcpyAsync(h_fin.data(), finished_, size_t(n), hipMemcpyDeviceToHost, st_));
-        Q3_HIP(hipStreamSynchronize(st_));
+        if (!(fixed_len && !cb)) {  // per-burst poll of the flags (async copies ordered after the burst)
+            Q3_HIP(hipMemcpyAsync(h_nframes.data(), n_frames_, size_t(n) * 4, hipMemcpyDeviceToHost, st_));
+            Q3_HIP(hipMemcpyAsync(h_fin.data(), finished_, size_t(n), hipMemcpyDeviceToHost, st_));
+        }
+        Q3_HIP(hipEventRecord(ring[bursts & 1], st_));
+        ++bursts;
+        if (fixed_len && !cb) continue;
+        Q3_HIP(hipEventSynchronize(ring[(bursts - 1) & 1]));
         done = true;
         for (int b = 0; b < n; ++b) done = done && h_fin[size_t(b)];
         if (cb) {  // .token events in generation order (Qwen3+Streaming.swift:24-27)
@@ -822,8 +827,8 @@ void Engine::debug_codec_stage(const int32_t* codes, int n_frames, const char* s
 // ------------------------------------------------------------------------------------------------
 EngineGroup::EngineGroup(std::unique_ptr<Model> model, const q3tts_load_opts& opts) : model_(std::move(model)), opts_(opts) {
     int lanes = opts.n_streams;
-    // measured on MI355X / ROCm 7.2: with >= 2 lanes the aggregate node-enqueue rate of
-    // hipGraphLaunch (~3.2 us per kernel node) caps throughput, so one lane is the default
+    // Measured: a lane's frame step takes ~4-5 ms whatever its batch size (latency-bound chain),
+    // and n concurrent chains overlap by only 1.6x (n=2) / 2.2x (n=4), so splitting a batch into lanes never pays.
     if (lanes <= 0) lanes = 1;
     lanes = std::max(1, std::min(lanes, opts.max_batch));
     q3tts_load_opts lo = opts;
@@ -831,6 +836,8 @@ EngineGroup::EngineGroup(std::unique_ptr<Model> model, const q3tts_load_opts& op
     for (int i = 0; i < lanes; ++i) {
         lanes_.push_back(std::make_unique<Engine>(model_.get(), lo));
         lanes_.back()->cb_mutex = &cb_mutex_;
+        // keep the sum of queued kernel packets of all lanes well under the 16k-entry AQL queue (~650 nodes per frame)
+        lanes_.back()->max_inflight_frames = std::max(2, 12000 / 650 / lanes);
     }
     speakers = lanes_[0]->speakers;
 }

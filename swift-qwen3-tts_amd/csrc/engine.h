@@ -65,10 +65,12 @@ class Engine {
     uint32_t row_offset = 0;       // global index of this lane's first row (RNG stream id)
     std::mutex* cb_mutex = nullptr;  // serialises event callbacks across lanes
     int request_base = 0;          // added to request_index in events
+    int max_inflight_frames = 16;  // frame steps queued but not finished (two bursts of half this)
   private:
     q3tts_load_opts opts_;
     hipStream_t st_ = nullptr;
     hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t burst_ev_[2] = {nullptr, nullptr};
     int Bm_ = 0, Mp_ = 0;  // max batch, padded to 16
     int Pcap_ = 0, Tcap_ = 0, Fcap_ = 0, max_pages_ = 0, n_pages_ = 0;
 
