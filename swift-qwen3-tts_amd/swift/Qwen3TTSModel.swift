@@ -1,0 +1,159 @@
+//
+//  Qwen3TTSModel.swift -- Swift shim over the C ABI in include/q3tts.h.
+//
+//  Keeps the public surface of AtomGradient/swift-qwen3-tts (Sources/Qwen3TTS/Models/Qwen3.swift:30,
+//  :1291-1301, :1382; Qwen3+Streaming.swift:8-18; Core/GenerationTypes.swift:15-84) while the MLX backend is
+//  replaced by libq3tts_hip.so. NOT compiled in this repository (no Swift toolchain in the build image);
+//  it is the binding a maintainer adds next to a `module.modulemap` exposing q3tts.h as `CQ3TTS`:
+//
+//      module CQ3TTS { header "q3tts.h"  link "q3tts_hip"  export * }
+//
+//  Differences a caller sees: audio comes back as [Float] (MLX is gone), a `seed:` argument exists, and
+//  `generateBatch` is new. Tokenisation stays in Swift via swift-transformers exactly as in the reference.
+//
+import CQ3TTS
+import Foundation
+import Tokenizers
+
+public enum AudioGenerationError: Error, LocalizedError {   // GenerationTypes.swift:63-84
+    case modelNotInitialized(String), generationFailed(String), invalidInput(String)
+    case audioDecodingFailed(String), audioEncodingFailed(String)
+    public var errorDescription: String? {
+        switch self {   // the engine already returns the reference's full message text
+        case .modelNotInitialized(let m), .generationFailed(let m), .invalidInput(let m),
+             .audioDecodingFailed(let m), .audioEncodingFailed(let m): return m
+        }
+    }
+    static func from(_ st: q3tts_status, _ msg: String) -> AudioGenerationError {
+        switch st {
+        case Q3TTS_ERR_MODEL_NOT_INITIALIZED: return .modelNotInitialized(msg)
+        case Q3TTS_ERR_GENERATION_FAILED: return .generationFailed(msg)
+        case Q3TTS_ERR_INVALID_INPUT: return .invalidInput(msg)
+        case Q3TTS_ERR_AUDIO_DECODING_FAILED: return .audioDecodingFailed(msg)
+        case Q3TTS_ERR_AUDIO_ENCODING_FAILED: return .audioEncodingFailed(msg)
+        default: return .modelNotInitialized(msg)   // IO / device failures surface at load time
+        }
+    }
+}
+public typealias Qwen3TTSError = AudioGenerationError
+
+public struct AudioGenerationInfo: Sendable {   // GenerationTypes.swift:15-21
+    public let promptTokenCount: Int, generationTokenCount: Int
+    public let prefillTime: TimeInterval, generateTime: TimeInterval
+    public let tokensPerSecond: Double, peakMemoryUsage: Double
+}
+
+public enum AudioGeneration: Sendable {   // GenerationTypes.swift:51-58
+    case token(Int)
+    case info(AudioGenerationInfo)
+    case audio([Float])
+}
+public typealias Qwen3TTSGeneration = AudioGeneration
+
+public final class Qwen3TTSModel {
+    private var handle: OpaquePointer?
+    public var tokenizer: Tokenizer?
+    private let info: q3tts_model_info
+
+    private init(handle: OpaquePointer, info: q3tts_model_info) { self.handle = handle; self.info = info }
+    deinit { q3tts_model_free(handle) }
+
+    /// fromPretrained(_:) -- Qwen3.swift:1382
+    public static func fromPretrained(_ modelPath: String, device: Int32 = 0, maxBatch: Int32 = 1) async throws -> Qwen3TTSModel {
+        var opts = q3tts_load_opts()
+        q3tts_default_load_opts(&opts)
+        opts.device = device
+        opts.max_batch = maxBatch
+        var h: OpaquePointer?
+        let st = q3tts_model_load(modelPath, &opts, &h)
+        guard st == Q3TTS_OK, let h else { throw AudioGenerationError.from(st, String(cString: q3tts_last_error(nil))) }
+        var mi = q3tts_model_info()
+        q3tts_model_get_info(h, &mi)
+        let m = Qwen3TTSModel(handle: h, info: mi)
+        m.tokenizer = try await AutoTokenizer.from(modelFolder: URL(fileURLWithPath: modelPath))   // Qwen3.swift:1458
+        return m
+    }
+
+    public var sampleRate: Int { Int(info.sample_rate) }                                    // Qwen3.swift:1262
+    public var ttsModelType: String { withUnsafeBytes(of: info.tts_model_type) { String(cString: $0.bindMemory(to: CChar.self).baseAddress!) } }
+    public var supportsVoiceCloning: Bool { info.supports_voice_cloning != 0 }                // Qwen3.swift:1210
+    public var supportedSpeakers: [String] {                                                 // Qwen3.swift:965
+        (0..<q3tts_model_num_speakers(handle)).map { String(cString: q3tts_model_speaker_name(handle, $0)) }
+    }
+
+    /// generate(text:speaker:instruct:language:temperature:topK:topP:repetitionPenalty:maxTokens:) -- Qwen3.swift:1291-1301
+    public func generate(text: String, speaker: String? = nil, instruct: String? = nil, language: String = "auto",
+                         temperature: Float = 0.9, topK: Int = 50, topP: Float = 1.0, repetitionPenalty: Float = 1.05,
+                         maxTokens: Int = 2048, seed: UInt64 = 0) async throws -> [Float] {
+        try run(text: text, speaker: speaker, instruct: instruct, language: language, temperature: temperature, topK: topK,
+                topP: topP, repetitionPenalty: repetitionPenalty, maxTokens: maxTokens, seed: seed, onEvent: nil)
+    }
+
+    /// generateStream(...) -- Qwen3+Streaming.swift:8-18: .token per frame, then .info, then .audio
+    public func generateStream(text: String, speaker: String? = nil, instruct: String? = nil, language: String = "auto",
+                               temperature: Float = 0.9, topK: Int = 50, topP: Float = 1.0, repetitionPenalty: Float = 1.05,
+                               maxTokens: Int = 2048, seed: UInt64 = 0) -> AsyncThrowingStream<Qwen3TTSGeneration, Error> {
+        AsyncThrowingStream { continuation in
+            Thread.detachNewThread {   // same threading model as the reference (Qwen3+Streaming.swift:19-20)
+                do {
+                    _ = try self.run(text: text, speaker: speaker, instruct: instruct, language: language,
+                                     temperature: temperature, topK: topK, topP: topP, repetitionPenalty: repetitionPenalty,
+                                     maxTokens: maxTokens, seed: seed) { continuation.yield($0) }
+                    continuation.finish()
+                } catch { continuation.finish(throwing: error) }
+            }
+        }
+    }
+
+    private func run(text: String, speaker: String?, instruct: String?, language: String, temperature: Float, topK: Int,
+                     topP: Float, repetitionPenalty: Float, maxTokens: Int, seed: UInt64,
+                     onEvent: ((Qwen3TTSGeneration) -> Void)?) throws -> [Float] {
+        guard let tokenizer else { throw AudioGenerationError.modelNotInitialized("Model not initialized: Tokenizer not loaded") }
+        // the three tokenisations of the reference (Qwen3.swift:274-275, 364-365, 822)
+        let textIds = tokenizer.encode(text: "<|im_start|>assistant\n\(text)<|im_end|>\n<|im_start|>assistant\n").map(Int32.init)
+        let instructIds = (instruct?.isEmpty == false)
+            ? tokenizer.encode(text: "<|im_start|>user\n\(instruct!)<|im_end|>\n").map(Int32.init) : []
+        let targetCount = Int32(tokenizer.encode(text: text).count)
+        var sampling = q3tts_sampling(temperature: temperature, top_k: Int32(topK), top_p: topP,
+                                      repetition_penalty: repetitionPenalty, seed: seed, force_frames: 0)
+        var result = q3tts_result()
+        let box = Unmanaged.passRetained(EventBox(onEvent))
+        defer { box.release(); q3tts_result_free(&result, 1) }
+        let st: q3tts_status = textIds.withUnsafeBufferPointer { tp in
+            instructIds.withUnsafeBufferPointer { ip in
+                withOptionalCString(speaker) { sp in
+                    language.withCString { lp in
+                        var req = q3tts_request(text_ids: tp.baseAddress, n_text_ids: Int32(tp.count),
+                                                instruct_ids: ip.count > 0 ? ip.baseAddress : nil, n_instruct_ids: Int32(ip.count),
+                                                target_token_count: targetCount, speaker: sp, language: lp, max_tokens: Int32(maxTokens))
+                        return q3tts_generate(handle, &req, 1, &sampling, onEvent == nil ? nil : eventTrampoline, box.toOpaque(), &result)
+                    }
+                }
+            }
+        }
+        guard st == Q3TTS_OK else { throw AudioGenerationError.from(st, String(cString: q3tts_last_error(handle))) }
+        guard result.status == Q3TTS_OK else { throw AudioGenerationError.generationFailed("Generation failed: No tokens generated") }
+        return Array(UnsafeBufferPointer(start: result.pcm, count: Int(result.n_samples)))
+    }
+}
+
+private final class EventBox { let f: ((Qwen3TTSGeneration) -> Void)?; init(_ f: ((Qwen3TTSGeneration) -> Void)?) { self.f = f } }
+
+private let eventTrampoline: q3tts_event_cb = { user, evp in
+    guard let user, let ev = evp?.pointee else { return }
+    let box = Unmanaged<EventBox>.fromOpaque(user).takeUnretainedValue()
+    switch ev.kind {
+    case Q3TTS_EVENT_TOKEN: box.f?(.token(Int(ev.token)))
+    case Q3TTS_EVENT_INFO:
+        let i = ev.info.pointee
+        box.f?(.info(AudioGenerationInfo(promptTokenCount: Int(i.prompt_token_count), generationTokenCount: Int(i.generation_token_count),
+                                         prefillTime: i.prefill_time, generateTime: i.generate_time,
+                                         tokensPerSecond: i.tokens_per_second, peakMemoryUsage: i.peak_memory_usage)))
+    default: box.f?(.audio(Array(UnsafeBufferPointer(start: ev.pcm, count: Int(ev.n_samples)))))
+    }
+}
+
+private func withOptionalCString<R>(_ s: String?, _ body: (UnsafePointer<CChar>?) -> R) -> R {
+    if let s { return s.withCString { body($0) } }
+    return body(nil)
+}
