@@ -65,7 +65,7 @@ def build_requests(preset: str, lo: int, hi: int, n_text: int, n_instruct: int):
     for row in range(lo, hi):
         p = synth.synthetic_prompt(row, n_text=n_text, n_instruct=n_instruct)
         reqs.append(GenerationRequest(p["text_ids"], p["target_token_count"], p.get("instruct_ids"),
-                                      "aiden" if preset == "0.6b" else None, "english"))
+                                      "aiden" if preset.startswith("0.6b") else None, "english"))
     return reqs
 
 
@@ -89,7 +89,7 @@ def cpu_baseline(ckpt: str, preset: str, n_text: int, n_instruct: int, frames: i
     om = O.OracleModel(ckpt)
     p = synth.synthetic_prompt(0, n_text=n_text, n_instruct=n_instruct)
     req = O.Request(text_ids=p["text_ids"], target_token_count=p["target_token_count"],
-                    instruct_ids=p.get("instruct_ids"), speaker="aiden" if preset == "0.6b" else None,
+                    instruct_ids=p.get("instruct_ids"), speaker="aiden" if preset.startswith("0.6b") else None,
                     language="english")
     t0 = time.time()
     tr = om.generate_codes(req, O.Sampling(temperature=0.0, force_frames=frames))
@@ -106,7 +106,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--preset", default="1.7b", choices=["1.7b", "0.6b"])
+    ap.add_argument("--preset", default="1.7b", choices=["1.7b", "0.6b", "0.6b-q4"])
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=200)
     ap.add_argument("--n-text", type=int, default=32)
@@ -194,7 +194,7 @@ def main():
     out = {
         "metric": "codec_tokens_per_s", "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (int4-g64 weights)" if args.preset.endswith("q4") else "bf16", "data": "synthetic",
         "config": {"workload": f"Qwen3-TTS-{args.preset.upper()} bf16, batch {B}/GPU x {args.frames} frames, "
                                f"{args.n_text} text + {n_instruct} instruct tokens, T={temp} top-k 50, "
                                "prompt assembly + prefill + hipGraph AR decode + fp32 codec decode -> 24 kHz PCM",

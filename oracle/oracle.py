@@ -209,6 +209,23 @@ def sanitize_speech_tokenizer(weights: Dict[str, np.ndarray]) -> Dict[str, np.nd
     return out
 
 
+def dequantize_mlx_affine(w: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """QuantizedLinear / QuantizedEmbedding as installed by quantize(model:...) (Qwen3.swift:1412-1425), MLX affine
+    mode: w[n][k] = q*scale + bias, q = k-th 4-bit field (little-endian, 8 per uint32) of row n, one bf16
+    scale/bias per 64 inputs; the dequantised weight is an array of the model dtype (bf16). Dequantising once at
+    load is arithmetically identical to o_qlinear_bf16 (checked in tests/test_quantized.py)."""
+    out = dict(w)
+    for key in [k for k in w if k.endswith(".scales")]:
+        base = key[: -len(".scales")]
+        packed, sc, bi = w[base + ".weight"], bf16_to_f32(w[key]), bf16_to_f32(w[base + ".biases"])
+        n, k8 = packed.shape
+        q = ((packed[:, :, None] >> (4 * np.arange(8, dtype=np.uint32))[None, None, :]) & 15).reshape(n, k8 * 8)
+        prod = (q.astype(np.float32) * np.repeat(sc, 64, axis=1)).astype(np.float32)   # mul and add rounded separately
+        out[base + ".weight"] = f32_to_bf16((prod + np.repeat(bi, 64, axis=1)).astype(np.float32))
+        del out[key], out[base + ".biases"]
+    return out
+
+
 # ----------------------------------------------------------------------------------------------
 # model
 # ----------------------------------------------------------------------------------------------
@@ -292,9 +309,11 @@ class OracleModel:
         self.cfg = _with_defaults(raw, _MODEL_DEF)
         self.t = _with_defaults(raw.get("talker_config"), _TALKER_DEF)
         self.cp = _with_defaults(self.t.get("code_predictor_config"), _CP_DEF)
-        if raw.get("quantization"):
-            raise NotImplementedError("oracle: quantised checkpoints are restated at block level only")
         w = load_safetensors_dir(model_dir)
+        if raw.get("quantization"):
+            q = raw["quantization"]
+            assert q.get("bits", 4) == 4 and q.get("group_size", 64) == 64
+            w = dequantize_mlx_affine(w)
         w = {k: v for k, v in w.items() if "position_ids" not in k}  # sanitize, Qwen3.swift:1223-1226
         self.token_map = w.pop("talker.model.text_token_map", None)  # :1434-1444
         self.w = w

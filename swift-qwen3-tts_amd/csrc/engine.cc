@@ -135,6 +135,7 @@ void Engine::alloc_workspace() {
 GemmArgs Engine::gemm_args(const LinearW& L, const uint16_t* x, int M) const {
     GemmArgs a{};
     a.W = L.w;
+    a.Wsb = L.sb;
     a.x = x;
     a.xMB = Mp_ / 16;
     a.M = M;

@@ -13,7 +13,8 @@ constexpr int kHeadDim = 128;    // Qwen3-TTS talker / code predictor head_dim (
 
 // ---- skinny GEMM (gemm_decode.hip) -------------------------------------------------------------
 struct GemmArgs {
-    const uint16_t* W;  // tiled weights (repack.hip)
+    const uint16_t* W;  // tiled weights (repack.hip): bf16 tiles, or packed int4 tiles when Wsb != nullptr
+    const uint32_t* Wsb;  // int4 path: per (tile, chunk, lane) {bf16 scale, bf16 bias} of the lane's 64-wide group
     const uint16_t* x;  // fragment-major activations (common.h: act_tiled_offset), rows >= M ignored
     int xMB;            // row blocks of the x allocation
     int M, Mpad, N, K;  // N, K are the padded (tiled) sizes

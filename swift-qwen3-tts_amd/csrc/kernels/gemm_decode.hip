@@ -54,12 +54,31 @@ __device__ __forceinline__ uint4 norm8(const uint4& hx, const uint4& wx, float r
     return make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// MLX affine int4, group 64 (QuantizedLinear installed by quantize(model:...) at Qwen3.swift:1412-1425):
+// w = bf16(q * scale + bias). One dwordx4 per lane holds the 32 nibbles of its four A fragments of a chunk
+// (8 consecutive k per uint32, little-endian nibbles), so an int4 weight tile is 1 KiB instead of 4 KiB.
+__device__ __forceinline__ void dequant_chunk(const uint4& qw, uint32_t sb, uint4 (&out)[4]) {
+    const float sc = lo_bf(sb), bi = hi_bf(sb);
+    const uint32_t w[4] = {qw.x, qw.y, qw.z, qw.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float q0 = (float)((w[i] >> (8 * j)) & 15u), q1 = (float)((w[i] >> (8 * j + 4)) & 15u);
+            // mul and add rounded separately like the oracle (no fma contraction)
+            o[j] = pack_bf(__fadd_rn(__fmul_rn(q0, sc), bi), __fadd_rn(__fmul_rn(q1, sc), bi));
+        }
+        out[i] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // EPI: 0 = bf16 store (+bias, +optional silu), row-major or fragment-major
 //      2 = gate/up tile pair -> bf16(bf16(silu(g)) * u), fragment-major
 //      3 = hidden-state store, fragment-major, in place: h = bf16((resid ? h : 0) + bf16(acc + bias)),
 //          plus ss_out[tile][m] = sum over the tile's 16 features of h^2
 // NORM: RMSNorm prologue on x (x is then the raw residual stream h)
-template <int MB, int EPI, int NW, int CH, bool NORM>
+template <int MB, int EPI, int NW, int CH, bool NORM, bool QUANT>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
     constexpr int NT = (EPI == 2) ? 2 : 1;  // weight tiles per workgroup
     __shared__ float red[NW][NT][MB][4][64];
@@ -83,18 +102,28 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
 
     // 1. weight loads first: they have the longest latency and depend on nothing
     constexpr int CHR = CH > 0 ? CH : 1;
-    uint4 wf[CHR][NT][4];
+    constexpr int WL = QUANT ? 1 : 4;  // dwordx4 loads per (chunk, tile): packed int4 needs one
+    uint4 wf[CHR][NT][WL];
+    uint32_t wsb[CHR][NT];
+    auto load_w = [&](int c, int kc) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const size_t blk = (size_t)(tile * NT + t) * KC + kc;
+            if constexpr (QUANT) {
+                wf[c][t][0] = Wt[blk * 64 + lane];
+                wsb[c][t] = a.Wsb[blk * 64 + lane];
+            } else {
+                const uint4* wp = Wt + blk * 256 + lane;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wf[c][t][i] = wp[i * 64];
+            }
+        }
+    };
     if constexpr (CH > 0) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const int kl = wave + c * NW;
-            const int kc = kl < KC ? kl : 0;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const uint4* wp = Wt + ((size_t)(tile * NT + t) * KC + kc) * 256 + lane;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) wf[c][t][i] = wp[i * 64];
-            }
+            load_w(c, kl < KC ? kl : 0);
         }
     }
 
@@ -121,7 +150,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
     }
 
     // 3. x fragments (+ norm) and MFMAs
-    auto chunk = [&](int kc, const uint4 (&w)[NT][4]) {
+    auto chunk = [&](int kc, int c) {
+        uint4 w[NT][4];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if constexpr (QUANT) {
+                dequant_chunk(wf[c][t][0], wsb[c][t], w[t]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) w[t][i] = wf[c][t][i];
+            }
+        }
         uint4 nw[4];
         if constexpr (NORM) {
             const uint4* np = reinterpret_cast<const uint4*>(a.norm_w + kc * 128 + 32 * (lane >> 4));
@@ -148,17 +187,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const int kl = wave + c * NW;
-            if (kl < KC) chunk(kl, wf[c]);  // wave-uniform
+            if (kl < KC) chunk(kl, c);  // wave-uniform
         }
     } else {
         for (int kl = wave; kl < KC; kl += NW) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const uint4* wp = Wt + ((size_t)(tile * NT + t) * KC + kl) * 256 + lane;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) wf[0][t][i] = wp[i * 64];
-            }
-            chunk(kl, wf[0]);
+            load_w(0, kl);
+            chunk(kl, 0);
         }
     }
 
@@ -237,14 +271,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
     }
 }
 
-template <int MB, int EPI, bool NORM>
+template <int MB, int EPI, bool NORM, bool QUANT>
 void launch_mb(const GemmArgs& a, hipStream_t st) {
     const int KC = a.K / 128;
     const int nw = KC <= 4 ? 4 : 8;  // no idle waves on short K
     const int ch = (KC + nw - 1) / nw;
     dim3 grid(a.N / 16);
 #define Q3_GEMM(NWv, CHv) \
-    hipLaunchKernelGGL((gemm_skinny_kernel<MB, EPI, NWv, CHv, NORM>), grid, dim3(NWv * 64), 0, st, a)
+    hipLaunchKernelGGL((gemm_skinny_kernel<MB, EPI, NWv, CHv, NORM, QUANT>), grid, dim3(NWv * 64), 0, st, a)
     if (nw == 4) {
         Q3_GEMM(4, 1);
     } else {
@@ -259,16 +293,22 @@ void launch_mb(const GemmArgs& a, hipStream_t st) {
 #undef Q3_GEMM
 }
 
-template <int EPI, bool NORM>
-void launch_epi(const GemmArgs& a, hipStream_t st) {
+template <int EPI, bool NORM, bool QUANT>
+void launch_q(const GemmArgs& a, hipStream_t st) {
     const int MB = (a.Mpad + 15) / 16;
     switch (MB) {
-        case 1: launch_mb<1, EPI, NORM>(a, st); break;
-        case 2: launch_mb<2, EPI, NORM>(a, st); break;
-        case 3: launch_mb<3, EPI, NORM>(a, st); break;
-        case 4: launch_mb<4, EPI, NORM>(a, st); break;
+        case 1: launch_mb<1, EPI, NORM, QUANT>(a, st); break;
+        case 2: launch_mb<2, EPI, NORM, QUANT>(a, st); break;
+        case 3: launch_mb<3, EPI, NORM, QUANT>(a, st); break;
+        case 4: launch_mb<4, EPI, NORM, QUANT>(a, st); break;
         default: throw Error(3, "gemm_skinny: M > 64 is not supported");
     }
+}
+
+template <int EPI, bool NORM>
+void launch_epi(const GemmArgs& a, hipStream_t st) {
+    if (a.Wsb) launch_q<EPI, NORM, true>(a, st);
+    else launch_q<EPI, NORM, false>(a, st);
 }
 
 }  // namespace

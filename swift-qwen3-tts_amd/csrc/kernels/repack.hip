@@ -27,7 +27,36 @@ __global__ __launch_bounds__(256) void tile_weights_kernel(const uint16_t* src, 
     *reinterpret_cast<uint4*>(dst + tile * 2048 + (size_t)i * 512 + lane * 8) = v;
 }
 
+// MLX affine int4 (group 64): packed [N][K/8] uint32 + bf16 scales/biases [N][K/64] ->
+//   q tiles  [tile][kc][lane] uint4 : the 16 bytes of row (lane&15) at k = kc*128 + 32*(lane>>4) .. +31
+//   sb tiles [tile][kc][lane] uint32: {scale, bias} of that lane's group (k/64)
+__global__ __launch_bounds__(64) void tile_int4_kernel(const uint32_t* wq, const uint16_t* scales, const uint16_t* biases,
+                                                       int N, int K, uint4* dq, uint32_t* dsb, int KC, int tile_off,
+                                                       int tile_stride) {
+    const int kc = blockIdx.x, j = blockIdx.y, lane = threadIdx.x;
+    const int row = 16 * j + (lane & 15), h = lane >> 4;
+    const int k = kc * 128 + 32 * h;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    uint32_t sb = 0;
+    if (row < N && k < K) {
+        v = *reinterpret_cast<const uint4*>(wq + (size_t)row * (K / 8) + k / 8);
+        const int g = k / 64, gpr = K / 64;
+        sb = (uint32_t)scales[(size_t)row * gpr + g] | ((uint32_t)biases[(size_t)row * gpr + g] << 16);
+    }
+    const size_t blk = (size_t)(tile_off + tile_stride * j) * KC + kc;
+    dq[blk * 64 + lane] = v;
+    dsb[blk * 64 + lane] = sb;
+}
+
 }  // namespace
+
+void launch_tile_int4(const uint32_t* wq, const uint16_t* scales, const uint16_t* biases, int N, int K, void* dq,
+                      uint32_t* dsb, int KC, int tile_off, int tile_stride, hipStream_t st) {
+    Q3_CHECK(K % 64 == 0, 6, "int4 weights need an inner size that is a multiple of the group size 64");
+    dim3 grid(KC, (N + 15) / 16);
+    hipLaunchKernelGGL(tile_int4_kernel, grid, dim3(64), 0, st, wq, scales, biases, N, K, reinterpret_cast<uint4*>(dq), dsb, KC,
+                       tile_off, tile_stride);
+}
 
 void launch_tile_weights(const uint16_t* src, int N, int K, uint16_t* dst, int KC, int tile_off, int tile_stride,
                          hipStream_t st) {

@@ -178,9 +178,8 @@ struct Builder {
     bool fill = true;  // false: allocate only (weights arrive by broadcast)
     uint8_t* base = nullptr;
     size_t off = 0;
-    uint16_t* staging = nullptr;  // device staging for raw bf16 matrices before tiling
-    size_t staging_elems = 0;
-    size_t max_staging = 0;       // collected in the dry pass
+    uint8_t* staging = nullptr;   // device staging for raw matrices before tiling
+    size_t max_staging = 0;       // bytes, collected in the dry pass
 
     template <class T>
     T* alloc(size_t n) {
@@ -221,13 +220,42 @@ struct MainTensors {
     }
 };
 
+// A Linear's weight as stored in the checkpoint: bf16 [N][K], or MLX affine int4 (packed uint32 [N][K/8] plus
+// bf16 scales/biases [N][K/64]) when `<name>.scales` exists (Qwen3.swift:1402-1425).
+struct LinSrc {
+    const TensorView* w = nullptr;
+    const TensorView* scales = nullptr;
+    const TensorView* biases = nullptr;
+    int N = 0, K = 0;
+    bool quant() const { return scales != nullptr; }
+};
+LinSrc lin_src(const SafetensorsDir& st, const std::string& name, int N, int K) {
+    LinSrc s;
+    s.N = N;
+    s.K = K;
+    s.w = &st.at(name + ".weight");
+    if (st.has(name + ".scales")) {
+        s.scales = &st.at(name + ".scales");
+        s.biases = &st.at(name + ".biases");
+        Q3_CHECK(s.w->dtype == DType::U32 && s.w->shape == std::vector<int64_t>({N, K / 8}), 6,
+                 "quantised weight '" + name + "' must be uint32 [out][in/8] (4-bit)");
+        Q3_CHECK(s.scales->dtype == DType::BF16 && s.biases->dtype == DType::BF16 &&
+                     s.scales->shape == std::vector<int64_t>({N, K / 64}) && s.biases->shape == s.scales->shape,
+                 6, "quantised '" + name + "' needs bf16 scales/biases [out][in/64] (group size 64)");
+    } else {
+        Q3_CHECK(s.w->dtype == DType::BF16 && s.w->shape == std::vector<int64_t>({N, K}), 6,
+                 "tensor '" + name + ".weight' has an unexpected dtype or shape");
+    }
+    return s;
+}
+
 const uint16_t* put_bf16(Builder& b, const TensorView& tv) {
     return b.put<uint16_t>(reinterpret_cast<const uint16_t*>(tv.data), size_t(tv.numel()));
 }
 
 // rows of several [N_i][K] matrices -> one tiled weight (tile index = tile_off + tile_stride * j)
 struct RowSrc {
-    const TensorView* tv;
+    LinSrc src;
     int tile_off, tile_stride;
 };
 LinearW put_linear(Builder& b, const std::vector<RowSrc>& srcs, int N, int K, int total_tiles, const TensorView* bias) {
@@ -236,27 +264,73 @@ LinearW put_linear(Builder& b, const std::vector<RowSrc>& srcs, int N, int K, in
     L.K = K;
     L.Kp = int(align_up(size_t(K), 128));
     L.Np = total_tiles * 16;
-    const size_t elems = size_t(L.Np) * L.Kp;
-    uint16_t* dst = b.alloc<uint16_t>(elems);
-    for (auto& s : srcs) b.max_staging = std::max(b.max_staging, size_t(s.tv->numel()));
+    const bool quant = srcs[0].src.quant();
+    for (auto& s : srcs) Q3_CHECK(s.src.quant() == quant && s.src.K == K, 6, "fused linears must share dtype and inner size");
+    const int KC = L.Kp / 128;
+    const size_t wbytes = quant ? size_t(L.Np) * L.Kp / 2 : size_t(L.Np) * L.Kp * 2;
+    uint8_t* dst = b.alloc<uint8_t>(wbytes);
+    uint32_t* dsb = quant ? b.alloc<uint32_t>(size_t(total_tiles) * KC * 64) : nullptr;
+    for (auto& s : srcs) b.max_staging = std::max(b.max_staging, s.src.w->nbytes + (quant ? 2 * s.src.scales->nbytes : 0) + 1024);
     if (!b.dry && b.fill) {
-        Q3_HIP(hipMemsetAsync(dst, 0, elems * 2, nullptr));
+        Q3_HIP(hipMemsetAsync(dst, 0, wbytes, nullptr));
+        if (dsb) Q3_HIP(hipMemsetAsync(dsb, 0, size_t(total_tiles) * KC * 64 * 4, nullptr));
         for (auto& s : srcs) {
-            const int n = int(s.tv->shape[0]);
-            Q3_CHECK(int(s.tv->shape[1]) == K, 6, "linear weight with unexpected inner size");
-            Q3_HIP(hipMemcpyAsync(b.staging, s.tv->data, size_t(n) * K * 2, hipMemcpyHostToDevice, nullptr));
-            launch_tile_weights(b.staging, n, K, dst, L.Kp / 128, s.tile_off, s.tile_stride, nullptr);
+            const int n = s.src.N;
+            Q3_HIP(hipMemcpyAsync(b.staging, s.src.w->data, s.src.w->nbytes, hipMemcpyHostToDevice, nullptr));
+            if (quant) {
+                uint8_t* ds = b.staging + align_up(s.src.w->nbytes, 256);
+                uint8_t* db = ds + align_up(s.src.scales->nbytes, 256);
+                Q3_HIP(hipMemcpyAsync(ds, s.src.scales->data, s.src.scales->nbytes, hipMemcpyHostToDevice, nullptr));
+                Q3_HIP(hipMemcpyAsync(db, s.src.biases->data, s.src.biases->nbytes, hipMemcpyHostToDevice, nullptr));
+                launch_tile_int4(reinterpret_cast<const uint32_t*>(b.staging), reinterpret_cast<const uint16_t*>(ds),
+                                 reinterpret_cast<const uint16_t*>(db), n, K, dst, dsb, KC, s.tile_off, s.tile_stride, nullptr);
+            } else {
+                launch_tile_weights(reinterpret_cast<const uint16_t*>(b.staging), n, K, reinterpret_cast<uint16_t*>(dst), KC,
+                                    s.tile_off, s.tile_stride, nullptr);
+            }
             Q3_HIP(hipStreamSynchronize(nullptr));
         }
     }
-    L.w = dst;
+    L.w = reinterpret_cast<const uint16_t*>(dst);
+    L.sb = dsb;
     if (bias) {
         // bias padded to Np so the epilogue may read any row of a padded tile
-        std::vector<uint16_t> tmp((size_t)(L.Np), 0);
+        std::vector<uint16_t> tmp(size_t(L.Np), 0);
         std::memcpy(tmp.data(), bias->data, size_t(bias->numel()) * 2);
         L.bias = b.put<uint16_t>(tmp.data(), tmp.size());
     }
     return L;
+}
+
+// Embedding table, dequantised at load when the checkpoint holds a QuantizedEmbedding (`.scales` present:
+// Qwen3.swift:1402-1406, 1419-1422): row = bf16(q * scale + bias), exactly what a dequantising gather returns.
+const uint16_t* put_embedding(Builder& b, const SafetensorsDir& st, const std::string& name, int64_t* rows_out, int dim) {
+    const TensorView& w = st.at(name + ".weight");
+    if (!st.has(name + ".scales")) {
+        Q3_CHECK(w.dtype == DType::BF16 && w.shape.size() == 2 && w.shape[1] == dim, 6, "unexpected embedding '" + name + "'");
+        if (rows_out) *rows_out = w.shape[0];
+        return put_bf16(b, w);
+    }
+    const TensorView& sc = st.at(name + ".scales");
+    const TensorView& bi = st.at(name + ".biases");
+    const int64_t rows = w.shape[0];
+    Q3_CHECK(w.dtype == DType::U32 && w.shape[1] == dim / 8 && sc.shape == std::vector<int64_t>({rows, dim / 64}), 6,
+             "unexpected quantised embedding '" + name + "'");
+    if (rows_out) *rows_out = rows;
+    std::vector<uint16_t> deq;
+    if (!b.dry && b.fill) {
+        deq.resize(size_t(rows) * dim);
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(w.data);
+        const uint16_t* s = reinterpret_cast<const uint16_t*>(sc.data);
+        const uint16_t* z = reinterpret_cast<const uint16_t*>(bi.data);
+        for (int64_t r = 0; r < rows; ++r)
+            for (int k = 0; k < dim; ++k) {
+                const float qv = float((q[r * (dim / 8) + k / 8] >> (4 * (k & 7))) & 15u);
+                const float prod = qv * bf16_to_f32_host(s[r * (dim / 64) + k / 64]);
+                deq[size_t(r) * dim + k] = f32_to_bf16_host(prod + bf16_to_f32_host(z[r * (dim / 64) + k / 64]));
+            }
+    }
+    return b.put<uint16_t>(deq.empty() ? nullptr : deq.data(), size_t(rows) * dim);
 }
 
 void build_stack(Builder& b, const MainTensors& mt, const std::string& prefix, StackW& s, int hidden,
@@ -281,20 +355,17 @@ void build_stack(Builder& b, const MainTensors& mt, const std::string& prefix, S
         L.ln2 = put_bf16(b, mt.bf16(p + ".post_attention_layernorm.weight", {hidden}));
         L.qn = put_bf16(b, mt.bf16(p + ".self_attn.q_norm.weight", {head_dim}));
         L.kn = put_bf16(b, mt.bf16(p + ".self_attn.k_norm.weight", {head_dim}));
-        const TensorView& q = mt.bf16(p + ".self_attn.q_proj.weight", {qd, hidden});
-        const TensorView& k = mt.bf16(p + ".self_attn.k_proj.weight", {kd, hidden});
-        const TensorView& v = mt.bf16(p + ".self_attn.v_proj.weight", {kd, hidden});
-        L.qkv = put_linear(b, {{&q, 0, 1}, {&k, qd / 16, 1}, {&v, (qd + kd) / 16, 1}}, qd + 2 * kd, hidden,
-                           (qd + 2 * kd) / 16, nullptr);
-        const TensorView& o = mt.bf16(p + ".self_attn.o_proj.weight", {hidden, qd});
-        L.o = put_linear(b, {{&o, 0, 1}}, hidden, qd, hidden / 16, nullptr);
-        const TensorView& g = mt.bf16(p + ".mlp.gate_proj.weight", {I, hidden});
-        const TensorView& u = mt.bf16(p + ".mlp.up_proj.weight", {I, hidden});
+        const SafetensorsDir& st = mt.st;
+        L.qkv = put_linear(b, {{lin_src(st, p + ".self_attn.q_proj", qd, hidden), 0, 1},
+                               {lin_src(st, p + ".self_attn.k_proj", kd, hidden), qd / 16, 1},
+                               {lin_src(st, p + ".self_attn.v_proj", kd, hidden), (qd + kd) / 16, 1}},
+                           qd + 2 * kd, hidden, (qd + 2 * kd) / 16, nullptr);
+        L.o = put_linear(b, {{lin_src(st, p + ".self_attn.o_proj", hidden, qd), 0, 1}}, hidden, qd, hidden / 16, nullptr);
         const int it = L.inter_p / 16;  // gate/up tile pairs, padded so that act has inter_p columns
-        L.gateup = put_linear(b, {{&g, 0, 2}, {&u, 1, 2}}, I, hidden, 2 * it, nullptr);
+        L.gateup = put_linear(b, {{lin_src(st, p + ".mlp.gate_proj", I, hidden), 0, 2}, {lin_src(st, p + ".mlp.up_proj", I, hidden), 1, 2}},
+                              I, hidden, 2 * it, nullptr);
         L.gateup.Np = L.inter_p;  // logical output columns (pairs of tiles)
-        const TensorView& d = mt.bf16(p + ".mlp.down_proj.weight", {hidden, I});
-        L.down = put_linear(b, {{&d, 0, 1}}, hidden, I, hidden / 16, nullptr);
+        L.down = put_linear(b, {{lin_src(st, p + ".mlp.down_proj", hidden, I), 0, 1}}, hidden, I, hidden / 16, nullptr);
     }
     s.final_norm = put_bf16(b, mt.bf16(prefix + ".norm.weight", {hidden}));
     // RoPE tables (Talker.swift:42-44,103-117; CodePredictor.swift:38-39,44-56): fp32 angles,
@@ -521,7 +592,9 @@ void build_codec(Builder& b, const TMap& t, const CodecDecoderConfig& dc, CodecW
     c.out_b = b.put_f32(need(t, "decoder.decoder.outConv.conv.bias"));
 }
 
-int64_t linear_bytes(const LinearW& L) { return int64_t(L.N) * L.K * 2; }
+int64_t linear_bytes(const LinearW& L) {  // weight bytes streamed per use: bf16, or 4 bit + {scale,bias} per 64
+    return L.sb ? int64_t(L.N) * L.K / 2 + int64_t(L.N) * (L.K / 64) * 4 : int64_t(L.N) * L.K * 2;
+}
 
 void build_all(Builder& b, Model& m, const SafetensorsDir& main, const TMap* codec_t, const LoadOptions& opt) {
     const ModelConfig& cfg = m.cfg;
@@ -529,13 +602,9 @@ void build_all(Builder& b, Model& m, const SafetensorsDir& main, const TMap* cod
     MainTensors mt{main};
     Q3_CHECK(t.head_dim == kHeadDim && t.cp.head_dim == kHeadDim, 6, "head_dim must be 128");
     const int H = t.hidden_size, TH = t.text_hidden_size;
-    m.codec_emb = put_bf16(b, mt.bf16("talker.model.codec_embedding.weight", {t.vocab_size, H}));
-    {
-        const TensorView& te = main.at("talker.model.text_embedding.weight");
-        Q3_CHECK(te.dtype == DType::BF16 && te.shape.size() == 2 && te.shape[1] == TH, 6, "unexpected text_embedding");
-        m.text_emb_rows = te.shape[0];  // fewer rows than text_vocab_size when the vocabulary is pruned
-        m.text_emb = put_bf16(b, te);
-    }
+    m.codec_emb = put_embedding(b, main, "talker.model.codec_embedding", nullptr, H);
+    // fewer rows than text_vocab_size when the vocabulary is pruned (docs/paper.tex:160-178)
+    m.text_emb = put_embedding(b, main, "talker.model.text_embedding", &m.text_emb_rows, TH);
     if (main.has("talker.model.text_token_map")) {  // Qwen3.swift:1434-1444
         const TensorView& tm = main.at("talker.model.text_token_map");
         Q3_CHECK(tm.dtype == DType::I32, 6, "text_token_map must be int32");
@@ -545,31 +614,27 @@ void build_all(Builder& b, Model& m, const SafetensorsDir& main, const TMap* cod
     for (int l = 0; l < t.num_hidden_layers; ++l) inter.push_back(t.inter(l));
     build_stack(b, mt, "talker.model", m.talker, H, inter, t.num_attention_heads, t.num_key_value_heads, t.head_dim,
                 t.rms_norm_eps, t.rope_theta, opt.max_pos_talker);
-    const TensorView& f1 = mt.bf16("talker.text_projection.linear_fc1.weight", {TH, TH});
     const TensorView& f1b = mt.bf16("talker.text_projection.linear_fc1.bias", {TH});
-    const TensorView& f2 = mt.bf16("talker.text_projection.linear_fc2.weight", {H, TH});
     const TensorView& f2b = mt.bf16("talker.text_projection.linear_fc2.bias", {H});
-    m.fc1 = put_linear(b, {{&f1, 0, 1}}, TH, TH, TH / 16, &f1b);
-    m.fc2 = put_linear(b, {{&f2, 0, 1}}, H, TH, H / 16, &f2b);
-    const TensorView& ch = mt.bf16("talker.codec_head.weight", {t.vocab_size, H});
-    m.codec_head = put_linear(b, {{&ch, 0, 1}}, t.vocab_size, H, t.vocab_size / 16, nullptr);
+    m.fc1 = put_linear(b, {{lin_src(main, "talker.text_projection.linear_fc1", TH, TH), 0, 1}}, TH, TH, TH / 16, &f1b);
+    m.fc2 = put_linear(b, {{lin_src(main, "talker.text_projection.linear_fc2", H, TH), 0, 1}}, H, TH, H / 16, &f2b);
+    m.codec_head = put_linear(b, {{lin_src(main, "talker.codec_head", t.vocab_size, H), 0, 1}}, t.vocab_size, H, t.vocab_size / 16,
+                              nullptr);
     Q3_CHECK(t.has_code_predictor, 6, "code_predictor_config is required");
     const CodePredictorConfig& cp = t.cp;
     const int CH = cp.hidden_size;
     m.has_cp_proj = (CH != H);  // CodePredictor.swift:295-299
     if (m.has_cp_proj) {
-        const TensorView& pw = mt.bf16("talker.code_predictor.small_to_mtp_projection.weight", {CH, H});
         const TensorView& pb = mt.bf16("talker.code_predictor.small_to_mtp_projection.bias", {CH});
-        m.cp_proj = put_linear(b, {{&pw, 0, 1}}, CH, H, CH / 16, &pb);
+        m.cp_proj = put_linear(b, {{lin_src(main, "talker.code_predictor.small_to_mtp_projection", CH, H), 0, 1}}, CH, H, CH / 16, &pb);
     }
     const int ng = cp.num_code_groups - 1;
     m.cp_emb.resize(size_t(ng));
     m.lm_head.resize(size_t(ng));
     for (int i = 0; i < ng; ++i) {
-        m.cp_emb[size_t(i)] = put_bf16(b, mt.bf16("talker.code_predictor.model.codec_embedding." + std::to_string(i) + ".weight",
-                                                   {cp.vocab_size, H}));
-        const TensorView& lh = mt.bf16("talker.code_predictor.lm_head." + std::to_string(i) + ".weight", {cp.vocab_size, CH});
-        m.lm_head[size_t(i)] = put_linear(b, {{&lh, 0, 1}}, cp.vocab_size, CH, cp.vocab_size / 16, nullptr);
+        m.cp_emb[size_t(i)] = put_embedding(b, main, "talker.code_predictor.model.codec_embedding." + std::to_string(i), nullptr, H);
+        m.lm_head[size_t(i)] = put_linear(b, {{lin_src(main, "talker.code_predictor.lm_head." + std::to_string(i), cp.vocab_size, CH), 0, 1}},
+                                          cp.vocab_size, CH, cp.vocab_size / 16, nullptr);
     }
     m.cp_emb_dev = b.put_side<const uint16_t*>(m.cp_emb.data(), m.cp_emb.size());
     std::vector<int> cp_inter((size_t)(cp.num_hidden_layers), cp.intermediate_size);
@@ -581,8 +646,9 @@ void build_all(Builder& b, Model& m, const SafetensorsDir& main, const TMap* cod
     }
     // distinct weight bytes of one frame step
     int64_t wb = linear_bytes(m.codec_head);
-    for (auto& L : m.talker.layers) wb += linear_bytes(L.qkv) + linear_bytes(L.o) + 2 * int64_t(L.inter) * H * 2 + linear_bytes(L.down);
-    for (auto& L : m.cp.layers) wb += linear_bytes(L.qkv) + linear_bytes(L.o) + 2 * int64_t(L.inter) * CH * 2 + linear_bytes(L.down);
+    auto gu = [](const LinearW& g) { LinearW t = g; t.N = 2 * g.N; return linear_bytes(t); };
+    for (auto& L : m.talker.layers) wb += linear_bytes(L.qkv) + linear_bytes(L.o) + gu(L.gateup) + linear_bytes(L.down);
+    for (auto& L : m.cp.layers) wb += linear_bytes(L.qkv) + linear_bytes(L.o) + gu(L.gateup) + linear_bytes(L.down);
     for (auto& L : m.lm_head) wb += linear_bytes(L);
     if (m.has_cp_proj) wb += linear_bytes(m.cp_proj);
     m.step_weight_bytes = wb;
@@ -600,8 +666,8 @@ std::unique_ptr<Model> load_model(const std::string& dir, const LoadOptions& opt
         m->cfg.parse(j);
     }
     Q3_CHECK(m->cfg.has_talker, 1, "Talker config is required");  // fatalError at Qwen3.swift:48-50
-    Q3_CHECK(!m->cfg.has_quantization, 6,
-             "quantised (int4) checkpoints are not supported by this build yet (SURVEY.md row A14)");
+    if (m->cfg.has_quantization)  // MLX affine quantisation as shipped with the "lite" checkpoints (docs/paper.tex:232,239)
+        Q3_CHECK(m->cfg.quant_bits == 4 && m->cfg.quant_group_size == 64, 6, "only 4-bit, group-size-64 quantisation is supported");
     SafetensorsDir main;
     main.open_dir(dir);  // Qwen3.swift:1391-1399
     SafetensorsDir st;
@@ -631,8 +697,7 @@ std::unique_ptr<Model> load_model(const std::string& dir, const LoadOptions& opt
     real.base = m->arena;
     real.side = &m->side_allocs;
     if (real.fill) {
-        Q3_HIP(hipMalloc(reinterpret_cast<void**>(&real.staging), dry.max_staging * 2));
-        real.staging_elems = dry.max_staging;
+        Q3_HIP(hipMalloc(reinterpret_cast<void**>(&real.staging), dry.max_staging));
     }
     try {
         build_all(real, *m, main, have_codec ? &codec_t : nullptr, opt);

@@ -14,8 +14,9 @@
 
 namespace q3 {
 
-struct LinearW {          // bf16 Linear in the streaming tile layout (gemm_decode.hip)
+struct LinearW {          // Linear in the streaming tile layout (gemm_decode.hip): bf16 tiles or packed int4 tiles
     const uint16_t* w = nullptr;
+    const uint32_t* sb = nullptr;    // int4 path: {scale, bias} per (tile, chunk, lane); nullptr for bf16
     const uint16_t* bias = nullptr;  // [N] or nullptr
     int N = 0, K = 0;                // logical sizes
     int Np = 0, Kp = 0;              // padded to 16 / 128
@@ -135,5 +136,7 @@ std::unique_ptr<Model> load_model(const std::string& dir, const LoadOptions& opt
 // GPU repack helpers (repack.hip)
 void launch_tile_weights(const uint16_t* src, int N, int K, uint16_t* dst, int KC, int tile_off, int tile_stride,
                          hipStream_t st);
+void launch_tile_int4(const uint32_t* wq, const uint16_t* scales, const uint16_t* biases, int N, int K, void* dq,
+                      uint32_t* dsb, int KC, int tile_off, int tile_stride, hipStream_t st);
 
 }  // namespace q3

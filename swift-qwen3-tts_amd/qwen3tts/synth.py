@@ -103,6 +103,18 @@ def preset(name: str) -> dict:
                    tts_pad_token_id=1010, tts_bos_token_id=1011, tts_eos_token_id=1012,
                    sample_rate=24000)
         return {"config": cfg, "speech_tokenizer": {"decoder_config": _codec_cfg(True)}}
+    if name == "tiny-q":
+        # like BASELINE config 5 in miniature: MLX affine int4 (group 64) Linears + pruned text vocabulary with a
+        # token map (docs/paper.tex:160-178, 232-256); embeddings stay bf16 (no `.scales` keys)
+        p = preset("tiny-b")
+        p["config"]["quantization"] = {"group_size": 64, "bits": 4}
+        p["config"]["talker_config"]["pruned_text_rows"] = 600  # writer-only hint, ignored by the loaders
+        return p
+    if name == "0.6b-q4":  # BASELINE config 5: 0.6B, int4-g64 Linears, pruned text vocabulary (47,427 rows)
+        p = preset("0.6b")
+        p["config"]["quantization"] = {"group_size": 64, "bits": 4}
+        p["config"]["talker_config"]["pruned_text_rows"] = 47427
+        return p
     if name in ("0.6b", "1.7b"):
         H, I = (1024, 3072) if name == "0.6b" else (2048, 6144)
         cp = dict(vocab_size=2048, hidden_size=1024, intermediate_size=3072, num_hidden_layers=5,
@@ -181,8 +193,24 @@ def talker_tensors(cfg: dict, g: _Gen, std: float = 0.02) -> Dict[str, Tuple[str
     nh, nkv, hd = t["num_attention_heads"], t["num_key_value_heads"], t["head_dim"]
     out: Dict[str, Tuple[str, np.ndarray]] = {}
 
+    quant = cfg.get("quantization")
+
     def lin(name, n, k, bias=False):
-        out[name + ".weight"] = g.normal_bf16((n, k), std)
+        if quant:  # MLX affine 4-bit: packed uint32 [n][k/8], bf16 scales/biases [n][k/64], w = q*scale + bias
+            if g.big and n * k >= (1 << 16):  # every 32-bit pattern is a valid row of eight 4-bit fields
+                t = g.torch.randint(-(1 << 31), (1 << 31) - 1, (n, k // 8), dtype=g.torch.int64, device=g.dev, generator=g.tgen)
+                packed = t.to(g.torch.int32).cpu().numpy().view(np.uint32)
+            else:
+                q = g.rng.integers(0, 16, size=(n, k), dtype=np.uint32)
+                packed = np.zeros((n, k // 8), np.uint32)
+                for j in range(8):
+                    packed |= q[:, j::8] << np.uint32(4 * j)
+            sc = g.uniform((n, k // 64), 0.002, 0.006)
+            out[name + ".weight"] = ("U32", packed)
+            out[name + ".scales"] = ("BF16", f32_to_bf16_bits(sc))
+            out[name + ".biases"] = ("BF16", f32_to_bf16_bits(-7.5 * sc + g.normal((n, k // 64), 0.0005)))
+        else:
+            out[name + ".weight"] = g.normal_bf16((n, k), std)
         if bias:
             out[name + ".bias"] = g.normal_bf16((n,), std)
 
@@ -208,7 +236,12 @@ def talker_tensors(cfg: dict, g: _Gen, std: float = 0.02) -> Dict[str, Tuple[str
 
     inter = t.get("per_layer_intermediate_sizes") or [t["intermediate_size"]] * t["num_hidden_layers"]
     out["talker.model.codec_embedding.weight"] = g.normal_bf16((V, H), std)
-    out["talker.model.text_embedding.weight"] = g.normal_bf16((TV, TH), std)
+    pruned = t.get("pruned_text_rows")
+    if pruned:  # compact table + original-id -> compact-index map (Qwen3.swift:1434-1444, Talker.swift:627-633)
+        out["talker.model.text_embedding.weight"] = g.normal_bf16((pruned, TH), std)
+        out["talker.model.text_token_map"] = ("I32", g.rng.integers(0, pruned, size=(TV,)).astype(np.int32))
+    else:
+        out["talker.model.text_embedding.weight"] = g.normal_bf16((TV, TH), std)
     stack("talker.model", H, inter, nh, nkv, hd)
     lin("talker.text_projection.linear_fc1", TH, TH, bias=True)
     lin("talker.text_projection.linear_fc2", H, TH, bias=True)
@@ -320,7 +353,7 @@ def write_checkpoint(model_dir: str, name: str = "tiny-a", seed: int = 1234,
             for q in parts[:-1]:
                 d = d[q]
             d[parts[-1]] = v
-    big = name in ("0.6b", "1.7b")
+    big = name in ("0.6b", "1.7b", "0.6b-q4")
     g = _Gen(seed, big)
     os.makedirs(os.path.join(model_dir, "speech_tokenizer"), exist_ok=True)
     with open(os.path.join(model_dir, "config.json"), "w") as f:

@@ -1,0 +1,73 @@
+"""SURVEY.md row A14 (MLX affine int4, group 64) and A3 (pruned vocabulary + token map), BASELINE config 5 in miniature."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import bf16_to_f32, tiny_request
+
+
+@pytest.fixture(scope="module")
+def q_ckpt(tmp_path_factory):
+    from qwen3tts import synth
+    d = str(tmp_path_factory.mktemp("tiny_q"))
+    synth.write_checkpoint(d, "tiny-q", seed=1234)
+    return d
+
+
+def test_oracle_dequant_matches_qlinear_block(q_ckpt):
+    """Dequantise-at-load (oracle.dequantize_mlx_affine) == on-the-fly o_qlinear_bf16, bit for bit."""
+    from oracle import oracle as O
+    raw = O.load_safetensors_dir(q_ckpt)
+    name = "talker.model.layers.1.mlp.down_proj"
+    Wq, sc, bi = raw[name + ".weight"], raw[name + ".scales"], raw[name + ".biases"]
+    N, K = Wq.shape[0], Wq.shape[1] * 8
+    assert Wq.dtype == np.uint32 and sc.shape == (N, K // 64)
+    rng = np.random.default_rng(0)
+    x = O.f32_to_bf16(rng.standard_normal((3, K)))
+    y1 = np.empty((3, N), np.uint16)
+    O.lib().o_qlinear_bf16(O._p16(x), Wq.ctypes.data_as(C.POINTER(C.c_uint32)), O._p16(sc), O._p16(bi), None, 3, K, N, 64, O._p16(y1))
+    W = O.dequantize_mlx_affine(raw)[name + ".weight"]
+    y2 = np.empty((3, N), np.uint16)
+    O.lib().o_linear_bf16(O._p16(x), O._p16(W), None, 3, K, N, O._p16(y2))
+    assert np.array_equal(y1, y2)
+    # MLX layout: element k of a row sits in bits 4*(k%8).. of word k//8
+    k = 37
+    q = (Wq[5, k // 8] >> (4 * (k % 8))) & 15
+    assert bf16_to_f32(W[5:6, k:k + 1])[0, 0] == bf16_to_f32(O.f32_to_bf16(np.float32(q) * bf16_to_f32(sc[5:6, 0:1]) + bf16_to_f32(bi[5:6, 0:1])))[0, 0]
+
+
+def test_oracle_token_map(q_ckpt):
+    from oracle import oracle as O
+    om = O.OracleModel(q_ckpt)
+    assert om.token_map is not None and om.w["talker.model.text_embedding.weight"].shape[0] == 600
+    ids = [3, 999, 17]
+    assert np.array_equal(om.embed_text(ids), om.w["talker.model.text_embedding.weight"][om.token_map[ids]])  # Talker.swift:627-633
+
+
+@pytest.mark.gpu
+def test_quantized_model_matches_oracle(q_ckpt):
+    """int4 dequant-in-register MFMA GEMM + token-map gather through the whole AR loop, teacher-forced."""
+    from oracle import oracle as O
+    from qwen3tts import GenerationRequest, Qwen3TTSModel
+    om = O.OracleModel(q_ckpt)
+    m = Qwen3TTSModel.from_pretrained(q_ckpt, max_batch=3, max_frames=32, max_prompt=64)
+    r = tiny_request(n_text=9)
+    req = GenerationRequest(r["text_ids"], 9, None, "aiden", "english")
+    oreq = O.Request(text_ids=r["text_ids"], target_token_count=9, speaker="aiden", language="english")
+    ie, tr, pad = m.debug_prepare_inputs(req)
+    oie, otr, opad = om.prepare_generation_inputs(oreq)
+    assert ie.shape == oie.shape and (np.abs(bf16_to_f32(ie) - bf16_to_f32(oie)) <= 2 ** -6 * np.maximum(np.abs(bf16_to_f32(oie)), 2.0 ** -8)).all()
+    F = 5
+    ref = om.generate_codes(oreq, O.Sampling(temperature=0.0, force_frames=F), keep_logits=True)
+    tl, cl, sampled = m.debug_generate_forced([req], ref.codes[None], temperature=0.0)
+    for got, exp in ((tl[0], np.stack(ref.talker_logits)), (cl[0], np.stack(ref.cp_logits))):
+        a, b = bf16_to_f32(got), bf16_to_f32(exp)
+        assert (np.abs(a - b) <= 2 * 2.0 ** -7 * np.abs(b).max(axis=-1, keepdims=True)).all(), float(np.abs(a - b).max())
+    assert (sampled[0] == ref.codes).mean() > 0.9
+    res = m.generate_batch([req, req, req], temperature=0.0, force_frames=F)   # hipGraph path, batch 3
+    assert np.array_equal(res[0].codes, res[2].codes) and res[0].audio.size == F * 1920
+    assert m.info.weight_bytes < 0.4 * 2 * sum(v.size for k, v in O.dequantize_mlx_affine(O.load_safetensors_dir(q_ckpt)).items()
+                                               if k.endswith("proj.weight") or "lm_head" in k or "codec_head" in k)
+    m.close()
