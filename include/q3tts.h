@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define Q3TTS_ABI_VERSION 1
+#define Q3TTS_ABI_VERSION 2
 
 typedef struct q3tts_model q3tts_model;
 
@@ -79,6 +79,7 @@ typedef struct {
     int32_t samples_per_frame; /* decodeUpsampleRate, 1920 */
     int32_t max_batch;
     int64_t weight_bytes;      /* distinct bytes streamed per decode step (roofline accounting) */
+    int32_t speaker_embedding_dim; /* enc_dim of the speaker encoder, 0 when absent */
 } q3tts_model_info;
 q3tts_status q3tts_model_get_info(const q3tts_model* m, q3tts_model_info* out);
 
@@ -100,6 +101,17 @@ typedef struct {
     const char* speaker;  /* NULL = none */
     const char* language; /* NULL = "auto" */
     int32_t max_tokens;   /* 0 = 2048 (reference default) */
+    /* Voice clone -- generateVoiceClone(text:referenceAudio:referenceText:language:...) (Qwen3.swift:1009-1020).
+     * ref_audio != NULL selects it; speaker / instruct_ids are then ignored, as in the reference.
+     *   ref_audio     = reference waveform, 24 kHz mono float32 (host memory, read during the call)
+     *   ref_text_ids  = tokens of "<|im_start|>assistant\n{referenceText}<|im_end|>\n" (:448-449)
+     * The reference's default repetition penalty on this path is 1.5 (:1017): set it in q3tts_sampling.
+     * Result: pcm = audio of the target text only (reference part cut proportionally, :1195-1199),
+     * codes = generated frames only. */
+    const float* ref_audio;
+    int64_t n_ref_samples;
+    const int32_t* ref_text_ids;
+    int32_t n_ref_text_ids;
 } q3tts_request;
 
 /* Defaults as generate(): 0.9 / 50 / 1.0 / 1.05 (Qwen3.swift:1296-1299). */
@@ -160,6 +172,19 @@ void q3tts_result_free(q3tts_result* results, int32_t n);
 q3tts_status q3tts_codec_decode(q3tts_model* m, const int32_t* codes, const int32_t* n_frames,
                                 int32_t batch, int32_t max_frames, float* pcm, int64_t* audio_lengths);
 
+/* Qwen3TTSSpeechTokenizer.encode (Models/SpeechTokenizer.swift:841-846 -> SpeechTokenizerEncoder.swift:1031-1056):
+ * 24 kHz mono float32 waveform -> codes [16][*n_frames] int32 (code row major, as the reference returns
+ * [1, 16, time]); cap_frames = capacity of `codes` in frames (q3tts_codec_encoded_frames gives the exact count). */
+q3tts_status q3tts_codec_encode(q3tts_model* m, const float* audio, int64_t n_samples, int32_t* codes,
+                                int32_t cap_frames, int32_t* n_frames);
+int32_t q3tts_codec_encoded_frames(const q3tts_model* m, int64_t n_samples);
+
+/* Qwen3TTSModel.extractSpeakerEmbedding(_:sampleRate:) (Models/Qwen3.swift:222-249): log-mel (n_fft 1024, hop 256,
+ * 128 mels) -> ECAPA-TDNN (Models/SpeakerEncoder.swift:364-394). out [enc_dim] float32; sample_rate must be 24000
+ * (:223-225). */
+q3tts_status q3tts_speaker_embedding(q3tts_model* m, const float* audio, int64_t n_samples, int32_t sample_rate,
+                                     float* out, int32_t cap);
+
 /* Timing of the last q3tts_generate / q3tts_codec_decode on this handle, measured with HIP events
  * on the engine's own stream (bench.py's roofline object reads these). */
 typedef struct {
@@ -169,6 +194,7 @@ typedef struct {
     int32_t frame_steps;    /* frame-step launches in decode_ms */
     int32_t rows;
     int64_t kv_bytes_read;  /* algorithmic KV bytes read over all frame steps */
+    double frontend_ms;     /* voice clone: codec encoder + speaker encoder over all rows of the call */
 } q3tts_timing;
 q3tts_status q3tts_last_timing(const q3tts_model* m, q3tts_timing* out);
 
@@ -210,6 +236,13 @@ q3tts_status q3tts_debug_linear(q3tts_model* m, const uint16_t* x, const uint16_
  * "block0".."block3". Output is channels-last [T][C] float32; *T,*C receive the shape. */
 q3tts_status q3tts_debug_codec_stage(q3tts_model* m, const int32_t* codes, int32_t n_frames,
                                      const char* stage, float* out, int64_t cap_floats, int32_t* T, int32_t* C);
+
+/* Voice-clone front end with intermediate activations for one waveform. Codec encoder stages
+ * (SpeechTokenizerEncoder.swift:1031-1056): "init_conv","layer0".."layer3","seanet","transformer","downsample",
+ * "rvq_first_in","rvq_rest_in"; speaker encoder stages (SpeakerEncoder.swift:364-394): "mel","h0".."h3","mfa",
+ * "pooled". Output is channels-last [T][C] float32. */
+q3tts_status q3tts_debug_frontend_stage(q3tts_model* m, const float* audio, int64_t n_samples, const char* stage,
+                                        float* out, int64_t cap_floats, int32_t* T, int32_t* C);
 
 #ifdef __cplusplus
 }

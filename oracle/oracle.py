@@ -142,6 +142,19 @@ _DEC_DEF = dict(latent_dim=1024, codebook_dim=512, codebook_size=2048, decoder_d
                 upsampling_ratios=[2, 2], layer_scale_initial_scale=0.01)
 
 
+# Qwen3TTSTokenizerEncoderConfig (Config.swift:476-504), Qwen3TTSSpeakerEncoderConfig (Config.swift:80-91)
+_ENC_DEF = dict(frame_rate=12.5, audio_channels=1, codebook_dim=256, codebook_size=2048, compress=2,
+                dilation_growth_rate=2, head_dim=64, hidden_size=512, intermediate_size=2048, kernel_size=7,
+                last_kernel_size=3, layer_scale_initial_scale=0.01, max_position_embeddings=8000,
+                num_attention_heads=8, num_filters=64, num_hidden_layers=8, num_key_value_heads=8,
+                num_quantizers=32, num_residual_layers=1, residual_kernel_size=3, rope_theta=10000.0,
+                sampling_rate=24000, sliding_window=250, upsampling_ratios=[8, 6, 5, 4], use_causal_conv=True,
+                use_conv_shortcut=False)
+_SPK_DEF = dict(mel_dim=128, enc_dim=1024, enc_channels=[512, 512, 512, 512, 1536], enc_kernel_sizes=[5, 3, 3, 3, 1],
+                enc_dilations=[1, 2, 3, 4, 1], enc_attention_channels=128, enc_res2net_scale=8, enc_se_channels=128,
+                sample_rate=24000)
+
+
 def _with_defaults(d: Optional[dict], defaults: dict) -> dict:
     out = dict(defaults)
     out.update(d or {})
@@ -168,18 +181,79 @@ _DEC_IDX = {"decoder.decoder.0": "decoder.decoder.initConv", "decoder.decoder.1"
             "decoder.decoder.6": "decoder.decoder.outConv"}
 
 
+_ENC_SEANET = {"encoder.encoder.layers.0.": "encoder.encoder.init_conv1d.",  # Qwen3.swift:1517-1528
+               "encoder.encoder.layers.1.": "encoder.encoder.layers.0.residuals.0.",
+               "encoder.encoder.layers.3.": "encoder.encoder.layers.0.downsample.",
+               "encoder.encoder.layers.4.": "encoder.encoder.layers.1.residuals.0.",
+               "encoder.encoder.layers.6.": "encoder.encoder.layers.1.downsample.",
+               "encoder.encoder.layers.7.": "encoder.encoder.layers.2.residuals.0.",
+               "encoder.encoder.layers.9.": "encoder.encoder.layers.2.downsample.",
+               "encoder.encoder.layers.10.": "encoder.encoder.layers.3.residuals.0.",
+               "encoder.encoder.layers.12.": "encoder.encoder.layers.3.downsample.",
+               "encoder.encoder.layers.14.": "encoder.encoder.final_conv1d."}
+
+
+def _sanitize_encoder_key(key: str, value: np.ndarray):
+    """Encoder half of sanitizeSpeechTokenizerWeights (Qwen3.swift:1592-1700): returns (new_key, new_value)."""
+    nk, nv = key, value
+    for a, b in _ENC_SEANET.items():  # :1594-1599
+        if nk.startswith(a):
+            nk = b + nk[len(a):]
+            break
+    if ".residuals." in nk:  # :1603-1607
+        nk = nk.replace(".block.1.", ".block.0.").replace(".block.3.", ".block.1.")
+    is_seanet = nk.startswith("encoder.encoder.") and "encoder_transformer" not in nk and "quantizer" not in nk \
+        and (".conv.weight" in nk or ".conv.bias" in nk)  # :1612-1615
+    if is_seanet:
+        nk = nk.replace(".conv.weight", ".conv.conv.weight").replace(".conv.bias", ".conv.conv.bias")
+        if nk.endswith(".weight") and value.ndim == 3:  # forced transpose, :1622-1624
+            nv = value.transpose(0, 2, 1)
+    if "encoder.encoder_transformer.layers." in nk:  # :1629-1649
+        nk = nk.replace("encoder.encoder_transformer.layers.", "encoder.encoder_transformer.transformer.layers.")
+        for a, b in ((".input_layernorm.", ".norm1."), (".post_attention_layernorm.", ".norm2."),
+                     (".mlp.fc1.", ".gating.linear1."), (".mlp.fc2.", ".gating.linear2."),
+                     (".self_attn_layer_scale.", ".layer_scale_1."), (".mlp_layer_scale.", ".layer_scale_2.")):
+            nk = nk.replace(a, b)
+    if nk.startswith("encoder.downsample.conv.") and "encoder.downsample.conv.conv." not in nk:  # :1652-1659
+        is_w = nk.endswith(".weight")
+        nk = nk.replace("encoder.downsample.conv.", "encoder.downsample.conv.conv.conv.")
+        if is_w and value.ndim == 3:
+            nv = value.transpose(0, 2, 1)
+    if "encoder.quantizer." in nk:  # :1664-1676
+        nk = nk.replace(".semantic_residual_vector_quantizer.", ".rvq_first.") \
+               .replace(".acoustic_residual_vector_quantizer.", ".rvq_rest.")
+        nk = nk.replace(".rvq_first.layers.", ".rvq_first.vq.layers.").replace(".rvq_rest.layers.", ".rvq_rest.vq.layers.")
+    was_seanet_w = nk.startswith("encoder.encoder.") and "encoder_transformer" not in nk and "quantizer" not in nk \
+        and nk.endswith(".conv.conv.weight")  # :1682-1685
+    is_proj = ("input_proj.weight" in nk or "output_proj.weight" in nk) and "quantizer" in nk
+    if is_proj and value.ndim == 3:  # :1688-1692
+        nv = value.transpose(0, 2, 1)
+    if "conv.weight" in nk and value.ndim == 3 and not is_proj and not was_seanet_w:  # :1696-1700
+        if not _is_mlx_conv_layout(value.shape):
+            nv = value.transpose(0, 2, 1)
+    return nk, np.ascontiguousarray(nv)
+
+
 def sanitize_speech_tokenizer(weights: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
-    """Decoder half of sanitizeSpeechTokenizerWeights (Qwen3.swift:1498-1750). Encoder keys are
-    passed through untouched (voice-clone path, not restated yet)."""
+    """sanitizeSpeechTokenizerWeights (Qwen3.swift:1498-1750), decoder and encoder halves."""
     out: Dict[str, np.ndarray] = {}
     cb: Dict[str, Dict[str, np.ndarray]] = {}
+    ecb: Dict[str, Dict[str, np.ndarray]] = {}
     for key, value in weights.items():
         if "._codebook.cluster_usage" in key or "._codebook.embedding_sum" in key:  # :1532-1543
             base = key.split("._codebook.")[0]
             cb.setdefault(base, {})["cluster_usage" if "cluster_usage" in key else "embedding_sum"] = value
             continue
+        if key.startswith("encoder.quantizer.") and ".codebook." in key:  # :1546-1565
+            parts = key.split(".codebook.")
+            if len(parts) == 2 and parts[1] in ("embed_sum", "cluster_usage"):
+                ecb.setdefault(parts[0], {})[parts[1]] = value
+                continue
+            if ".initialized" in key:
+                continue
         if key.startswith("encoder."):
-            out[key] = value
+            nk, nv = _sanitize_encoder_key(key, value)
+            out[nk] = nv
             continue
         nk = key
         for a, b in _DEC_IDX.items():  # :1573-1578
@@ -206,6 +280,26 @@ def sanitize_speech_tokenizer(weights: Dict[str, np.ndarray]) -> Dict[str, np.nd
         if "cluster_usage" in d and "embedding_sum" in d:
             usage = np.clip(d["cluster_usage"].astype(np.float32)[:, None], np.float32(1e-5), None)
             out[base + ".codebook.embed.weight"] = (d["embedding_sum"].astype(np.float32) / usage).astype(np.float32)
+    for base, d in ecb.items():  # :1727-1747; EncoderEuclideanCodebook.updateInPlace (SpeechTokenizerEncoder.swift:738-743)
+        if "cluster_usage" in d and "embed_sum" in d:
+            nb = base.replace(".semantic_residual_vector_quantizer.", ".rvq_first.") \
+                     .replace(".acoustic_residual_vector_quantizer.", ".rvq_rest.")
+            nb = nb.replace(".rvq_first.layers.", ".rvq_first.vq.layers.", 1).replace(".rvq_rest.layers.", ".rvq_rest.vq.layers.", 1)
+            out[nb + ".codebook.embeddingSum"] = d["embed_sum"].astype(np.float32)
+            out[nb + ".codebook.clusterUsage"] = d["cluster_usage"].astype(np.float32)
+    return out
+
+
+def sanitize_main(weights: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """Qwen3TTSModel.sanitize (Qwen3.swift:1219-1243): drop position_ids, conv weights to MLX layout
+    (only the speaker encoder has 3-d conv weights in the main checkpoint)."""
+    out = {}
+    for k, v in weights.items():
+        if "position_ids" in k:
+            continue
+        if ("conv" in k or "speaker_encoder.fc" in k) and "weight" in k and v.ndim == 3 and not _is_mlx_conv_layout(v.shape):
+            v = np.ascontiguousarray(v.transpose(0, 2, 1))
+        out[k] = v
     return out
 
 
@@ -247,6 +341,8 @@ class Request:
     instruct_ids: Optional[List[int]] = None
     speaker: Optional[str] = None
     language: str = "auto"
+    ref_audio: Optional[np.ndarray] = None      # voice clone: 24 kHz mono float32 (Qwen3.swift:1009-1013)
+    ref_text_ids: Optional[List[int]] = None    # tokens of "<|im_start|>assistant\n{refText}<|im_end|>\n" (:448-449)
     max_tokens: int = 2048
 
 
@@ -256,6 +352,7 @@ class GenTrace:
     talker_logits: List[np.ndarray] = field(default_factory=list)  # per frame, bf16 bits [V]
     cp_logits: List[np.ndarray] = field(default_factory=list)      # per frame [15][Vcp]
     hit_eos: bool = False
+    ref_codes: Optional[np.ndarray] = None  # voice clone: [16][T_ref]
 
 
 class _StackHolder:
@@ -314,7 +411,7 @@ class OracleModel:
             q = raw["quantization"]
             assert q.get("bits", 4) == 4 and q.get("group_size", 64) == 64
             w = dequantize_mlx_affine(w)
-        w = {k: v for k, v in w.items() if "position_ids" not in k}  # sanitize, Qwen3.swift:1223-1226
+        w = sanitize_main(w)  # Qwen3.swift:1219-1243
         self.token_map = w.pop("talker.model.text_token_map", None)  # :1434-1444
         self.w = w
         t, cp = self.t, self.cp
@@ -330,11 +427,14 @@ class OracleModel:
         self.has_proj = "talker.code_predictor.small_to_mtp_projection.weight" in w
         st_dir = os.path.join(model_dir, "speech_tokenizer")
         self.codec = None
+        self.ec = None
         if os.path.isdir(st_dir):  # postLoadHook, Qwen3.swift:1462-1494
             with open(os.path.join(st_dir, "config.json")) as f:
                 sraw = json.load(f)
             self.dc = _with_defaults(sraw.get("decoder_config"), _DEC_DEF)
+            self.ec = _with_defaults(sraw["encoder_config"], _ENC_DEF) if sraw.get("encoder_config") else None
             self.codec = sanitize_speech_tokenizer(load_safetensors_dir(st_dir))
+        self.sc = _with_defaults(raw["speaker_encoder_config"], _SPK_DEF) if raw.get("speaker_encoder_config") else None
         _ = L
 
     # -- small helpers ---------------------------------------------------------------------
@@ -469,7 +569,11 @@ class OracleModel:
         still produced by the oracle, the fed-back tokens come from the array.
         RNG draw index: frame*16 + codebook."""
         t, cp = self.t, self.cp
-        inp, trailing, tts_pad = self.prepare_generation_inputs(req)
+        ref_codes = None
+        if req.ref_audio is not None:
+            inp, trailing, tts_pad, ref_codes = self.prepare_icl_generation_inputs(req)
+        else:
+            inp, trailing, tts_pad = self.prepare_generation_inputs(req)
         max_tok = self.effective_max_tokens(req, s)
         if forced_codes is not None:
             max_tok = forced_codes.shape[0]
@@ -479,6 +583,7 @@ class OracleModel:
         seen = np.zeros(V, np.uint8)
         codes: List[List[int]] = []
         tr = GenTrace(codes=np.zeros((0, 16), np.int32))
+        tr.ref_codes = ref_codes
         cur = inp
         trailing_idx = 0
         ncg = t["num_code_groups"]
@@ -668,3 +773,325 @@ class OracleModel:
         if 0 < valid < pcm.shape[0]:
             pcm = pcm[:valid]
         return pcm, tr
+
+    # -- voice clone front end: codec encoder (V1) ---------------------------------------------
+    @property
+    def has_encoder(self) -> bool:  # Qwen3TTSSpeechTokenizer.hasEncoder (SpeechTokenizer.swift:816-818)
+        return self.codec is not None and self.ec is not None
+
+    @property
+    def supports_voice_cloning(self) -> bool:  # Qwen3.swift:1210-1214
+        return self.cfg["tts_model_type"] == "base" and self.has_encoder
+
+    @staticmethod
+    def _conv_f32(x, W, b, stride, dil, pl, pr, mode):
+        x = np.ascontiguousarray(x, np.float32)
+        T, Cin = x.shape
+        Cout, K, ci = W.shape
+        assert ci == Cin, (W.shape, x.shape)
+        args = [_pf(x), _pf(W), _pf(b), C.c_int(T), C.c_int(Cin), C.c_int(Cout), C.c_int(K), C.c_int(stride),
+                C.c_int(dil), C.c_int(pl), C.c_int(pr), C.c_int(mode)]
+        Tout = lib().o_conv1d_f32(*args, None)
+        out = np.empty((max(Tout, 0), Cout), np.float32)
+        if Tout > 0:
+            lib().o_conv1d_f32(*args, _pf(out))
+        return out
+
+    def _sconv(self, x, prefix, K, stride=1, dil=1):
+        """StreamableConv1d, causal (SpeechTokenizerEncoder.swift:163-186) over NormConv1d/EncoderConv1d
+        (:218-282). Padding is always zeros: `padMode` is stored but never read (:184)."""
+        W, b = self.codec[prefix + ".conv.conv.weight"], self.codec.get(prefix + ".conv.conv.bias")
+        assert W.shape[1] == K, (prefix, W.shape, K)
+        T = x.shape[0]
+        eff = (K - 1) * dil + 1
+        ptotal = eff - stride
+        nframes = np.float32(max(T + ptotal - eff, 0)) / np.float32(stride) + np.float32(1.0)  # :115, Float
+        ideal = (int(np.ceil(nframes)) - 1) * stride + eff - ptotal
+        extra = max(0, ideal - T)
+        return self._conv_f32(x, W, b, stride, dil, ptotal, extra, 0)
+
+    @staticmethod
+    def _elu(x):  # :1075-1077, alpha 1
+        x = x.astype(np.float32)
+        return np.where(x > 0, x, (np.exp(np.minimum(x, 0)).astype(np.float32) - np.float32(1.0))).astype(np.float32)
+
+    def _lin_w(self, x, W):
+        M, K = x.shape
+        out = np.empty((M, W.shape[0]), np.float32)
+        lib().o_linear_f32(_pf(np.ascontiguousarray(x, np.float32)), _pf(np.ascontiguousarray(W, np.float32)), None,
+                           C.c_int(M), C.c_int(K), C.c_int(W.shape[0]), _pf(out))
+        return out
+
+    @staticmethod
+    def rope_tables_f32(T: int, dim: int, base: float):
+        """MLXNN.RoPE(dimensions: dim, traditional: false, base) at offset 0 (SpeechTokenizerEncoder.swift:494,
+        505-508): angle(pos, i) = pos * base^(-i/(dim/2)), halves layout. Tables are evaluated in double and
+        rounded to fp32 (the engine builds the same tables on the host)."""
+        half = dim // 2
+        inv = np.power(float(base), -np.arange(half, dtype=np.float64) / half)
+        ang = np.arange(T, dtype=np.float64)[:, None] * inv[None, :]
+        return np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32)
+
+    def encoder_codebook(self, name: str, j: int):
+        """EncoderEuclideanCodebook.updateInPlace (:738-743): embedding = embed_sum / max(usage, 1e-5),
+        c2 = sum(e^2)/2 (squares in fp32, the sum accumulated in double and rounded once: the centre of every
+        fp32 summation order MLX could pick)."""
+        p = f"encoder.quantizer.{name}.vq.layers.{j}.codebook"
+        usage = np.maximum(self.codec[p + ".clusterUsage"], np.float32(1e-5))[:, None]
+        emb = (self.codec[p + ".embeddingSum"] / usage).astype(np.float32)
+        c2 = ((emb * emb).astype(np.float32).astype(np.float64).sum(-1).astype(np.float32) / np.float32(2)).astype(np.float32)
+        return emb, c2
+
+    def codec_encode(self, audio: np.ndarray, stages: Optional[dict] = None, all_layers: bool = False):
+        """Qwen3TTSSpeechTokenizerEncoder.encode (SpeechTokenizerEncoder.swift:1031-1056) for one waveform
+        [S] -> codes [16][T] int32. `stages` receives channels-last activations and, per RVQ layer, the gap
+        between the two smallest distances (tests use it to recognise near-ties)."""
+        ec, cw = self.ec, self.codec
+        assert ec["num_residual_layers"] == 1 and not ec["use_conv_shortcut"] and ec["use_causal_conv"]
+        x = np.ascontiguousarray(np.asarray(audio, np.float32).reshape(-1, 1))
+        x = self._sconv(x, "encoder.encoder.init_conv1d", ec["kernel_size"])  # SeanetEncoder :436-443
+        if stages is not None:
+            stages["init_conv"] = x
+        for i, ratio in enumerate(reversed(ec["upsampling_ratios"])):  # :417
+            p = f"encoder.encoder.layers.{i}"
+            y = self._sconv(self._elu(x), p + ".residuals.0.block.0", ec["residual_kernel_size"])  # :333-347
+            y = self._sconv(self._elu(y), p + ".residuals.0.block.1", 1)
+            x = (y + x).astype(np.float32)
+            x = self._sconv(self._elu(x), p + ".downsample", 2 * ratio, stride=ratio)  # :384-390
+            if stages is not None:
+                stages[f"layer{i}"] = x
+        x = self._sconv(self._elu(x), "encoder.encoder.final_conv1d", ec["last_kernel_size"])
+        if stages is not None:
+            stages["seanet"] = x
+        # EncoderProjectedTransformer (:650-674): no input/output projection (dims equal), causal mask (:1039-1043)
+        T = x.shape[0]
+        nh, hd = ec["num_attention_heads"], ec["hidden_size"] // ec["num_attention_heads"]
+        assert ec["num_key_value_heads"] == nh
+        cos, sin = self.rope_tables_f32(T, hd, ec["rope_theta"])
+        half = hd // 2
+
+        def rope(a):  # [T][nh*hd]
+            a = a.reshape(T, nh, hd)
+            x1, x2 = a[:, :, :half], a[:, :, half:]
+            c, s_ = cos[:, None, :], sin[:, None, :]
+            o1 = ((x1 * c).astype(np.float32) - (x2 * s_).astype(np.float32)).astype(np.float32)
+            o2 = ((x1 * s_).astype(np.float32) + (x2 * c).astype(np.float32)).astype(np.float32)
+            return np.ascontiguousarray(np.concatenate([o1, o2], -1).reshape(T, nh * hd))
+
+        def ln(a, pfx):  # LayerNorm eps 1e-5 (:559-560)
+            out = np.empty_like(a)
+            lib().o_layernorm_f32(_pf(np.ascontiguousarray(a)), _pf(cw[pfx + ".weight"]), _pf(cw[pfx + ".bias"]),
+                                  C.c_float(1e-5), C.c_int(a.shape[0]), C.c_int(a.shape[1]), _pf(out))
+            return out
+
+        for l in range(ec["num_hidden_layers"]):  # EncoderTransformerLayer :571-590
+            p = f"encoder.encoder_transformer.transformer.layers.{l}"
+            n1 = ln(x, p + ".norm1")
+            q = rope(self._lin_w(n1, cw[p + ".self_attn.q_proj.weight"]))
+            k = rope(self._lin_w(n1, cw[p + ".self_attn.k_proj.weight"]))
+            v = self._lin_w(n1, cw[p + ".self_attn.v_proj.weight"])
+            ao = np.empty_like(q)
+            lib().o_attention_causal_f32(_pf(q), _pf(k), _pf(v), C.c_int(T), C.c_int(nh), C.c_int(hd), _pf(ao))
+            y = self._lin_w(ao, cw[p + ".self_attn.o_proj.weight"])
+            x = (x + (y * cw[p + ".layer_scale_1.scale"]).astype(np.float32)).astype(np.float32)
+            n2 = ln(x, p + ".norm2")
+            h1 = self._lin_w(n2, cw[p + ".gating.linear1.weight"])
+            # geluApprox (:1080-1082): x*0.5*(1+tanh(0.7978845608*(x+0.044715*x^3)))
+            f = np.float32
+            inner = (f(0.7978845608) * (h1 + (f(0.044715) * (h1 * h1 * h1).astype(f)).astype(f)).astype(f)).astype(f)
+            g = ((h1 * f(0.5)).astype(f) * (f(1.0) + np.tanh(inner).astype(f)).astype(f)).astype(f)
+            y = self._lin_w(g, cw[p + ".gating.linear2.weight"])
+            x = (x + (y * cw[p + ".layer_scale_2.scale"]).astype(np.float32)).astype(np.float32)
+        if stages is not None:
+            stages["transformer"] = x
+        enc_rate = np.float32(ec["sampling_rate"]) / np.float32(int(np.prod(ec["upsampling_ratios"])))  # :1008-1009
+        ds = int(enc_rate / np.float32(ec["frame_rate"]))
+        x = self._sconv(x, "encoder.downsample.conv", 2 * ds, stride=ds)  # EncoderConvDownsample1d, no bias
+        if stages is not None:
+            stages["downsample"] = x
+        Tq = x.shape[0]
+        codes = []
+        gaps = []
+        for name, nq in (("rvq_first", 1), ("rvq_rest", ec["num_quantizers"] - 1)):  # :934-941
+            W = cw[f"encoder.quantizer.{name}.input_proj.weight"]  # [dim][1][in]
+            r = self._lin_w(x, W[:, 0, :])  # EncoderConv1dProj :897-902
+            if stages is not None:
+                stages[f"{name}_in"] = r
+            n_used = nq if all_layers else min(nq, 16 - len(codes))  # later layers never reach the output (:1055)
+            for j in range(n_used):  # EncoderResidualVectorQuantization.encode :816-829
+                emb, c2 = self.encoder_codebook(name, j)
+                dist = (c2[None, :] - self._lin_w(r, emb)).astype(np.float32)  # :755-756
+                idx = np.argmin(dist, axis=-1)
+                part = np.partition(dist, 1, axis=-1)
+                gaps.append((part[:, 1] - part[:, 0]).astype(np.float32))
+                r = (r - emb[idx]).astype(np.float32)  # :823
+                codes.append(idx.astype(np.int32))
+        if stages is not None:
+            stages["gaps"] = np.stack(gaps[:16])
+        return np.stack(codes[:16]).reshape(16, Tq)  # :1055
+
+    # -- voice clone front end: speaker encoder (V2) ---------------------------------------------
+    @staticmethod
+    def mel_spectrogram(audio: np.ndarray, n_fft=1024, num_mels=128, sample_rate=24000, hop=256, win=1024,
+                        fmin=0.0, fmax=12000.0) -> np.ndarray:
+        """melSpectrogram (SpeakerEncoder.swift:410-456) -> [T][mels] float32. The DFT is evaluated in double and
+        rounded to complex64 (the reference runs a single-precision FFT; both are the exact DFT to fp32 rounding)."""
+        f = np.float32
+        x = np.asarray(audio, f).reshape(-1)
+        n = np.arange(win, dtype=f)
+        window = (f(0.5) * (f(1.0) - np.cos((f(2.0) * f(np.pi)) * n / f(win - 1)).astype(f))).astype(f)  # :459-462
+        padded = np.concatenate([np.zeros(n_fft // 2, f), x, np.zeros(n_fft // 2, f)])  # :430-431
+        nfr = (padded.shape[0] - n_fft) // hop + 1  # :469
+        frames = np.stack([padded[i * hop: i * hop + n_fft] * window for i in range(nfr)]).astype(f)  # :473-477
+        spec = np.fft.rfft(frames.astype(np.float64), axis=-1).astype(np.complex64)  # :484-486, 513 bins
+        mag = np.abs(spec).astype(f)
+        power = (mag * mag).astype(f)  # :437
+        nfreq = n_fft // 2 + 1
+        fb = np.empty((nfreq, num_mels), f)
+        lib().o_mel_filterbank(C.c_int(n_fft), C.c_int(num_mels), C.c_int(sample_rate), C.c_float(fmin), C.c_float(fmax),
+                               _pf(fb))
+        mel = np.empty((nfr, num_mels), f)
+        lib().o_linear_f32(_pf(np.ascontiguousarray(power)), _pf(np.ascontiguousarray(fb.T)), None, C.c_int(nfr),
+                           C.c_int(nfreq), C.c_int(num_mels), _pf(mel))  # :449
+        return np.log(np.maximum(mel, f(1e-10))).astype(f)  # :452
+
+    def _tdnn(self, x, prefix, K, dil):
+        """TimeDelayNetBlock (SpeakerEncoder.swift:45-70): reflect pad, conv, ReLU. x [T][C]."""
+        W, b = self.w_f32(prefix + ".conv.weight"), self.w_f32(prefix + ".conv.bias")
+        pad = (K - 1) * dil // 2
+        assert W.shape[1] == K and pad < x.shape[0]
+        return np.maximum(self._conv_f32(x, W, b, 1, dil, pad, pad, 1), np.float32(0))
+
+    def w_f32(self, name: str) -> np.ndarray:
+        """Speaker-encoder parameters are stored in the checkpoint dtype (bf16) and meet fp32 activations:
+        MLX promotes to fp32, i.e. an exact upcast of the stored values."""
+        a = self.w[name]
+        return np.ascontiguousarray(bf16_to_f32(a) if a.dtype == np.uint16 else a.astype(np.float32))
+
+    def speaker_embedding(self, audio: np.ndarray, stages: Optional[dict] = None) -> np.ndarray:
+        """extractSpeakerEmbedding (Qwen3.swift:222-249) -> Qwen3TTSSpeakerEncoder (SpeakerEncoder.swift:364-394).
+        Returns fp32 [enc_dim]."""
+        sc = self.sc
+        f = np.float32
+        mel = self.mel_spectrogram(audio, 1024, 128, 24000, 256, 1024, 0.0, 12000.0)
+        if stages is not None:
+            stages["mel"] = mel
+        ch, ks, dl = sc["enc_channels"], sc["enc_kernel_sizes"], sc["enc_dilations"]
+        scale = sc["enc_res2net_scale"]
+        h = self._tdnn(mel, "speaker_encoder.blocks.0", ks[0], dl[0])
+        if stages is not None:
+            stages["h0"] = h
+        hs = []
+        for bi in (1, 2, 3):  # SqueezeExcitationRes2NetBlock :204-211
+            p = f"speaker_encoder.blocks.{bi}"
+            res = h
+            o = self._tdnn(h, p + ".tdnn1", 1, 1)
+            cs = o.shape[1] // scale
+            parts, prev = [], None
+            for i in range(scale):  # Res2NetBlock :96-116
+                chunk = o[:, i * cs:(i + 1) * cs]
+                if i == 0:
+                    prev = chunk
+                elif i == 1:
+                    prev = self._tdnn(chunk, f"{p}.res2net_block.blocks.{i - 1}", ks[bi], dl[bi])
+                else:
+                    prev = self._tdnn((chunk + prev).astype(f), f"{p}.res2net_block.blocks.{i - 1}", ks[bi], dl[bi])
+                parts.append(prev)
+            o = np.ascontiguousarray(np.concatenate(parts, 1))
+            o = self._tdnn(o, p + ".tdnn2", 1, 1)
+            # SqueezeExcitationBlock :143-155
+            m = (o.astype(np.float64).mean(0)).astype(f)[None, :]
+            s1 = np.maximum(self._lin_w(m, self.w_f32(p + ".se_block.conv1.weight")[:, 0, :]) + self.w_f32(p + ".se_block.conv1.bias"), f(0)).astype(f)
+            z = (self._lin_w(s1, self.w_f32(p + ".se_block.conv2.weight")[:, 0, :]) + self.w_f32(p + ".se_block.conv2.bias")).astype(f)
+            se = (f(1.0) / (f(1.0) + np.exp(-z).astype(f))).astype(f)
+            h = ((o * se).astype(f) + res).astype(f)
+            hs.append(h)
+            if stages is not None:
+                stages[f"h{bi}"] = h
+        o = self._tdnn(np.ascontiguousarray(np.concatenate(hs, 1)), "speaker_encoder.mfa", ks[4], dl[4])  # :379-380
+        if stages is not None:
+            stages["mfa"] = o
+        # AttentiveStatisticsPooling :238-272
+        T = o.shape[0]
+        o64 = o.astype(np.float64)
+        mean = o64.mean(0).astype(f)
+        var = ((o64 - o64.mean(0)) ** 2).mean(0).astype(f)
+        std = np.sqrt(var + f(1e-12)).astype(f)
+        att_in = np.ascontiguousarray(np.concatenate([o, np.broadcast_to(mean, o.shape), np.broadcast_to(std, o.shape)], 1), f)
+        a = np.tanh(self._tdnn(att_in, "speaker_encoder.asp.tdnn", 1, 1)).astype(f)
+        a = (self._lin_w(a, self.w_f32("speaker_encoder.asp.conv.weight")[:, 0, :]) + self.w_f32("speaker_encoder.asp.conv.bias")).astype(f)
+        a = a - a.max(0, keepdims=True)
+        e = np.exp(a).astype(f)
+        att = (e / e.astype(np.float64).sum(0).astype(f)).astype(f)  # softmax over time
+        wmean = (att.astype(np.float64) * o64).sum(0).astype(f)
+        wvar = (att.astype(np.float64) * (o64 - wmean.astype(np.float64)) ** 2).sum(0).astype(f)
+        wstd = np.sqrt(np.maximum(wvar, f(1e-12))).astype(f)
+        pooled = np.concatenate([wmean, wstd])[None, :].astype(f)
+        if stages is not None:
+            stages["pooled"] = pooled[0]
+        out = (self._lin_w(pooled, self.w_f32("speaker_encoder.fc.weight")[:, 0, :]) + self.w_f32("speaker_encoder.fc.bias")).astype(f)
+        _ = T
+        return out[0]
+
+    # -- voice clone: prompt + generation (V3) ---------------------------------------------------
+    def prepare_icl_generation_inputs(self, req: Request):
+        """prepareICLGenerationInputs (Qwen3.swift:418-582). Returns (input_embeds, trailing, tts_pad, ref_codes
+        [16][T]). The speaker x-vector (fp32) is rounded to bf16 when it enters the prompt: the talker's storage
+        dtype, as for every other prompt row (MLX would instead promote the concatenated prefix to fp32)."""
+        t, cfg = self.t, self.cfg
+        if not self.has_encoder:
+            raise RuntimeError("Model not initialized: Speech tokenizer encoder not available")
+        audio = np.asarray(req.ref_audio, np.float32).reshape(-1)
+        ref_codes = self.codec_encode(audio)  # :443
+        ref_ids, target_ids = list(req.ref_text_ids), list(req.text_ids)
+        ref_text_ids = ref_ids[3: len(ref_ids) - 2]  # :451
+        text_ids = target_ids[3: len(target_ids) - 5]  # :457
+        tts = self.text_projection(self.embed_text([cfg["tts_bos_token_id"], cfg["tts_eos_token_id"],
+                                                    cfg["tts_pad_token_id"]]))
+        tts_bos, tts_eos, tts_pad = tts[0:1], tts[1:2], tts[2:3]
+        text_embed = self.text_projection(self.embed_text(ref_text_ids + text_ids))  # :473-475
+        text_embed = np.concatenate([text_embed, tts_eos], 0)
+        ce = self.codec_embed(ref_codes[0])  # :485-491
+        for i in range(t["num_code_groups"] - 1):
+            ce = self.add(ce, self.cp_embed(i, ref_codes[i + 1]))
+        codec_icl = np.concatenate([self.codec_embed([t["codec_bos_id"]]), ce], 0)  # :494-496
+        text_with_pad = self.add(text_embed, self.codec_embed([t["codec_pad_id"]]))  # :505-506
+        codec_with_pad = self.add(codec_icl, tts_pad)  # :509-510
+        icl = np.concatenate([text_with_pad, codec_with_pad], 0)
+        lang = req.language.lower()
+        lid = t["codec_language_id"].get(lang) if lang != "auto" else None  # :515-519 (no dialect override here)
+        speaker_embed = None
+        if self.sc is not None:  # :522-525
+            speaker_embed = f32_to_bf16(self.speaker_embedding(audio))[None, :]
+        if lid is None:
+            prefill = [t["codec_nothink_id"], t["codec_think_bos_id"], t["codec_think_eos_id"]]
+        else:
+            prefill = [t["codec_think_id"], t["codec_think_bos_id"], lid, t["codec_think_eos_id"]]
+        prefix = self.codec_embed(prefill)
+        suffix = self.codec_embed([t["codec_pad_id"], t["codec_bos_id"]])
+        prefix = np.concatenate([prefix] + ([speaker_embed] if speaker_embed is not None else []) + [suffix], 0)
+        role = self.text_projection(self.embed_text(target_ids[0:3]))  # :564-566
+        n = prefix.shape[0]
+        combined = np.concatenate([np.repeat(tts_pad, n - 2, 0), tts_bos], 0)
+        combined = self.add(combined, prefix[: n - 1])  # :569-573
+        input_embeds = np.concatenate([role, combined, icl], 0)  # :576
+        return (np.ascontiguousarray(input_embeds), np.ascontiguousarray(tts_pad), np.ascontiguousarray(tts_pad),
+                ref_codes)
+
+    def generate_voice_clone(self, req: Request, s: Sampling, row: int = 0):
+        """generateVoiceClone (Qwen3.swift:1009-1203): ICL prompt, the same AR loop (EOS is tested before the
+        history append, :1098-1102, which cannot change any output), decode [ref ++ generated] and cut the
+        reference part proportionally (:1195-1199). Returns (pcm, GenTrace, ref_codes)."""
+        tr = self.generate_codes(req, s, row)
+        if tr.codes.shape[0] == 0:
+            raise RuntimeError("Generation failed: No tokens generated")
+        ref_codes = tr.ref_codes
+        full = np.concatenate([ref_codes.T.astype(np.int32), tr.codes], 0)  # :1178-1180
+        pcm, valid = self.codec_decode(full)
+        if 0 < valid < pcm.shape[0]:
+            pcm = pcm[:valid]
+        ref_len, total = ref_codes.shape[1], full.shape[0]
+        cut = int(np.float32(ref_len) / np.float32(max(total, 1)) * np.float32(pcm.shape[0]))  # :1196
+        if 0 < cut < pcm.shape[0]:
+            pcm = pcm[cut:]
+        return pcm, tr, ref_codes

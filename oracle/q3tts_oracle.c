@@ -624,17 +624,18 @@ O_API void o_silu_mul_f32(const float* g, const float* u, int64_t n, float* out)
     for (int64_t i = 0; i < n; ++i) out[i] = silu_f(g[i]) * u[i];
 }
 
-/* DecoderTransformerAttention core (SpeechTokenizer.swift:512-528): full bidirectional attention,
- * no positional encoding, no mask. q,k,v [T][heads][D] -> out [T][heads][D]. */
-O_API void o_attention_full_f32(const float* q, const float* k, const float* v, int T, int heads,
-                                int D, float* out) {
+/* Scaled-dot-product attention, q,k,v [T][heads][D] -> out [T][heads][D]; causal = additive
+ * -inf mask above the diagonal (SpeechTokenizerEncoder.swift:1039-1043). */
+static void attention_f32(const float* q, const float* k, const float* v, int T, int heads, int D,
+                          int causal, float* out) {
     float scale = powf((float)D, -0.5f);
 #pragma omp parallel for collapse(2) schedule(static)
     for (int i = 0; i < T; ++i)
         for (int h = 0; h < heads; ++h) {
+            int Tk = causal ? i + 1 : T;
             float* sc = (float*)malloc(sizeof(float) * (size_t)T);
             float mx = -INFINITY;
-            for (int t = 0; t < T; ++t) {
+            for (int t = 0; t < Tk; ++t) {
                 float a = 0.f;
                 for (int d = 0; d < D; ++d)
                     a += q[((size_t)i * heads + h) * D + d] * k[((size_t)t * heads + h) * D + d];
@@ -643,15 +644,87 @@ O_API void o_attention_full_f32(const float* q, const float* k, const float* v, 
                 if (a > mx) mx = a;
             }
             float sum = 0.f;
-            for (int t = 0; t < T; ++t) {
+            for (int t = 0; t < Tk; ++t) {
                 sc[t] = expf(sc[t] - mx);
                 sum += sc[t];
             }
             for (int d = 0; d < D; ++d) {
                 float a = 0.f;
-                for (int t = 0; t < T; ++t) a += sc[t] * v[((size_t)t * heads + h) * D + d];
+                for (int t = 0; t < Tk; ++t) a += sc[t] * v[((size_t)t * heads + h) * D + d];
                 out[((size_t)i * heads + h) * D + d] = a / sum;
             }
             free(sc);
         }
+}
+
+/* DecoderTransformerAttention core (SpeechTokenizer.swift:512-528): full bidirectional attention,
+ * no positional encoding, no mask. */
+O_API void o_attention_full_f32(const float* q, const float* k, const float* v, int T, int heads,
+                                int D, float* out) {
+    attention_f32(q, k, v, T, heads, D, 0, out);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Voice-clone front end (fp32): codec encoder + speaker encoder blocks                       */
+/* ------------------------------------------------------------------------------------------ */
+
+/* EncoderAttention core (SpeechTokenizerEncoder.swift:497-526) under the causal mask built in
+ * encode() (:1039-1043); RoPE is applied by the caller. */
+O_API void o_attention_causal_f32(const float* q, const float* k, const float* v, int T, int heads,
+                                  int D, float* out) {
+    attention_f32(q, k, v, T, heads, D, 1, out);
+}
+
+/* General 1-D convolution on channels-last data, MLX.conv1d semantics after explicit padding:
+ *   StreamableConv1d (SpeechTokenizerEncoder.swift:163-186): zero pad (left, right), stride, dilation;
+ *   TimeDelayNetBlock (SpeakerEncoder.swift:62-69) : reflect pad (pad_mode 1, SpeakerEncoder.swift:26-40).
+ * x [T][Cin], W [Cout][K][Cin], out [Tout][Cout], Tout = (T + pl + pr - (K-1)*dil - 1)/stride + 1. */
+O_API int o_conv1d_f32(const float* x, const float* W, const float* bias, int T, int Cin, int Cout, int K,
+                       int stride, int dil, int pad_left, int pad_right, int pad_mode, float* out) {
+    int Tp = T + pad_left + pad_right;
+    int Tout = (Tp - (K - 1) * dil - 1) / stride + 1;
+    if (Tout <= 0) return 0;
+    if (!out) return Tout;
+#pragma omp parallel for schedule(static)
+    for (int t = 0; t < Tout; ++t) {
+        for (int co = 0; co < Cout; ++co) {
+            float acc = 0.f;
+            for (int k = 0; k < K; ++k) {
+                int ti = t * stride + k * dil - pad_left;
+                if (ti < 0 || ti >= T) {
+                    if (pad_mode == 0) continue;
+                    ti = ti < 0 ? -ti : 2 * (T - 1) - ti;
+                }
+                const float* xr = x + (size_t)ti * Cin;
+                const float* wr = W + ((size_t)co * K + k) * Cin;
+                for (int ci = 0; ci < Cin; ++ci) acc += xr[ci] * wr[ci];
+            }
+            if (bias) acc += bias[co];
+            out[(size_t)t * Cout + co] = acc;
+        }
+    }
+    return Tout;
+}
+
+/* melFilterbank (SpeakerEncoder.swift:493-550), all arithmetic in Float as in the Swift source:
+ * HTK mel scale, integer bin edges floor((nfft+1)*hz/sr), triangular slopes. out [nfft/2+1][n_mels]. */
+O_API void o_mel_filterbank(int nfft, int n_mels, int sr, float fmin, float fmax, float* out) {
+    int nfreq = nfft / 2 + 1;
+    float mel_min = 2595.0f * log10f(1.0f + fmin / 700.0f);
+    float mel_max = 2595.0f * log10f(1.0f + fmax / 700.0f);
+    int* bins = (int*)malloc(sizeof(int) * (size_t)(n_mels + 2));
+    for (int i = 0; i <= n_mels + 1; ++i) {
+        float mel = mel_min + (float)i * (mel_max - mel_min) / (float)(n_mels + 1);
+        float hz = 700.0f * (powf(10.0f, mel / 2595.0f) - 1.0f);
+        bins[i] = (int)floorf((float)(nfft + 1) * hz / (float)sr);
+    }
+    memset(out, 0, sizeof(float) * (size_t)nfreq * n_mels);
+    for (int m = 0; m < n_mels; ++m) {
+        int left = bins[m], center = bins[m + 1], right = bins[m + 2];
+        for (int k = left; k < center; ++k)
+            if (k < nfreq && center > left) out[(size_t)k * n_mels + m] = (float)(k - left) / (float)(center - left);
+        for (int k = center; k < right; ++k)
+            if (k < nfreq && right > center) out[(size_t)k * n_mels + m] = (float)(right - k) / (float)(right - center);
+    }
+    free(bins);
 }

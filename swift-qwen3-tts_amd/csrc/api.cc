@@ -99,9 +99,10 @@ q3tts_status q3tts_model_get_info(const q3tts_model* m, q3tts_model_info* out) {
         const q3::ModelConfig& c = md.cfg;
         std::strncpy(out->tts_model_type, c.tts_model_type.c_str(), sizeof(out->tts_model_type) - 1);
         out->sample_rate = c.sample_rate;
-        // supportsVoiceCloning needs the codec encoder (Qwen3.swift:1210-1214): not built yet -> 0
-        out->supports_voice_cloning = 0;
-        out->has_voice_cloning = 0;
+        // supportsVoiceCloning: base model with a codec encoder (Qwen3.swift:1210-1214); hasVoiceCloning: speaker encoder (:61-63)
+        out->supports_voice_cloning = (c.tts_model_type == "base" && md.has_codec && md.has_codec_encoder) ? 1 : 0;
+        out->has_voice_cloning = md.has_speaker_encoder ? 1 : 0;
+        out->speaker_embedding_dim = md.has_speaker_encoder ? md.speaker.enc_dim : 0;
         out->hidden_size = c.talker.hidden_size;
         out->num_layers = c.talker.num_hidden_layers;
         out->vocab_size = c.talker.vocab_size;
@@ -154,6 +155,39 @@ q3tts_status q3tts_codec_decode(q3tts_model* m, const int32_t* codes, const int3
         Q3_CHECK(m && codes && n_frames && pcm && audio_lengths, 3, "Invalid input: null argument");
         m->eng->lane0().codec_decode(codes, n_frames, batch, max_frames, pcm, audio_lengths);
         m->eng->timing.codec_ms = m->eng->lane0().timing.codec_ms;
+    });
+}
+
+q3tts_status q3tts_codec_encode(q3tts_model* m, const float* audio, int64_t n_samples, int32_t* codes, int32_t cap_frames,
+                                int32_t* n_frames) {
+    return guarded(m, [&] {
+        Q3_CHECK(m && audio && codes && n_frames, 3, "Invalid input: null argument");
+        *n_frames = m->eng->lane0().codec_encode(audio, n_samples, codes, cap_frames);
+        m->eng->timing = m->eng->lane0().timing;
+    });
+}
+
+int32_t q3tts_codec_encoded_frames(const q3tts_model* m, int64_t n_samples) {
+    if (!m || n_samples <= 0 || n_samples > (int64_t(1) << 24)) return 0;
+    return m->eng->lane0().encoded_frames(n_samples);
+}
+
+q3tts_status q3tts_speaker_embedding(q3tts_model* m, const float* audio, int64_t n_samples, int32_t sample_rate, float* out,
+                                     int32_t cap) {
+    return guarded(m, [&] {
+        Q3_CHECK(m && audio && out, 3, "Invalid input: null argument");
+        Q3_CHECK(sample_rate == 24000, 3,
+                 "Invalid input: Only 24kHz audio is supported for speaker embedding extraction");  // Qwen3.swift:223-225
+        m->eng->lane0().speaker_embedding(audio, n_samples, out, cap);
+        m->eng->timing = m->eng->lane0().timing;
+    });
+}
+
+q3tts_status q3tts_debug_frontend_stage(q3tts_model* m, const float* audio, int64_t n_samples, const char* stage, float* out,
+                                        int64_t cap_floats, int32_t* T, int32_t* C) {
+    return guarded(m, [&] {
+        Q3_CHECK(m && audio && stage && out && T && C, 3, "Invalid input: null argument");
+        m->eng->lane0().debug_frontend_stage(audio, n_samples, stage, out, cap_floats, T, C);
     });
 }
 

@@ -27,7 +27,13 @@ struct ConvGemmArgs {
     int ppf;                // positions per frame at this stage
     int Tmax;
     int B, Cin, N, K, dil;
-    int act;                // 0: none, 1: GELU (erf)
+    int act;                // 0: none, 1: GELU (erf), 2: GELU (tanh form), 3: ReLU, 4: sigmoid, 5: tanh(ReLU)
+    // voice-clone front end (SpeechTokenizerEncoder.swift, SpeakerEncoder.swift); all zero for the decoder
+    int pre_act;            // 1: ELU(alpha 1) on the input while staging (SeanetResnetBlock :338, :389, :441)
+    const float* x2;        // optional second input added to x before the conv (Res2NetBlock, SpeakerEncoder.swift:110)
+    int ldx2;
+    int shift;              // input row = t - (K-1)*dil + shift + tap*dil: "same" convs use shift = (K-1)*dil/2
+    int reflect;            // 1: rows outside [0,T) are mirrored (reflectPad1d, SpeakerEncoder.swift:26-40), else zero
 };
 void launch_conv_gemm(const ConvGemmArgs& a, hipStream_t st);
 
@@ -51,5 +57,34 @@ void launch_attn_full_f32(const float* qkv, int heads, const int32_t* frames, in
 // SnakeBeta -> k7 conv C->1 -> clip(-1,1) (MainDecoder tail, SpeechTokenizer.swift:687-688,781)
 void launch_out_conv(const float* x, int C, const float* ea, const float* ib, const float* w, const float* bias,
                      const int32_t* frames, int ppf, int Tmax, int B, float* pcm, hipStream_t st);
+
+// ---- voice-clone front end (kernels/voice_frontend.hip) ------------------------------------------
+// first SEANet conv: 1 -> C channels, causal k taps (SpeechTokenizerEncoder.swift:404-414). w [C][K], out [S][C]
+void launch_enc_init_conv(const float* audio, int64_t S, const float* w, const float* bias, int C, int K, float* out,
+                          hipStream_t st);
+// LayerNorm with bias over the last dim (EncoderTransformerLayer norm1/norm2, :559-560)
+void launch_layernorm_f32(const float* x, const float* w, const float* b, float eps, int C, int T, float* out,
+                          hipStream_t st);
+// MLXNN.RoPE(traditional: false) on the q and k thirds of qkv [T][3*heads*64], in place (:505-508).
+// cos/sin [T][32] fp32 tables.
+void launch_rope_qk_f32(float* qkv, int heads, int T, const float* cos_t, const float* sin_t, hipStream_t st);
+// causal variant of launch_attn_full_f32 (mask built at :1039-1043)
+void launch_attn_causal_f32(const float* qkv, int heads, int T, float* out, hipStream_t st);
+// EncoderResidualVectorQuantization.encode (:816-829) over `n_layers` codebooks: r -= emb[argmin(c2 - r.emb)].
+// x [T][ldx] (dim columns used), cb/c2 device pointer tables, codes out [(layer0 + j) * T + t].
+void launch_rvq_encode(const float* x, int ldx, int T, int dim, int bins, const float* const* cb, const float* const* c2,
+                       int n_layers, int32_t* codes, hipStream_t st);
+// power spectrum -> mel -> log (SpeakerEncoder.swift:437-452). spec [T][ld]: re in [0,nfreq), im in [nfreq,2*nfreq)
+void launch_log_mel(const float* spec, int ld, int T, int nfreq, const float* fb, int n_mels, float* out, hipStream_t st);
+// per-channel mean / variance over time (SqueezeExcitationBlock :146, AttentiveStatisticsPooling :243-245)
+void launch_time_stats(const float* x, int ld, int T, int C, float* mean, float* std_or_null, float eps, hipStream_t st);
+// out[t][c] = x[t][c] * se[c] + res[t][c]   (SE gate + block residual, SpeakerEncoder.swift:154, :210)
+void launch_scale_res(const float* x, int ldx, const float* se, const float* res, int ldr, float* out, int ldo, int T, int C,
+                      hipStream_t st);
+// out[t] = [x[t] | mean | std]   (AttentiveStatisticsPooling :248-252)
+void launch_asp_concat(const float* x, const float* mean, const float* stdv, int T, int C, float* out, hipStream_t st);
+// softmax over time of att [T][C], weighted mean / std of x -> pooled [2C] (:262-270)
+void launch_asp_pool(const float* att, const float* x, int T, int C, float eps, float* pooled, hipStream_t st);
+void launch_copy2d_f32(const float* src, int lds, float* dst, int ldd, int T, int C, hipStream_t st);
 
 }  // namespace q3

@@ -126,6 +126,77 @@ struct CodecDecoderConfig {  // Config.swift:385-415
     }
 };
 
+struct CodecEncoderConfig {  // Qwen3TTSTokenizerEncoderConfig, Config.swift:476-504
+    float frame_rate = 12.5f;
+    int audio_channels = 1, codebook_dim = 256, codebook_size = 2048, compress = 2, dilation_growth_rate = 2;
+    int head_dim = 64, hidden_size = 512, intermediate_size = 2048, kernel_size = 7, last_kernel_size = 3;
+    float layer_scale_initial_scale = 0.01f;
+    int max_position_embeddings = 8000, num_attention_heads = 8, num_filters = 64, num_hidden_layers = 8;
+    int num_key_value_heads = 8, num_quantizers = 32, num_residual_layers = 1, residual_kernel_size = 3;
+    float rope_theta = 10000.0f;
+    int sampling_rate = 24000, sliding_window = 250;
+    std::vector<int> upsampling_ratios{8, 6, 5, 4};
+    bool use_causal_conv = true, use_conv_shortcut = false;
+    static bool flag(const Json& j, const char* k, bool def) {
+        const Json* v = j.get(k);
+        return (v && v->kind == Json::Bool) ? v->b : def;
+    }
+    void parse(const Json& j) {
+        frame_rate = float(j.f64("frame_rate", frame_rate));
+        audio_channels = int(j.i64("audio_channels", audio_channels));
+        codebook_dim = int(j.i64("codebook_dim", codebook_dim));
+        codebook_size = int(j.i64("codebook_size", codebook_size));
+        compress = int(j.i64("compress", compress));
+        dilation_growth_rate = int(j.i64("dilation_growth_rate", dilation_growth_rate));
+        head_dim = int(j.i64("head_dim", head_dim));
+        hidden_size = int(j.i64("hidden_size", hidden_size));
+        intermediate_size = int(j.i64("intermediate_size", intermediate_size));
+        kernel_size = int(j.i64("kernel_size", kernel_size));
+        last_kernel_size = int(j.i64("last_kernel_size", last_kernel_size));
+        layer_scale_initial_scale = float(j.f64("layer_scale_initial_scale", layer_scale_initial_scale));
+        max_position_embeddings = int(j.i64("max_position_embeddings", max_position_embeddings));
+        num_attention_heads = int(j.i64("num_attention_heads", num_attention_heads));
+        num_filters = int(j.i64("num_filters", num_filters));
+        num_hidden_layers = int(j.i64("num_hidden_layers", num_hidden_layers));
+        num_key_value_heads = int(j.i64("num_key_value_heads", num_key_value_heads));
+        num_quantizers = int(j.i64("num_quantizers", num_quantizers));
+        num_residual_layers = int(j.i64("num_residual_layers", num_residual_layers));
+        residual_kernel_size = int(j.i64("residual_kernel_size", residual_kernel_size));
+        rope_theta = float(j.f64("rope_theta", rope_theta));
+        sampling_rate = int(j.i64("sampling_rate", sampling_rate));
+        sliding_window = int(j.i64("sliding_window", sliding_window));
+        upsampling_ratios = j.ints("upsampling_ratios", upsampling_ratios);
+        use_causal_conv = flag(j, "use_causal_conv", use_causal_conv);
+        use_conv_shortcut = flag(j, "use_conv_shortcut", use_conv_shortcut);
+    }
+    int hop() const {  // samples per encoder-transformer position
+        int t = 1;
+        for (int r : upsampling_ratios) t *= r;
+        return t;
+    }
+    int downsample_stride() const {  // SpeechTokenizerEncoder.swift:1008-1009, Float arithmetic
+        const float enc_rate = float(sampling_rate) / float(hop());
+        return int(enc_rate / frame_rate);
+    }
+};
+
+struct SpeakerEncoderConfig {  // Qwen3TTSSpeakerEncoderConfig, Config.swift:80-91
+    int mel_dim = 128, enc_dim = 1024;
+    std::vector<int> enc_channels{512, 512, 512, 512, 1536}, enc_kernel_sizes{5, 3, 3, 3, 1}, enc_dilations{1, 2, 3, 4, 1};
+    int enc_attention_channels = 128, enc_res2net_scale = 8, enc_se_channels = 128, sample_rate = 24000;
+    void parse(const Json& j) {
+        mel_dim = int(j.i64("mel_dim", mel_dim));
+        enc_dim = int(j.i64("enc_dim", enc_dim));
+        enc_channels = j.ints("enc_channels", enc_channels);
+        enc_kernel_sizes = j.ints("enc_kernel_sizes", enc_kernel_sizes);
+        enc_dilations = j.ints("enc_dilations", enc_dilations);
+        enc_attention_channels = int(j.i64("enc_attention_channels", enc_attention_channels));
+        enc_res2net_scale = int(j.i64("enc_res2net_scale", enc_res2net_scale));
+        enc_se_channels = int(j.i64("enc_se_channels", enc_se_channels));
+        sample_rate = int(j.i64("sample_rate", sample_rate));
+    }
+};
+
 struct ModelConfig {  // Config.swift:635-657, 584-594
     std::string tts_model_type = "voice_design", tts_model_size = "1b7";
     int tts_pad_token_id = 151671, tts_bos_token_id = 151672, tts_eos_token_id = 151673;
@@ -135,6 +206,8 @@ struct ModelConfig {  // Config.swift:635-657, 584-594
     bool has_quantization = false;
     int quant_group_size = 64, quant_bits = 4;
     bool has_speaker_encoder = false;
+    SpeakerEncoderConfig speaker;
+    CodecEncoderConfig codec_enc;
     // speech_tokenizer/config.json
     bool has_codec = false;
     int decode_upsample_rate = 1920;
@@ -157,11 +230,17 @@ struct ModelConfig {  // Config.swift:635-657, 584-594
             quant_group_size = int(q->i64("group_size", 64));
             quant_bits = int(q->i64("bits", 4));
         }
-        has_speaker_encoder = j.has("speaker_encoder_config");
+        if (const Json* sp = j.get("speaker_encoder_config"); sp && sp->kind == Json::Obj) {  // Qwen3.swift:55-57
+            has_speaker_encoder = true;
+            speaker.parse(*sp);
+        }
     }
     void parse_speech_tokenizer(const Json& j) {
         decode_upsample_rate = int(j.i64("decode_upsample_rate", decode_upsample_rate));
-        has_codec_encoder = j.has("encoder_config");
+        if (const Json* e = j.get("encoder_config"); e && e->kind == Json::Obj) {  // SpeechTokenizer.swift:808-812
+            has_codec_encoder = true;
+            codec_enc.parse(*e);
+        }
         if (const Json* d = j.get("decoder_config"); d && d->kind == Json::Obj) {
             has_codec = true;
             codec.parse(*d);

@@ -8,6 +8,7 @@
 #include <thread>
 
 #include "codec.h"
+#include "frontend.h"
 
 namespace q3 {
 
@@ -38,6 +39,7 @@ Engine::Engine(Model* model, const q3tts_load_opts& opts) : m_(model), opts_(opt
     Q3_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
     for (auto& e : ev_) Q3_HIP(hipEventCreate(&e));
     for (auto& e : burst_ev_) Q3_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : ev_fe_) Q3_HIP(hipEventCreate(&e));
     Bm_ = opts.max_batch;
     Mp_ = int(align_up(size_t(Bm_), 16));
     Pcap_ = opts.max_prompt;
@@ -49,17 +51,23 @@ Engine::Engine(Model* model, const q3tts_load_opts& opts) : m_(model), opts_(opt
     std::sort(speakers.begin(), speakers.end());
     alloc_workspace();
     if (m_->has_codec) codec_ = std::make_unique<CodecRunner>(*m_, st_);
+    if (m_->has_codec_encoder || m_->has_speaker_encoder) fe_ = std::make_unique<VoiceFrontEnd>(*m_, st_);
 }
 
 Engine::~Engine() {
     for (auto& g : graphs_) (void)hipGraphExecDestroy(g.second);
     codec_.reset();
+    fe_.reset();
+    for (void* p : {(void*)ref_audio_dev_, (void*)ref_codes_dev_, (void*)extra_, (void*)spk_f32_, (void*)dec_codes_})
+        if (p) (void)hipFree(p);
     if (ws_) (void)hipFree(ws_);
     for (void* p : {(void*)forced_dev_, (void*)sampled_dev_, (void*)tl_dump_, (void*)cl_dump_})
         if (p) (void)hipFree(p);
     for (auto& e : ev_)
         if (e) (void)hipEventDestroy(e);
     for (auto& e : burst_ev_)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& e : ev_fe_)
         if (e) (void)hipEventDestroy(e);
     if (st_) (void)hipStreamDestroy(st_);
 }
@@ -72,7 +80,7 @@ void Engine::alloc_workspace() {
     const int L = t.num_hidden_layers, CL = t.cp.num_hidden_layers;
     kv_layer_stride_ = size_t(n_pages_) * t.num_key_value_heads * kPageTokens * kHeadDim;
     cp_kv_layer_stride_ = size_t(Bm_) * t.cp.num_key_value_heads * kPageTokens * kHeadDim;
-    proj_cap_ = Bm_ * (Pcap_ + 8);
+    proj_cap_ = Bm_ * (2 * Pcap_ + 8);  // text + instruct or reference-text ids + the three tts tokens per row
     for (int pass = 0; pass < 2; ++pass) {
         Bump b{pass ? ws_ : nullptr};
         auto stream = [&](Stream& s, int hid, int q, int k, int inter_p, int vocab) {
@@ -325,6 +333,32 @@ ResolvedRequest Engine::resolve(const q3tts_request& r, const q3tts_sampling& sp
         return s;
     };
     bool use_speaker = false, use_instruct = false;
+    if (r.ref_audio != nullptr) {  // generateVoiceClone (Qwen3.swift:1009-1046): no routing by model type, no speaker/instruct
+        Q3_CHECK(m_->has_codec, 1, "Model not initialized: Speech tokenizer not loaded");  // :1029-1031
+        Q3_CHECK(m_->has_codec_encoder, 1,
+                 "Model not initialized: Voice cloning (ICL mode) requires the speech tokenizer encoder. Make sure to load a model "
+                 "with encoder weights.");  // :1033-1038
+        Q3_CHECK(r.n_ref_samples > 0, 3, "Invalid input: reference audio is empty");
+        Q3_CHECK(r.ref_text_ids && r.n_ref_text_ids >= 5, 3, "Invalid input: ref_text_ids must hold the chat-template tokens");
+        Q3_CHECK(r.n_text_ids >= 8, 3, "Invalid input: text_ids must hold the chat-template tokens");
+        Q3_CHECK(m_->codec_enc.bins <= t.vocab_size && m_->codec_enc.bins <= t.cp.vocab_size, 3,
+                 "Invalid input: encoder codebook larger than the codec embedding tables");
+        o.clone = true;
+        o.ref_audio = r.ref_audio;
+        o.n_ref_samples = r.n_ref_samples;
+        o.ref_text_ids.assign(r.ref_text_ids, r.ref_text_ids + r.n_ref_text_ids);
+        const std::string lang = lower(r.language ? r.language : "auto");
+        if (lang != "auto") {  // :515-519 (no dialect override on this path)
+            auto it = t.codec_language_id.find(lang);
+            if (it != t.codec_language_id.end()) o.language_id = it->second;
+        }
+        o.target_token_count = r.target_token_count;
+        const int mt = r.max_tokens > 0 ? r.max_tokens : 2048;
+        o.max_frames = sp.force_frames > 0 ? sp.force_frames : std::min(mt, std::max(75, r.target_token_count * 6));  // :1051-1052
+        for (int id : o.text_ids) Q3_CHECK(id >= 0 && id < t.text_vocab_size, 3, "Invalid input: text token id out of range");
+        for (int id : o.ref_text_ids) Q3_CHECK(id >= 0 && id < t.text_vocab_size, 3, "Invalid input: reference text token id out of range");
+        return o;
+    }
     if (type == "custom_voice" || type == "base") {
         const char* nm = type == "custom_voice" ? "CustomVoice" : "Base";
         Q3_CHECK(r.speaker != nullptr, 3,
@@ -394,8 +428,9 @@ void Engine::assemble_prompts(const std::vector<ResolvedRequest>& reqs, std::vec
         const auto& r = reqs[size_t(b)];
         text_off[size_t(b)] = int(ids.size());
         ids.insert(ids.end(), r.text_ids.begin(), r.text_ids.end());
-        instr_off[size_t(b)] = int(ids.size());
+        instr_off[size_t(b)] = int(ids.size());  // doubles as the reference-text offset of voice-clone rows
         ids.insert(ids.end(), r.instruct_ids.begin(), r.instruct_ids.end());
+        ids.insert(ids.end(), r.ref_text_ids.begin(), r.ref_text_ids.end());
         tts_off[size_t(b)] = int(ids.size());
         ids.push_back(cfg.tts_bos_token_id);  // Qwen3.swift:282-292
         ids.push_back(cfg.tts_eos_token_id);
@@ -408,21 +443,39 @@ void Engine::assemble_prompts(const std::vector<ResolvedRequest>& reqs, std::vec
     for (int b = 0; b < n; ++b) {
         const auto& r = reqs[size_t(b)];
         const int bos = tts_off[size_t(b)], eos = bos + 1, pad = bos + 2;
-        std::vector<int> cp_ids;  // codec prefix, Qwen3.swift:322-359
+        std::vector<int> cp_ids;  // codec prefix, Qwen3.swift:322-359 / 527-561
         if (r.language_id < 0) cp_ids = {t.codec_nothink_id, t.codec_think_bos_id, t.codec_think_eos_id};
         else cp_ids = {t.codec_think_id, t.codec_think_bos_id, r.language_id, t.codec_think_eos_id};
         if (r.speaker_token >= 0) cp_ids.push_back(r.speaker_token);
+        if (r.clone && m_->has_speaker_encoder) cp_ids.push_back(-2 - r.extra_base);  // x-vector row (:553-558)
         cp_ids.push_back(t.codec_pad_id);
         cp_ids.push_back(t.codec_bos_id);
-        for (int id : cp_ids) Q3_CHECK(id >= 0 && id < t.vocab_size, 3, "Invalid input: codec prefix id out of range");
+        for (int id : cp_ids) Q3_CHECK(id < t.vocab_size && id != -1, 3, "Invalid input: codec prefix id out of range");
         const int nc = int(cp_ids.size());
         int p = 0;
         auto push = [&](int a, int c) {
+            Q3_CHECK(p < Pcap_, 3, "Invalid input: prompt longer than max_prompt");
             pa.push_back(a);
             pb.push_back(c);
             pd.push_back(b * Pcap_ + p);
             ++p;
         };
+        if (r.clone) {  // prepareICLGenerationInputs (Qwen3.swift:418-582)
+            const int tl = int(r.text_ids.size()), rl = int(r.ref_text_ids.size()), ro = instr_off[size_t(b)];
+            for (int i = 0; i < 3; ++i) push(text_off[size_t(b)] + i, -1);                     // role, :564-566
+            for (int i = 0; i < nc - 1; ++i) push(i < nc - 2 ? pad : bos, cp_ids[size_t(i)]);  // :569-573
+            for (int i = 3; i < rl - 2; ++i) push(ro + i, t.codec_pad_id);                     // reference text, :451, :505-506
+            for (int i = 3; i < tl - 5; ++i) push(text_off[size_t(b)] + i, t.codec_pad_id);    // target text, :457
+            push(eos, t.codec_pad_id);                                                         // :476
+            push(pad, t.codec_bos_id);                                                         // :494-496, :509-510
+            for (int f = 0; f < r.ref_T; ++f) push(pad, -2 - (r.extra_base + 1 + f));
+            n_prompt[size_t(b)] = p;
+            ta.push_back(pad);  // trailing text is just tts_pad (:579)
+            tb.push_back(-1);
+            td.push_back(b * Tcap_);
+            n_trailing[size_t(b)] = 1;
+            continue;
+        }
         for (int i = 0; i < int(r.instruct_ids.size()); ++i) push(instr_off[size_t(b)] + i, -1);  // :383-384
         for (int i = 0; i < 3; ++i) push(text_off[size_t(b)] + i, -1);                            // role, :371
         for (int i = 0; i < nc - 1; ++i) push(i < nc - 2 ? pad : bos, cp_ids[size_t(i)]);         // :375-379
@@ -451,7 +504,7 @@ void Engine::assemble_prompts(const std::vector<ResolvedRequest>& reqs, std::vec
         Q3_HIP(hipMemcpyAsync(da, a.data(), k * 4, hipMemcpyHostToDevice, st_));
         Q3_HIP(hipMemcpyAsync(db, bb.data(), k * 4, hipMemcpyHostToDevice, st_));
         Q3_HIP(hipMemcpyAsync(dd, d.data(), k * 4, hipMemcpyHostToDevice, st_));
-        launch_compose_rows(proj_out_, H, m_->codec_emb, H, da, db, dd, dst, H, int(k), H, st_);
+        launch_compose_rows(proj_out_, H, m_->codec_emb, H, extra_, H, da, db, dd, dst, H, int(k), H, st_);
         Q3_HIP(hipStreamSynchronize(st_));  // host vectors are reused by the next call
     };
     run(pa, pb, pd, prompt_);
@@ -459,11 +512,145 @@ void Engine::assemble_prompts(const std::vector<ResolvedRequest>& reqs, std::vec
     launch_copy_rows(proj_out_ + size_t(tts_off[0] + 2) * H, H, tts_pad_, H, 1, H, st_);
 }
 
+const float* Engine::upload_audio(const float* audio, int64_t n) {
+    if (size_t(n) > ref_audio_cap_) {
+        Q3_HIP(hipStreamSynchronize(st_));
+        if (ref_audio_dev_) Q3_HIP(hipFree(ref_audio_dev_));
+        ref_audio_dev_ = nullptr;
+        Q3_HIP(hipMalloc(reinterpret_cast<void**>(&ref_audio_dev_), size_t(n) * 4));
+        ref_audio_cap_ = size_t(n);
+    }
+    Q3_HIP(hipMemcpyAsync(ref_audio_dev_, audio, size_t(n) * 4, hipMemcpyHostToDevice, st_));
+    return ref_audio_dev_;
+}
+
+// Steps 1, 5 and 8 of prepareICLGenerationInputs (Qwen3.swift:436-444, 479-491, 521-525) for every voice-clone row:
+// reference codes, the per-frame sums of their 16 embeddings and the speaker x-vector, all left on the device.
+void Engine::prepare_clone_rows(std::vector<ResolvedRequest>& reqs) {
+    const int H = m_->cfg.talker.hidden_size;
+    Q3_CHECK(fe_ != nullptr, 1, "Model not initialized: Speech tokenizer encoder not available");
+    size_t total_codes = 0, total_rows = 0;
+    for (auto& r : reqs) {
+        if (!r.clone) continue;
+        r.ref_T = fe_->encoded_frames(r.n_ref_samples);
+        r.ref_off = int(total_codes);
+        r.extra_base = int(total_rows);
+        total_codes += size_t(16) * r.ref_T;
+        total_rows += size_t(1) + r.ref_T;
+    }
+    if (total_codes > ref_codes_cap_) {
+        if (ref_codes_dev_) Q3_HIP(hipFree(ref_codes_dev_));
+        ref_codes_dev_ = nullptr;
+        Q3_HIP(hipMalloc(reinterpret_cast<void**>(&ref_codes_dev_), total_codes * 4));
+        ref_codes_cap_ = total_codes;
+    }
+    if (total_rows > extra_cap_) {
+        if (extra_) Q3_HIP(hipFree(extra_));
+        extra_ = nullptr;
+        Q3_HIP(hipMalloc(reinterpret_cast<void**>(&extra_), total_rows * H * 2));
+        extra_cap_ = total_rows;
+    }
+    if (!spk_f32_) Q3_HIP(hipMalloc(reinterpret_cast<void**>(&spk_f32_), size_t(H) * 4));
+    for (auto& r : reqs) {
+        if (!r.clone) continue;
+        const float* a = upload_audio(r.ref_audio, r.n_ref_samples);
+        const int T = fe_->encode(a, r.n_ref_samples, ref_codes_dev_ + r.ref_off);
+        Q3_CHECK(T == r.ref_T, 7, "internal error: reference frame count");
+        uint16_t* rows = extra_ + size_t(r.extra_base) * H;
+        if (m_->has_speaker_encoder) {
+            // The x-vector is fp32; it enters the prompt in the talker's storage dtype like every other row
+            // (the reference's MLX concat would instead promote the prompt to fp32).
+            fe_->speaker_embedding(a, r.n_ref_samples, spk_f32_);
+            launch_f32_to_bf16(spk_f32_, rows, H, st_);
+        }
+        launch_ref_embed_rows(ref_codes_dev_ + r.ref_off, T, 16, m_->codec_emb, m_->cp_emb_dev, H, rows + H, H, st_);
+    }
+}
+
+int Engine::encoded_frames(int64_t n_samples) const {
+    return (fe_ && m_->has_codec_encoder) ? fe_->encoded_frames(n_samples) : 0;
+}
+
+int Engine::codec_encode(const float* audio, int64_t n_samples, int32_t* codes, int cap_frames) {
+    Q3_CHECK(fe_ && m_->has_codec_encoder, 1, "Model not initialized: Speech tokenizer encoder not available");
+    Q3_CHECK(audio && n_samples > 0, 3, "Invalid input: empty audio");
+    const int T = fe_->encoded_frames(n_samples);
+    Q3_CHECK(T <= cap_frames, 3, "Invalid input: output buffer too small for the encoded frames");
+    if (size_t(16) * T > ref_codes_cap_) {
+        if (ref_codes_dev_) Q3_HIP(hipFree(ref_codes_dev_));
+        ref_codes_dev_ = nullptr;
+        Q3_HIP(hipMalloc(reinterpret_cast<void**>(&ref_codes_dev_), size_t(16) * T * 4));
+        ref_codes_cap_ = size_t(16) * T;
+    }
+    const float* a = upload_audio(audio, n_samples);
+    Q3_HIP(hipEventRecord(ev_fe_[0], st_));
+    fe_->encode(a, n_samples, ref_codes_dev_);
+    Q3_HIP(hipEventRecord(ev_fe_[1], st_));
+    Q3_HIP(hipStreamSynchronize(st_));
+    Q3_HIP(hipMemcpy(codes, ref_codes_dev_, size_t(16) * T * 4, hipMemcpyDeviceToHost));
+    float ms = 0;
+    Q3_HIP(hipEventElapsedTime(&ms, ev_fe_[0], ev_fe_[1]));
+    timing = q3tts_timing{};
+    timing.frontend_ms = ms;
+    return T;
+}
+
+void Engine::speaker_embedding(const float* audio, int64_t n_samples, float* out, int cap) {
+    Q3_CHECK(fe_ && m_->has_speaker_encoder, 1, "Model not initialized: Speaker encoder not available for this model");
+    Q3_CHECK(audio && n_samples > 0, 3, "Invalid input: empty audio");
+    const int D = m_->speaker.enc_dim;
+    Q3_CHECK(cap >= D, 3, "Invalid input: output buffer too small for the speaker embedding");
+    if (!spk_f32_) Q3_HIP(hipMalloc(reinterpret_cast<void**>(&spk_f32_), size_t(m_->cfg.talker.hidden_size) * 4));
+    const float* a = upload_audio(audio, n_samples);
+    Q3_HIP(hipEventRecord(ev_fe_[0], st_));
+    fe_->speaker_embedding(a, n_samples, spk_f32_);
+    Q3_HIP(hipEventRecord(ev_fe_[1], st_));
+    Q3_HIP(hipStreamSynchronize(st_));
+    Q3_HIP(hipMemcpy(out, spk_f32_, size_t(D) * 4, hipMemcpyDeviceToHost));
+    float ms = 0;
+    Q3_HIP(hipEventElapsedTime(&ms, ev_fe_[0], ev_fe_[1]));
+    timing = q3tts_timing{};
+    timing.frontend_ms = ms;
+}
+
+void Engine::debug_frontend_stage(const float* audio, int64_t n_samples, const char* stage, float* out, int64_t cap, int* T, int* C) {
+    Q3_CHECK(fe_ != nullptr, 1, "Model not initialized: Speech tokenizer encoder not available");
+    Q3_CHECK(audio && n_samples > 0 && stage, 3, "Invalid input: empty audio or stage name");
+    const float* a = upload_audio(audio, n_samples);
+    StageCapture cap_s;
+    cap_s.name = stage;
+    static const char* kSpeaker[] = {"mel", "h0", "h1", "h2", "h3", "mfa", "pooled"};
+    bool is_spk = false;
+    for (const char* s : kSpeaker) is_spk = is_spk || cap_s.name == s;
+    if (is_spk) {
+        Q3_CHECK(m_->has_speaker_encoder, 1, "Model not initialized: Speaker encoder not available for this model");
+        if (!spk_f32_) Q3_HIP(hipMalloc(reinterpret_cast<void**>(&spk_f32_), size_t(m_->cfg.talker.hidden_size) * 4));
+        fe_->speaker_embedding(a, n_samples, spk_f32_, &cap_s);
+    } else {
+        Q3_CHECK(m_->has_codec_encoder, 1, "Model not initialized: Speech tokenizer encoder not available");
+        const int Tq = fe_->encoded_frames(n_samples);
+        if (size_t(16) * Tq > ref_codes_cap_) {
+            if (ref_codes_dev_) Q3_HIP(hipFree(ref_codes_dev_));
+            ref_codes_dev_ = nullptr;
+            Q3_HIP(hipMalloc(reinterpret_cast<void**>(&ref_codes_dev_), size_t(16) * Tq * 4));
+            ref_codes_cap_ = size_t(16) * Tq;
+        }
+        fe_->encode(a, n_samples, ref_codes_dev_, &cap_s);
+    }
+    Q3_HIP(hipStreamSynchronize(st_));
+    Q3_CHECK(!cap_s.data.empty(), 3, std::string("Invalid input: unknown front-end stage '") + stage + "'");
+    Q3_CHECK(int64_t(cap_s.data.size()) <= cap, 3, "Invalid input: output buffer too small");
+    std::memcpy(out, cap_s.data.data(), cap_s.data.size() * 4);
+    *T = cap_s.T;
+    *C = cap_s.C;
+}
+
 void Engine::debug_prepare_inputs(const q3tts_request& req, uint16_t* input_embeds, int cap_prompt, int* n_prompt,
                                   uint16_t* trailing, int cap_trailing, int* n_trailing, uint16_t* tts_pad) {
     q3tts_sampling sp{};
     q3tts_default_sampling(&sp);
     std::vector<ResolvedRequest> rr{resolve(req, sp)};
+    if (rr[0].clone) prepare_clone_rows(rr);
     std::vector<int> np, nt;
     assemble_prompts(rr, np, nt);
     const int H = m_->cfg.talker.hidden_size;
@@ -494,6 +681,12 @@ void Engine::generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp
     for (auto& r : rr) Q3_CHECK(r.max_frames <= Fcap_, 3, "Invalid input: max_tokens exceeds the configured max_frames");
     if (m_->has_codec == false)
         throw Error(1, "Model not initialized: Speech tokenizer not loaded");  // Qwen3.swift:799-801
+
+    bool any_clone = false;
+    for (auto& r : rr) any_clone = any_clone || r.clone;
+    Q3_HIP(hipEventRecord(ev_fe_[0], st_));
+    if (any_clone) prepare_clone_rows(rr);  // codec encoder + speaker encoder, once per request (Qwen3.swift:443, :524)
+    Q3_HIP(hipEventRecord(ev_fe_[1], st_));
 
     std::vector<int> np, nt;
     assemble_prompts(rr, np, nt);
@@ -631,7 +824,38 @@ void Engine::generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp
     }
     float* pcm_dev = nullptr;
     const int up = codec_->upsample();
-    if (Fmax > 0) codec_->decode(codes_, Fcap_, frames, &pcm_dev);
+    std::vector<std::vector<int32_t>> ref_code0((size_t)(n));  // first code row of each reference (valid-length count)
+    if (any_clone && Fmax > 0) {  // decode [reference ++ generated] (Qwen3.swift:1176-1186)
+        std::vector<int> dframes((size_t)(n), 0);
+        int Fdec = 0;
+        for (int b = 0; b < n; ++b) {
+            const int F = frames[size_t(b)];
+            dframes[size_t(b)] = F > 0 ? F + (rr[size_t(b)].clone ? rr[size_t(b)].ref_T : 0) : 0;
+            Fdec = std::max(Fdec, dframes[size_t(b)]);
+        }
+        const size_t need = size_t(n) * Fdec * 16;
+        if (need > dec_codes_cap_) {
+            if (dec_codes_) Q3_HIP(hipFree(dec_codes_));
+            dec_codes_ = nullptr;
+            Q3_HIP(hipMalloc(reinterpret_cast<void**>(&dec_codes_), need * 4));
+            dec_codes_cap_ = need;
+        }
+        for (int b = 0; b < n; ++b) {
+            const auto& r = rr[size_t(b)];
+            if (frames[size_t(b)] == 0) continue;
+            launch_build_decode_codes(r.clone ? ref_codes_dev_ + r.ref_off : nullptr, r.clone ? r.ref_T : 0,
+                                      codes_ + size_t(b) * Fcap_ * 16, frames[size_t(b)], dec_codes_ + size_t(b) * Fdec * 16, st_);
+            if (r.clone) {
+                ref_code0[size_t(b)].resize(size_t(r.ref_T));
+                Q3_HIP(hipMemcpyAsync(ref_code0[size_t(b)].data(), ref_codes_dev_ + r.ref_off, size_t(r.ref_T) * 4,
+                                      hipMemcpyDeviceToHost, st_));
+            }
+        }
+        codec_->decode(dec_codes_, Fdec, dframes, &pcm_dev);
+        Fmax = Fdec;
+    } else if (Fmax > 0) {
+        codec_->decode(codes_, Fcap_, frames, &pcm_dev);
+    }
     Q3_HIP(hipEventRecord(ev_[3], st_));
     Q3_HIP(hipStreamSynchronize(st_));
     float ms = 0;
@@ -641,6 +865,8 @@ void Engine::generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp
     timing.decode_ms = ms;
     Q3_HIP(hipEventElapsedTime(&ms, ev_[2], ev_[3]));
     timing.codec_ms = ms;
+    Q3_HIP(hipEventElapsedTime(&ms, ev_fe_[0], ev_fe_[1]));
+    timing.frontend_ms = ms;
     timing.frame_steps = launched;
     timing.rows = n;
     {
@@ -673,12 +899,20 @@ void Engine::generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp
         // audioLengths = count(code0 > 0) * 1920, trim when 0 < valid < len (SpeechTokenizer.swift:831-833, Qwen3.swift:954-959)
         int valid_tok = 0;
         for (int f = 0; f < F; ++f) valid_tok += r.codes[size_t(f) * 16] > 0 ? 1 : 0;
-        int64_t ns = int64_t(F) * up;
+        for (int32_t c : ref_code0[size_t(b)]) valid_tok += c > 0 ? 1 : 0;
+        const int ref_T = rr[size_t(b)].clone ? rr[size_t(b)].ref_T : 0, total_f = ref_T + F;
+        int64_t ns = int64_t(total_f) * up;
         const int64_t valid = int64_t(valid_tok) * up;
         if (valid > 0 && valid < ns) ns = valid;
+        int64_t cut = 0;
+        if (ref_T > 0) {  // proportional removal of the reference part (Qwen3.swift:1195-1199), Float arithmetic
+            cut = int64_t(float(ref_T) / float(std::max(total_f, 1)) * float(ns));
+            if (!(cut > 0 && cut < ns)) cut = 0;
+        }
+        ns -= cut;
         r.n_samples = ns;
         r.pcm = static_cast<float*>(std::malloc(size_t(ns) * 4));
-        Q3_HIP(hipMemcpy(r.pcm, pcm_dev + size_t(b) * Fmax * up, size_t(ns) * 4, hipMemcpyDeviceToHost));
+        Q3_HIP(hipMemcpy(r.pcm, pcm_dev + size_t(b) * Fmax * up + cut, size_t(ns) * 4, hipMemcpyDeviceToHost));
         r.status = Q3TTS_OK;
     }
     if (cb) {
@@ -899,6 +1133,7 @@ void EngineGroup::generate(const q3tts_request* reqs, int n, const q3tts_samplin
         timing.prefill_ms = std::max(timing.prefill_ms, t.prefill_ms);
         timing.decode_ms = std::max(timing.decode_ms, t.decode_ms);
         timing.codec_ms = std::max(timing.codec_ms, t.codec_ms);
+        timing.frontend_ms = std::max(timing.frontend_ms, t.frontend_ms);
         timing.frame_steps = std::max(timing.frame_steps, t.frame_steps);
         timing.rows += t.rows;
         timing.kv_bytes_read += t.kv_bytes_read;

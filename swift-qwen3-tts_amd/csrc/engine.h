@@ -31,9 +31,18 @@ struct ResolvedRequest {
     int language_id = -1;    // -1: none ("auto" without dialect)
     int max_frames = 0;
     int target_token_count = 0;
+    // voice clone (generateVoiceClone, Qwen3.swift:1009-1203)
+    bool clone = false;
+    std::vector<int32_t> ref_text_ids;
+    const float* ref_audio = nullptr;  // caller memory, valid during the call
+    int64_t n_ref_samples = 0;
+    int ref_T = 0;        // reference frames (filled by prepare_clone_rows)
+    int extra_base = 0;   // first row of this request in extra_: speaker x-vector, then ref_T embedding sums
+    int ref_off = 0;      // offset of this request's [16][ref_T] codes in ref_codes_dev_
 };
 
 class CodecRunner;
+class VoiceFrontEnd;
 
 class Engine {
   public:
@@ -56,6 +65,11 @@ class Engine {
     void codec_decode(const int32_t* codes, const int32_t* n_frames, int batch, int max_frames, float* pcm,
                       int64_t* audio_lengths);
     void debug_codec_stage(const int32_t* codes, int n_frames, const char* stage, float* out, int64_t cap, int* T, int* C);
+    // voice-clone front end (SpeechTokenizer.swift:841-846; Qwen3.swift:222-249); host buffers in and out
+    int codec_encode(const float* audio, int64_t n_samples, int32_t* codes, int cap_frames);
+    int encoded_frames(int64_t n_samples) const;
+    void speaker_embedding(const float* audio, int64_t n_samples, float* out, int cap);
+    void debug_frontend_stage(const float* audio, int64_t n_samples, const char* stage, float* out, int64_t cap, int* T, int* C);
 
     std::vector<std::string> speakers;  // sorted (Qwen3.swift:965-971)
 
@@ -71,6 +85,7 @@ class Engine {
     hipStream_t st_ = nullptr;
     hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t burst_ev_[2] = {nullptr, nullptr};
+    hipEvent_t ev_fe_[2] = {nullptr, nullptr};
     int Bm_ = 0, Mp_ = 0;  // max batch, padded to 16
     int Pcap_ = 0, Tcap_ = 0, Fcap_ = 0, max_pages_ = 0, n_pages_ = 0;
 
@@ -104,6 +119,19 @@ class Engine {
 
     std::map<int, hipGraphExec_t> graphs_;  // keyed by batch size
     std::unique_ptr<CodecRunner> codec_;
+    std::unique_ptr<VoiceFrontEnd> fe_;
+    // voice-clone scratch (grown on demand)
+    float* ref_audio_dev_ = nullptr;
+    size_t ref_audio_cap_ = 0;
+    int32_t* ref_codes_dev_ = nullptr;
+    size_t ref_codes_cap_ = 0;
+    uint16_t* extra_ = nullptr;  // [rows][H] bf16: speaker x-vectors and reference-frame embedding sums
+    size_t extra_cap_ = 0;
+    float* spk_f32_ = nullptr;
+    int32_t* dec_codes_ = nullptr;  // [n][Fdec][16]: reference ++ generated codes for the decoder
+    size_t dec_codes_cap_ = 0;
+    const float* upload_audio(const float* audio, int64_t n);
+    void prepare_clone_rows(std::vector<ResolvedRequest>& reqs);
 
     void alloc_workspace();
     ResolvedRequest resolve(const q3tts_request& r, const q3tts_sampling& sp) const;

@@ -160,10 +160,17 @@ struct FrameEndArgs {  // Qwen3.swift:919-935 + loop bookkeeping
 };
 void launch_frame_end(const FrameEndArgs& a, hipStream_t st);
 
-// prompt assembly (Qwen3.swift:371-406): dst[dst_row[i]] = b[i] < 0 ? proj[a[i]] : bf16(proj[a[i]] + table[b[i]])
-void launch_compose_rows(const uint16_t* proj, int ldp, const uint16_t* table, int ldt, const int32_t* a,
-                         const int32_t* b, const int32_t* dst_row, uint16_t* dst, int ldd, int n, int dim,
+// prompt assembly (Qwen3.swift:371-406, 505-510): dst[dst_row[i]] = proj[a[i]] when b[i] == -1, else
+// bf16(proj[a[i]] + other) with other = table[b[i]] (b >= 0) or extra[-2 - b[i]] (voice-clone rows)
+void launch_compose_rows(const uint16_t* proj, int ldp, const uint16_t* table, int ldt, const uint16_t* extra, int lde,
+                         const int32_t* a, const int32_t* b, const int32_t* dst_row, uint16_t* dst, int ldd, int n, int dim,
                          hipStream_t st);
+// sum of the 16 codebook embeddings of reference frames (Qwen3.swift:485-491); codes [groups][T]
+void launch_ref_embed_rows(const int32_t* codes, int T, int groups, const uint16_t* codec_emb, const uint16_t* const* cp_emb,
+                           int H, uint16_t* out, int ldo, hipStream_t st);
+void launch_f32_to_bf16(const float* x, uint16_t* out, int n, hipStream_t st);
+// out [Tref + F][16] = transpose(ref [16][Tref]) ++ gen [F][16]   (Qwen3.swift:1176-1180)
+void launch_build_decode_codes(const int32_t* ref, int Tref, const int32_t* gen, int F, int32_t* out, hipStream_t st);
 
 // copies rows (bf16) between strided buffers: dst[r][0..dim) = src[r][0..dim)
 void launch_copy_rows(const uint16_t* src, int lds, uint16_t* dst, int ldd, int rows, int dim, hipStream_t st);

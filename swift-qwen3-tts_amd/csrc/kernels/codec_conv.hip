@@ -7,6 +7,9 @@
 // pointwise convs / Linears of the ConvNeXt blocks and the transformer (K = 1), with
 //   prologue : SnakeBeta on the input (:232-254) while staging the tile,
 //   epilogue : + bias, exact-erf GELU, per-channel scale (LayerScale / gamma), + residual.
+// The voice-clone front end (SpeechTokenizerEncoder.swift, SpeakerEncoder.swift) reuses it with an ELU or
+// pre-add prologue, "same" (shifted, reflect-padded) windows and ReLU / sigmoid / tanh epilogues; strided
+// convs arrive as K = 2 causal convs over a [T/r][r*C] view of the input (model.cc).
 //
 //   out[b][t][n] = res[b][t][n] + scale[n] * act( bias[n] + sum_{tap,ci} W[n][tap][ci] * A(b, t-(K-1-tap)*dil, ci) )
 //
@@ -31,6 +34,16 @@ constexpr int MAX_HALO = 56;   // (K-1)*dil <= 54 in the decoder (k7, dil 9)
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
+// geluApprox (SpeechTokenizerEncoder.swift:1080-1082), relu / sigmoid / tanh(relu) (SpeakerEncoder.swift:68, 151, 255-256)
+__device__ __forceinline__ float act_other(float v, int act) {
+    switch (act) {
+        case 2: return v * 0.5f * (1.0f + tanhf(0.7978845608f * (v + 0.044715f * (v * v * v))));
+        case 3: return fmaxf(v, 0.f);
+        case 4: return 1.0f / (1.0f + expf(-v));
+        default: return tanhf(fmaxf(v, 0.f));
+    }
+}
+
 template <int BN>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
     constexpr int CT = BN / 32;  // 16-channel tiles per wave (wave tile = 64 positions x BN/2 channels)
@@ -48,6 +61,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
     const int halo = (a.K - 1) * a.dil;
     const int rows = BM + halo;
     const float* xb = a.x + (size_t)b * a.x_bstride;
+    const float* x2b = a.x2;  // front-end calls are single-row (B = 1)
     const int nchunks = (a.Cin + KC - 1) / KC;
     const int steps = nchunks * a.K;
 
@@ -89,10 +103,21 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
         __syncthreads();  // previous chunk's MFMAs are done with As
         for (int item = tid; item < rows * 8; item += 256) {
             const int r = item >> 3, c4 = (item & 7) * 4;
-            const int t = t0 - halo + r;
+            int t = t0 - halo + a.shift + r;
+            if (a.reflect) t = t < 0 ? -t : (t >= T ? 2 * (T - 1) - t : t);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (t >= 0 && t < T && c0 + c4 < a.Cin) {
                 v = *reinterpret_cast<const float4*>(xb + (size_t)t * a.ldx + c0 + c4);
+                if (x2b) {
+                    const float4 u = *reinterpret_cast<const float4*>(x2b + (size_t)t * a.ldx2 + c0 + c4);
+                    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                }
+                if (a.pre_act == 1) {  // ELU, alpha 1 (SpeechTokenizerEncoder.swift:1075-1077)
+                    v.x = v.x > 0.f ? v.x : expf(v.x) - 1.0f;
+                    v.y = v.y > 0.f ? v.y : expf(v.y) - 1.0f;
+                    v.z = v.z > 0.f ? v.z : expf(v.z) - 1.0f;
+                    v.w = v.w > 0.f ? v.w : expf(v.w) - 1.0f;
+                }
                 if (a.snake_ea) {
                     const float4 ea = *reinterpret_cast<const float4*>(a.snake_ea + c0 + c4);
                     const float4 ib = *reinterpret_cast<const float4*>(a.snake_ib + c0 + c4);
@@ -152,6 +177,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
             if (a.act == 1) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+            } else if (a.act != 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = act_other(v[j], a.act);
             }
             if (a.scale) {
                 const float4 sv = *reinterpret_cast<const float4*>(a.scale + n);
@@ -170,6 +198,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
 
 void launch_conv_gemm(const ConvGemmArgs& a, hipStream_t st) {
     Q3_CHECK((a.K - 1) * a.dil <= MAX_HALO, 3, "conv_gemm: receptive field too large");
+    Q3_CHECK(!a.x2 || (a.B == 1 && a.ldx2 % 4 == 0), 3, "conv_gemm: the pre-add input is single-row only");
     Q3_CHECK(a.Cin % 4 == 0 && a.N % 4 == 0 && a.ldx % 4 == 0 && a.ldo % 4 == 0, 3, "conv_gemm: channels must be multiples of 4");
     const int mt = (a.Tmax + BM - 1) / BM;
     if (mt <= 0 || a.B <= 0) return;

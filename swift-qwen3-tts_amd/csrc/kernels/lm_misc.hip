@@ -99,18 +99,44 @@ __global__ void add_rows_kernel(const uint16_t* a, int lda, const uint16_t* b, i
     for (int i = threadIdx.x; i < dim; i += blockDim.x) orow[i] = f2bf(bf2f(ar[i]) + bf2f(br[i]));
 }
 
-__global__ void compose_rows_kernel(const uint16_t* proj, int ldp, const uint16_t* table, int ldt, const int32_t* a,
-                                    const int32_t* b, const int32_t* dst_row, uint16_t* dst, int ldd, int dim) {
+__global__ void compose_rows_kernel(const uint16_t* proj, int ldp, const uint16_t* table, int ldt, const uint16_t* extra,
+                                    int lde, const int32_t* a, const int32_t* b, const int32_t* dst_row, uint16_t* dst,
+                                    int ldd, int dim) {
     const int r = blockIdx.x;
     const uint16_t* pa = proj + (size_t)a[r] * ldp;
     const int bi = b[r];
     uint16_t* o = dst + (size_t)dst_row[r] * ldd;
-    if (bi < 0) {
+    if (bi == -1) {
         for (int i = threadIdx.x; i < dim; i += blockDim.x) o[i] = pa[i];
     } else {
-        const uint16_t* pb = table + (size_t)bi * ldt;
+        const uint16_t* pb = bi >= 0 ? table + (size_t)bi * ldt : extra + (size_t)(-2 - bi) * lde;
         for (int i = threadIdx.x; i < dim; i += blockDim.x) o[i] = f2bf(bf2f(pa[i]) + bf2f(pb[i]));
     }
+}
+
+// Voice-clone prompt rows (Qwen3.swift:485-491): out[t] = codec_emb[c0[t]] + cp_emb[0][c1[t]] + ... left to right,
+// each add rounded to bf16. codes [groups][T].
+__global__ void ref_embed_rows_kernel(const int32_t* codes, int T, int groups, const uint16_t* codec_emb,
+                                      const uint16_t* const* cp_emb, int H, uint16_t* out, int ldo) {
+    const int t = blockIdx.x;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) {
+        float v = bf2f(codec_emb[(size_t)codes[t] * H + i]);
+        for (int g = 1; g < groups; ++g) v = rbf(v + bf2f(cp_emb[g - 1][(size_t)codes[(size_t)g * T + t] * H + i]));
+        out[(size_t)t * ldo + i] = f2bf(v);
+    }
+}
+
+// decoder input of a voice-clone row (Qwen3.swift:1176-1180): reference frames ([16][Tref]) then generated ([F][16])
+__global__ void build_decode_codes_kernel(const int32_t* ref, int Tref, const int32_t* gen, int F, int32_t* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (Tref + F) * 16) return;
+    const int f = i >> 4, g = i & 15;
+    out[i] = f < Tref ? ref[(size_t)g * Tref + f] : gen[(size_t)(f - Tref) * 16 + g];
+}
+
+__global__ void f32_to_bf16_kernel(const float* x, uint16_t* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = f2bf(x[i]);
 }
 
 __global__ void copy_rows_kernel(const uint16_t* src, int lds, uint16_t* dst, int ldd, int dim) {
@@ -228,11 +254,26 @@ void launch_add_rows(const uint16_t* a, int lda, const uint16_t* b, int ldb, int
     if (rows <= 0) return;
     hipLaunchKernelGGL(add_rows_kernel, dim3(rows), dim3(256), 0, st, a, lda, b, ldb, dim, out, ldo);
 }
-void launch_compose_rows(const uint16_t* proj, int ldp, const uint16_t* table, int ldt, const int32_t* a,
-                         const int32_t* b, const int32_t* dst_row, uint16_t* dst, int ldd, int n, int dim,
+void launch_compose_rows(const uint16_t* proj, int ldp, const uint16_t* table, int ldt, const uint16_t* extra, int lde,
+                         const int32_t* a, const int32_t* b, const int32_t* dst_row, uint16_t* dst, int ldd, int n, int dim,
                          hipStream_t st) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(compose_rows_kernel, dim3(n), dim3(256), 0, st, proj, ldp, table, ldt, a, b, dst_row, dst, ldd, dim);
+    hipLaunchKernelGGL(compose_rows_kernel, dim3(n), dim3(256), 0, st, proj, ldp, table, ldt, extra, lde, a, b, dst_row, dst,
+                       ldd, dim);
+}
+void launch_ref_embed_rows(const int32_t* codes, int T, int groups, const uint16_t* codec_emb, const uint16_t* const* cp_emb,
+                           int H, uint16_t* out, int ldo, hipStream_t st) {
+    if (T <= 0) return;
+    hipLaunchKernelGGL(ref_embed_rows_kernel, dim3(T), dim3(256), 0, st, codes, T, groups, codec_emb, cp_emb, H, out, ldo);
+}
+void launch_build_decode_codes(const int32_t* ref, int Tref, const int32_t* gen, int F, int32_t* out, hipStream_t st) {
+    const int n = (Tref + F) * 16;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(build_decode_codes_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ref, Tref, gen, F, out);
+}
+void launch_f32_to_bf16(const float* x, uint16_t* out, int n, hipStream_t st) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((n + 255) / 256), dim3(256), 0, st, x, out, n);
 }
 void launch_copy_rows(const uint16_t* src, int lds, uint16_t* dst, int ldd, int rows, int dim, hipStream_t st) {
     if (rows <= 0) return;

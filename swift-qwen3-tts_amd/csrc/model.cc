@@ -92,9 +92,73 @@ void replace_all(std::string& s, const std::string& a, const std::string& b) {
 }
 bool contains(const std::string& s, const std::string& a) { return s.find(a) != std::string::npos; }
 bool starts_with(const std::string& s, const std::string& a) { return s.rfind(a, 0) == 0; }
+bool ends_with(const std::string& s, const std::string& a) {
+    return s.size() >= a.size() && s.compare(s.size() - a.size(), a.size(), a) == 0;
+}
 
-// Decoder half of sanitizeSpeechTokenizerWeights (Qwen3.swift:1498-1750). Encoder tensors are
-// left alone (voice-clone front end, SURVEY.md rows V1-V3, not built yet).
+// Encoder half of sanitizeSpeechTokenizerWeights (Qwen3.swift:1592-1700): key remaps of the SEANet / transformer /
+// quantizer trees and the conv-weight transposes to [out][k][in].
+void sanitize_encoder_entry(std::string& nk, HostTensor& t) {
+    static const std::pair<const char*, const char*> kSeanet[] = {  // :1517-1528
+        {"encoder.encoder.layers.0.", "encoder.encoder.init_conv1d."},
+        {"encoder.encoder.layers.1.", "encoder.encoder.layers.0.residuals.0."},
+        {"encoder.encoder.layers.3.", "encoder.encoder.layers.0.downsample."},
+        {"encoder.encoder.layers.4.", "encoder.encoder.layers.1.residuals.0."},
+        {"encoder.encoder.layers.6.", "encoder.encoder.layers.1.downsample."},
+        {"encoder.encoder.layers.7.", "encoder.encoder.layers.2.residuals.0."},
+        {"encoder.encoder.layers.9.", "encoder.encoder.layers.2.downsample."},
+        {"encoder.encoder.layers.10.", "encoder.encoder.layers.3.residuals.0."},
+        {"encoder.encoder.layers.12.", "encoder.encoder.layers.3.downsample."},
+        {"encoder.encoder.layers.14.", "encoder.encoder.final_conv1d."}};
+    const size_t nd = t.shape.size();
+    bool transposed = false;
+    for (auto& m : kSeanet)  // :1594-1599
+        if (starts_with(nk, m.first)) {
+            nk = std::string(m.second) + nk.substr(std::strlen(m.first));
+            break;
+        }
+    if (contains(nk, ".residuals.")) {  // :1603-1607
+        replace_all(nk, ".block.1.", ".block.0.");
+        replace_all(nk, ".block.3.", ".block.1.");
+    }
+    const bool is_seanet = starts_with(nk, "encoder.encoder.") && !contains(nk, "encoder_transformer") && !contains(nk, "quantizer") &&
+                           (contains(nk, ".conv.weight") || contains(nk, ".conv.bias"));  // :1612-1615
+    if (is_seanet) {
+        replace_all(nk, ".conv.weight", ".conv.conv.weight");
+        replace_all(nk, ".conv.bias", ".conv.conv.bias");
+        if (ends_with(nk, ".weight") && nd == 3) transposed = true;  // forced, :1622-1624
+    }
+    if (contains(nk, "encoder.encoder_transformer.layers.")) {  // :1629-1649
+        replace_all(nk, "encoder.encoder_transformer.layers.", "encoder.encoder_transformer.transformer.layers.");
+        replace_all(nk, ".input_layernorm.", ".norm1.");
+        replace_all(nk, ".post_attention_layernorm.", ".norm2.");
+        replace_all(nk, ".mlp.fc1.", ".gating.linear1.");
+        replace_all(nk, ".mlp.fc2.", ".gating.linear2.");
+        replace_all(nk, ".self_attn_layer_scale.", ".layer_scale_1.");
+        replace_all(nk, ".mlp_layer_scale.", ".layer_scale_2.");
+    }
+    if (starts_with(nk, "encoder.downsample.conv.") && !contains(nk, "encoder.downsample.conv.conv.")) {  // :1652-1659
+        const bool is_w = ends_with(nk, ".weight");
+        replace_all(nk, "encoder.downsample.conv.", "encoder.downsample.conv.conv.conv.");
+        if (is_w && nd == 3) transposed = true;
+    }
+    if (contains(nk, "encoder.quantizer.")) {  // :1664-1676
+        replace_all(nk, ".semantic_residual_vector_quantizer.", ".rvq_first.");
+        replace_all(nk, ".acoustic_residual_vector_quantizer.", ".rvq_rest.");
+        replace_all(nk, ".rvq_first.layers.", ".rvq_first.vq.layers.");
+        replace_all(nk, ".rvq_rest.layers.", ".rvq_rest.vq.layers.");
+    }
+    const bool was_seanet_w = starts_with(nk, "encoder.encoder.") && !contains(nk, "encoder_transformer") &&
+                              !contains(nk, "quantizer") && ends_with(nk, ".conv.conv.weight");  // :1682-1685
+    const bool is_proj = (contains(nk, "input_proj.weight") || contains(nk, "output_proj.weight")) && contains(nk, "quantizer");
+    if (is_proj && nd == 3) transposed = true;  // :1688-1692
+    // :1696-1700 re-derives the value from the ORIGINAL tensor: a transpose when the heuristic says "not MLX
+    // layout", otherwise whatever was decided above stays
+    if (contains(nk, "conv.weight") && nd == 3 && !is_proj && !was_seanet_w && !is_mlx_conv_layout(t.shape)) transposed = true;
+    if (transposed) t = permute3(t, 0, 2, 1);
+}
+
+// sanitizeSpeechTokenizerWeights (Qwen3.swift:1498-1750), decoder and encoder halves.
 std::map<std::string, HostTensor> sanitize_speech_tokenizer(const SafetensorsDir& st, bool with_data) {
     static const std::pair<const char*, const char*> kIndex[] = {
         {"decoder.decoder.0", "decoder.decoder.initConv"}, {"decoder.decoder.1", "decoder.decoder.block0"},
@@ -102,7 +166,8 @@ std::map<std::string, HostTensor> sanitize_speech_tokenizer(const SafetensorsDir
         {"decoder.decoder.4", "decoder.decoder.block3"},   {"decoder.decoder.5", "decoder.decoder.outSnake"},
         {"decoder.decoder.6", "decoder.decoder.outConv"}};
     std::map<std::string, HostTensor> out;
-    std::map<std::string, std::pair<const TensorView*, const TensorView*>> cb;  // base -> (usage, sum)
+    std::map<std::string, std::pair<const TensorView*, const TensorView*>> cb;   // base -> (usage, sum)
+    std::map<std::string, std::pair<const TensorView*, const TensorView*>> ecb;  // encoder codebooks
     for (auto& kv : st.all()) {
         const std::string& key = kv.first;
         const TensorView& tv = kv.second;
@@ -112,7 +177,25 @@ std::map<std::string, HostTensor> sanitize_speech_tokenizer(const SafetensorsDir
             else cb[base].second = &tv;
             continue;
         }
-        if (starts_with(key, "encoder.")) continue;
+        if (starts_with(key, "encoder.quantizer.") && contains(key, ".codebook.")) {  // :1546-1565
+            const size_t pos = key.find(".codebook.");
+            const std::string field = key.substr(pos + 10);
+            if (key.find(".codebook.", pos + 1) == std::string::npos && (field == "embed_sum" || field == "cluster_usage")) {
+                auto& e = ecb[key.substr(0, pos)];
+                (field == "cluster_usage" ? e.first : e.second) = &tv;
+                continue;
+            }
+            if (contains(key, ".initialized")) continue;
+        }
+        if (starts_with(key, "encoder.")) {
+            HostTensor t;
+            t.shape = tv.shape;
+            if (with_data) t.data = to_f32(tv);
+            std::string nk = key;
+            sanitize_encoder_entry(nk, t);
+            out[nk] = std::move(t);
+            continue;
+        }
         std::string nk = key;
         for (auto& m : kIndex) {  // :1573-1578
             std::string pre = std::string(m.first) + ".";
@@ -166,6 +249,40 @@ std::map<std::string, HostTensor> sanitize_speech_tokenizer(const SafetensorsDir
             }
         }
         out[kv.first + ".codebook.embed.weight"] = std::move(e);
+    }
+    for (auto& kv : ecb) {  // raw sums and usage under the Swift property names (:1727-1747)
+        if (!kv.second.first || !kv.second.second) continue;
+        std::string nb = kv.first;
+        replace_all(nb, ".semantic_residual_vector_quantizer.", ".rvq_first.");
+        replace_all(nb, ".acoustic_residual_vector_quantizer.", ".rvq_rest.");
+        replace_all(nb, ".rvq_first.layers.", ".rvq_first.vq.layers.");
+        replace_all(nb, ".rvq_rest.layers.", ".rvq_rest.vq.layers.");
+        HostTensor sum, usage;
+        sum.shape = kv.second.second->shape;
+        usage.shape = kv.second.first->shape;
+        if (with_data) {
+            sum.data = to_f32(*kv.second.second);
+            usage.data = to_f32(*kv.second.first);
+        }
+        out[nb + ".codebook.embeddingSum"] = std::move(sum);
+        out[nb + ".codebook.clusterUsage"] = std::move(usage);
+    }
+    return out;
+}
+
+// Qwen3TTSModel.sanitize (Qwen3.swift:1219-1243) for the only 3-d tensors of the main checkpoint: the speaker
+// encoder's Conv1d weights, PyTorch [out][in][k] -> MLX [out][k][in] unless the shape heuristic says otherwise.
+std::map<std::string, HostTensor> speaker_encoder_tensors(const SafetensorsDir& main, bool with_data) {
+    std::map<std::string, HostTensor> out;
+    for (auto& kv : main.all()) {
+        const std::string& key = kv.first;
+        if (!starts_with(key, "speaker_encoder.")) continue;
+        HostTensor t;
+        t.shape = kv.second.shape;
+        if (with_data) t.data = to_f32(kv.second);  // bf16 parameters meet fp32 activations: exact upcast
+        const bool is_conv_w = (contains(key, "conv") || contains(key, "speaker_encoder.fc")) && contains(key, "weight");
+        if (is_conv_w && t.shape.size() == 3 && !is_mlx_conv_layout(t.shape)) t = permute3(t, 0, 2, 1);
+        out[key] = std::move(t);
     }
     return out;
 }
@@ -592,11 +709,227 @@ void build_codec(Builder& b, const TMap& t, const CodecDecoderConfig& dc, CodecW
     c.out_b = b.put_f32(need(t, "decoder.decoder.outConv.conv.bias"));
 }
 
+// ---- voice-clone front end ------------------------------------------------------------------------
+// A strided causal conv (k = 2r, stride r) over channels-last data is a K = 2 causal conv over the
+// [T/r][r*C] view of the same buffer: W[n][2r][C] read as [n][2][r*C] needs no reordering.
+ConvW put_strided_conv(Builder& b, const TMap& t, const std::string& name, int stride) {
+    ConvW c = put_conv(b, t, name);
+    Q3_CHECK(c.K == 2 * stride, 6, "unexpected strided conv geometry: " + name);
+    c.K = 2;
+    c.Cin *= stride;
+    return c;
+}
+
+void build_codec_encoder(Builder& b, const TMap& t, const CodecEncoderConfig& ec, CodecEncW& e) {
+    Q3_CHECK(ec.num_residual_layers == 1 && ec.upsampling_ratios.size() == 4, 6,
+             "codec encoder: the reference's key mapping fixes one residual layer and four ratios (Qwen3.swift:1517-1528)");
+    Q3_CHECK(!ec.use_conv_shortcut && ec.use_causal_conv && ec.audio_channels == 1, 6, "codec encoder: unsupported SEANet variant");
+    Q3_CHECK(ec.num_attention_heads * 64 == ec.hidden_size && ec.num_key_value_heads == ec.num_attention_heads, 6,
+             "codec encoder: attention must be heads x 64 without grouped keys");
+    const std::string se = "encoder.encoder.";
+    const HostTensor& iw = need(t, se + "init_conv1d.conv.conv.weight");  // [C0][K][1]
+    Q3_CHECK(iw.shape.size() == 3 && iw.shape[2] == 1 && iw.shape[1] == ec.kernel_size, 6, "unexpected first SEANet conv");
+    e.init_C = int(iw.shape[0]);
+    e.init_K = int(iw.shape[1]);
+    e.init_w = b.put_f32(iw);
+    e.init_b = b.put_f32(need(t, se + "init_conv1d.conv.conv.bias"));
+    e.layers.resize(4);
+    int C = e.init_C;
+    for (int i = 0; i < 4; ++i) {
+        auto& L = e.layers[size_t(i)];
+        L.ratio = ec.upsampling_ratios[size_t(3 - i)];  // ratios reversed (SpeechTokenizerEncoder.swift:417)
+        L.C = C;
+        const std::string p = se + "layers." + std::to_string(i);
+        L.res1 = put_conv(b, t, p + ".residuals.0.block.0.conv.conv");
+        L.res2 = put_conv(b, t, p + ".residuals.0.block.1.conv.conv");
+        Q3_CHECK(L.res1.Cin == C && L.res1.K == ec.residual_kernel_size && L.res2.K == 1 && L.res2.N == C && L.res2.Cin == L.res1.N, 6,
+                 "unexpected SEANet residual block shapes");
+        L.down = put_strided_conv(b, t, p + ".downsample.conv.conv", L.ratio);
+        Q3_CHECK(L.down.Cin == C * L.ratio, 6, "unexpected SEANet downsample shape");
+        C = L.down.N;
+    }
+    e.final_conv = put_conv(b, t, se + "final_conv1d.conv.conv");
+    Q3_CHECK(e.final_conv.Cin == C && e.final_conv.N == ec.hidden_size, 6, "unexpected last SEANet conv");
+    e.hidden = ec.hidden_size;
+    e.heads = ec.num_attention_heads;
+    e.tlayers.resize(size_t(ec.num_hidden_layers));
+    for (int l = 0; l < ec.num_hidden_layers; ++l) {
+        auto& L = e.tlayers[size_t(l)];
+        const std::string p = "encoder.encoder_transformer.transformer.layers." + std::to_string(l);
+        L.ln1_w = b.put_f32(need(t, p + ".norm1.weight"));
+        L.ln1_b = b.put_f32(need(t, p + ".norm1.bias"));
+        L.ln2_w = b.put_f32(need(t, p + ".norm2.weight"));
+        L.ln2_b = b.put_f32(need(t, p + ".norm2.bias"));
+        L.qkv = put_linear_concat(b, t, {p + ".self_attn.q_proj", p + ".self_attn.k_proj", p + ".self_attn.v_proj"});
+        L.o = put_conv(b, t, p + ".self_attn.o_proj");
+        L.o.scale = b.put_f32(need(t, p + ".layer_scale_1.scale"));
+        L.fc1 = put_conv(b, t, p + ".gating.linear1");
+        L.fc2 = put_conv(b, t, p + ".gating.linear2");
+        L.fc2.scale = b.put_f32(need(t, p + ".layer_scale_2.scale"));
+    }
+    {  // MLXNN.RoPE(dimensions: 64, traditional: false, base) at offset 0 (SpeechTokenizerEncoder.swift:494): fp32 tables
+       // of double-precision angles, as in the oracle
+        e.max_T = ec.max_position_embeddings;
+        HostTensor cs, sn;
+        cs.shape = sn.shape = {e.max_T, 32};
+        if (!b.dry && b.fill) {
+            cs.data.resize(size_t(e.max_T) * 32);
+            sn.data.resize(size_t(e.max_T) * 32);
+            for (int i = 0; i < 32; ++i) {
+                const double inv = std::pow(double(ec.rope_theta), -double(i) / 32.0);
+                for (int p = 0; p < e.max_T; ++p) {
+                    cs.data[size_t(p) * 32 + i] = float(std::cos(double(p) * inv));
+                    sn.data[size_t(p) * 32 + i] = float(std::sin(double(p) * inv));
+                }
+            }
+        }
+        e.rope_cos = b.put_f32(cs);
+        e.rope_sin = b.put_f32(sn);
+    }
+    e.ds = ec.downsample_stride();
+    e.down = put_strided_conv(b, t, "encoder.downsample.conv.conv.conv", e.ds);
+    Q3_CHECK(e.down.N == ec.hidden_size && e.down.bias == nullptr, 6, "unexpected encoder downsample conv");
+    {  // the two 1x1 input projections side by side (EncoderConv1dProj, :889-903)
+        const HostTensor& w1 = need(t, "encoder.quantizer.rvq_first.input_proj.weight");  // [dim][1][hidden]
+        const HostTensor& w2 = need(t, "encoder.quantizer.rvq_rest.input_proj.weight");
+        Q3_CHECK(w1.shape.size() == 3 && w1.shape[1] == 1 && w1.shape == w2.shape && w1.shape[2] == ec.hidden_size, 6,
+                 "unexpected quantizer input projection");
+        e.dim = int(w1.shape[0]);
+        HostTensor cat;
+        cat.shape = {2 * e.dim, 1, ec.hidden_size};
+        if (!w1.data.empty()) {
+            cat.data = w1.data;
+            cat.data.insert(cat.data.end(), w2.data.begin(), w2.data.end());
+        }
+        e.rvq_in.N = 2 * e.dim;
+        e.rvq_in.K = 1;
+        e.rvq_in.Cin = ec.hidden_size;
+        e.rvq_in.w = b.put_f32(cat);
+    }
+    // only the first 16 code rows reach the caller (validNumQuantizers, :957, :1055): 1 semantic + 15 acoustic
+    e.n_layers = std::min(16, ec.num_quantizers);
+    e.bins = ec.codebook_size;
+    e.cb.resize(size_t(e.n_layers));
+    e.c2.resize(size_t(e.n_layers));
+    for (int j = 0; j < e.n_layers; ++j) {
+        const std::string p = "encoder.quantizer." + (j == 0 ? std::string("rvq_first.vq.layers.0") : "rvq_rest.vq.layers." + std::to_string(j - 1)) +
+                              ".codebook";
+        const HostTensor& sum = need(t, p + ".embeddingSum");
+        const HostTensor& usage = need(t, p + ".clusterUsage");
+        Q3_CHECK(sum.shape.size() == 2 && sum.shape[0] == e.bins && sum.shape[1] == e.dim && usage.numel() == e.bins, 6,
+                 "unexpected encoder codebook shape");
+        HostTensor emb, c2;
+        emb.shape = sum.shape;
+        c2.shape = {e.bins};
+        if (!sum.data.empty()) {  // EncoderEuclideanCodebook.updateInPlace (:738-743)
+            emb.data.resize(sum.data.size());
+            c2.data.resize(size_t(e.bins));
+            for (int r = 0; r < e.bins; ++r) {
+                const float u = std::max(usage.data[size_t(r)], 1e-5f);
+                double acc = 0.0;
+                for (int d = 0; d < e.dim; ++d) {
+                    const float v = sum.data[size_t(r) * e.dim + d] / u;
+                    emb.data[size_t(r) * e.dim + d] = v;
+                    const float sq = v * v;
+                    acc += double(sq);
+                }
+                c2.data[size_t(r)] = float(acc) / 2.0f;
+            }
+        }
+        e.cb[size_t(j)] = b.put_f32(emb);
+        e.c2[size_t(j)] = b.put_f32(c2);
+    }
+    e.cb_dev = b.put_side<const float*>(e.cb.data(), e.cb.size());
+    e.c2_dev = b.put_side<const float*>(e.c2.data(), e.c2.size());
+}
+
+// melFilterbank (SpeakerEncoder.swift:493-550), Float arithmetic as in the Swift source
+std::vector<float> mel_filterbank(int nfft, int n_mels, int sr, float fmin, float fmax) {
+    const int nfreq = nfft / 2 + 1;
+    const float mel_min = 2595.0f * log10f(1.0f + fmin / 700.0f), mel_max = 2595.0f * log10f(1.0f + fmax / 700.0f);
+    std::vector<int> bins((size_t)(n_mels + 2));
+    for (int i = 0; i <= n_mels + 1; ++i) {
+        const float mel = mel_min + float(i) * (mel_max - mel_min) / float(n_mels + 1);
+        const float hz = 700.0f * (powf(10.0f, mel / 2595.0f) - 1.0f);
+        bins[size_t(i)] = int(floorf(float(nfft + 1) * hz / float(sr)));
+    }
+    std::vector<float> fb((size_t)(nfreq) * n_mels, 0.f);
+    for (int m = 0; m < n_mels; ++m) {
+        const int left = bins[size_t(m)], center = bins[size_t(m + 1)], right = bins[size_t(m + 2)];
+        for (int k = left; k < center; ++k)
+            if (k < nfreq && center > left) fb[size_t(k) * n_mels + m] = float(k - left) / float(center - left);
+        for (int k = center; k < right; ++k)
+            if (k < nfreq && right > center) fb[size_t(k) * n_mels + m] = float(right - k) / float(right - center);
+    }
+    return fb;
+}
+
+void build_speaker_encoder(Builder& b, const TMap& t, const SpeakerEncoderConfig& sc, SpeakerEncW& s) {
+    Q3_CHECK(sc.enc_channels.size() == 5 && sc.enc_kernel_sizes.size() == 5 && sc.enc_dilations.size() == 5, 6,
+             "speaker encoder: five stages expected (SpeakerEncoder.swift:283-297)");
+    Q3_CHECK(sc.mel_dim == 128, 6, "speaker encoder: mel_dim must be 128 (Qwen3.swift:232-241 hard-codes it)");
+    s.n_fft = 1024; s.hop = 256; s.nfreq = 513; s.n_mels = 128;  // extractSpeakerEmbedding, Qwen3.swift:232-241
+    {  // STFT as a GEMM: row k = Hann[n] * cos(2 pi k n / N), row nfreq + k = Hann[n] * sin(...); |X|^2 ignores the sign.
+       // Hann window with the (N - 1) denominator (SpeakerEncoder.swift:459-462).
+        const int N = s.n_fft, rows = int(align_up(size_t(2 * s.nfreq), 4));
+        HostTensor w;
+        w.shape = {rows, 1, N};
+        if (!b.dry && b.fill) {
+            w.data.assign(size_t(rows) * N, 0.f);
+            std::vector<float> win((size_t)(N));
+            for (int n = 0; n < N; ++n) win[size_t(n)] = 0.5f * (1.0f - cosf(2.0f * 3.14159265358979323846f * float(n) / float(N - 1)));
+            for (int k = 0; k < s.nfreq; ++k)
+                for (int n = 0; n < N; ++n) {
+                    const double ang = 2.0 * 3.14159265358979323846 * double((int64_t(k) * n) % N) / double(N);
+                    w.data[size_t(k) * N + n] = float(double(win[size_t(n)]) * std::cos(ang));
+                    w.data[size_t(s.nfreq + k) * N + n] = float(double(win[size_t(n)]) * std::sin(ang));
+                }
+        }
+        s.dft.N = rows; s.dft.K = 1; s.dft.Cin = N;
+        s.dft.w = b.put_f32(w);
+    }
+    {
+        HostTensor fb;
+        fb.shape = {s.nfreq, s.n_mels};
+        if (!b.dry && b.fill) fb.data = mel_filterbank(s.n_fft, s.n_mels, 24000, 0.f, 12000.f);
+        s.mel_fb = b.put_f32(fb);
+    }
+    const auto& ch = sc.enc_channels;
+    const auto& ks = sc.enc_kernel_sizes;
+    const auto& dl = sc.enc_dilations;
+    s.scale = sc.enc_res2net_scale;
+    s.enc_dim = sc.enc_dim;
+    s.b0 = put_conv(b, t, "speaker_encoder.blocks.0.conv", dl[0]);
+    Q3_CHECK(s.b0.K == ks[0] && s.b0.Cin == sc.mel_dim && s.b0.N == ch[0], 6, "unexpected speaker encoder input conv");
+    for (int bi = 1; bi <= 3; ++bi) {
+        auto& B = s.blocks[bi - 1];
+        const std::string p = "speaker_encoder.blocks." + std::to_string(bi);
+        B.C = ch[size_t(bi)];
+        Q3_CHECK(B.C == ch[size_t(bi - 1)] && B.C % (4 * s.scale) == 0, 6,
+                 "speaker encoder: SE-Res2Net blocks need equal widths (residual add) divisible by 4*scale");
+        B.tdnn1 = put_conv(b, t, p + ".tdnn1.conv");
+        for (int j = 0; j < s.scale - 1; ++j) {
+            B.res.push_back(put_conv(b, t, p + ".res2net_block.blocks." + std::to_string(j) + ".conv", dl[size_t(bi)]));
+            Q3_CHECK(B.res.back().K == ks[size_t(bi)] && B.res.back().Cin == B.C / s.scale, 6, "unexpected Res2Net conv shape");
+        }
+        B.tdnn2 = put_conv(b, t, p + ".tdnn2.conv");
+        B.se1 = put_conv(b, t, p + ".se_block.conv1");
+        B.se2 = put_conv(b, t, p + ".se_block.conv2");
+    }
+    s.mfa = put_conv(b, t, "speaker_encoder.mfa.conv", dl[4]);
+    Q3_CHECK(s.mfa.K == ks[4] && s.mfa.Cin == ch[1] + ch[2] + ch[3] && s.mfa.N == ch[4], 6, "unexpected speaker encoder MFA conv");
+    s.asp_tdnn = put_conv(b, t, "speaker_encoder.asp.tdnn.conv");
+    s.asp_conv = put_conv(b, t, "speaker_encoder.asp.conv");
+    s.fc = put_conv(b, t, "speaker_encoder.fc");
+    Q3_CHECK(s.asp_tdnn.Cin == 3 * ch[4] && s.asp_conv.N == ch[4] && s.fc.Cin == 2 * ch[4] && s.fc.N == sc.enc_dim, 6,
+             "unexpected speaker encoder pooling shapes");
+}
+
 int64_t linear_bytes(const LinearW& L) {  // weight bytes streamed per use: bf16, or 4 bit + {scale,bias} per 64
     return L.sb ? int64_t(L.N) * L.K / 2 + int64_t(L.N) * (L.K / 64) * 4 : int64_t(L.N) * L.K * 2;
 }
 
-void build_all(Builder& b, Model& m, const SafetensorsDir& main, const TMap* codec_t, const LoadOptions& opt) {
+void build_all(Builder& b, Model& m, const SafetensorsDir& main, const TMap* codec_t, const TMap* spk_t, const LoadOptions& opt) {
     const ModelConfig& cfg = m.cfg;
     const TalkerConfig& t = cfg.talker;
     MainTensors mt{main};
@@ -643,6 +976,15 @@ void build_all(Builder& b, Model& m, const SafetensorsDir& main, const TMap* cod
     if (codec_t) {
         build_codec(b, *codec_t, cfg.codec, m.codec);
         m.has_codec = true;
+        if (cfg.has_codec_encoder) {  // SpeechTokenizer.swift:808-812
+            build_codec_encoder(b, *codec_t, cfg.codec_enc, m.codec_enc);
+            m.has_codec_encoder = true;
+        }
+    }
+    if (spk_t) {  // Qwen3.swift:55-57
+        Q3_CHECK(cfg.speaker.enc_dim == H, 6, "speaker encoder: enc_dim must equal the talker hidden size (Qwen3.swift:553-558)");
+        build_speaker_encoder(b, *spk_t, cfg.speaker, m.speaker);
+        m.has_speaker_encoder = true;
     }
     // distinct weight bytes of one frame step
     int64_t wb = linear_bytes(m.codec_head);
@@ -682,12 +1024,15 @@ std::unique_ptr<Model> load_model(const std::string& dir, const LoadOptions& opt
         st.open_dir(st_dir);
         codec_t = sanitize_speech_tokenizer(st, !opt.skip_tensor_data);
     }
+    TMap spk_t;
+    if (m->cfg.has_speaker_encoder) spk_t = speaker_encoder_tensors(main, !opt.skip_tensor_data);
+    const TMap* spk_p = m->cfg.has_speaker_encoder ? &spk_t : nullptr;
     Builder dry;
     dry.dry = true;
     {
         Model scratch;
         scratch.cfg = m->cfg;
-        build_all(dry, scratch, main, have_codec ? &codec_t : nullptr, opt);
+        build_all(dry, scratch, main, have_codec ? &codec_t : nullptr, spk_p, opt);
     }
     m->arena_bytes = align_up(dry.off, 256);
     Q3_HIP(hipMalloc(reinterpret_cast<void**>(&m->arena), m->arena_bytes));
@@ -700,7 +1045,7 @@ std::unique_ptr<Model> load_model(const std::string& dir, const LoadOptions& opt
         Q3_HIP(hipMalloc(reinterpret_cast<void**>(&real.staging), dry.max_staging));
     }
     try {
-        build_all(real, *m, main, have_codec ? &codec_t : nullptr, opt);
+        build_all(real, *m, main, have_codec ? &codec_t : nullptr, spk_p, opt);
     } catch (...) {
         if (real.staging) (void)hipFree(real.staging);
         throw;

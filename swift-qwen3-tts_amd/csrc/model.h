@@ -101,6 +101,52 @@ struct CodecW {
     int out_C = 0;
 };
 
+// Codec encoder (SpeechTokenizerEncoder.swift): SEANet -> causal transformer -> stride-2 conv -> split RVQ search.
+struct CodecEncW {
+    const float* init_w = nullptr;  // [C0][K] (one input channel)
+    const float* init_b = nullptr;
+    int init_C = 0, init_K = 0;
+    struct Layer {
+        ConvW res1, res2;  // k3 C->C/2, k1 C/2->C (ELU before each, skip connection)
+        ConvW down;        // k=2r stride r as a K=2 causal conv over the [T/r][r*C] view (same bytes as [N][2r][C])
+        int ratio = 1, C = 0;
+    };
+    std::vector<Layer> layers;
+    ConvW final_conv;
+    struct TLayer {
+        const float *ln1_w = nullptr, *ln1_b = nullptr, *ln2_w = nullptr, *ln2_b = nullptr;
+        ConvW qkv, o, fc1, fc2;  // o / fc2 carry the LayerScale
+    };
+    std::vector<TLayer> tlayers;
+    int heads = 0, hidden = 0;
+    const float* rope_cos = nullptr;  // [max_T][32]
+    const float* rope_sin = nullptr;
+    int max_T = 0;
+    ConvW down;  // stride ds, same view trick
+    int ds = 2;
+    ConvW rvq_in;  // rows: rvq_first.input_proj | rvq_rest.input_proj
+    int dim = 0, bins = 0, n_layers = 0;  // layers that reach the output (16: 1 semantic + 15 acoustic)
+    std::vector<const float*> cb, c2;
+    const float* const* cb_dev = nullptr;
+    const float* const* c2_dev = nullptr;
+};
+
+// ECAPA-TDNN speaker encoder + log-mel front end (SpeakerEncoder.swift)
+struct SpeakerEncW {
+    ConvW dft;                    // windowed DFT basis [2*nfreq (+pad)][1][n_fft]: Hann * cos | Hann * sin
+    const float* mel_fb = nullptr;  // [nfreq][n_mels]
+    int n_fft = 1024, hop = 256, nfreq = 513, n_mels = 128;
+    ConvW b0;
+    struct Block {
+        ConvW tdnn1, tdnn2, se1, se2;
+        std::vector<ConvW> res;  // scale-1 convs on C/scale channels
+        int C = 0;
+    };
+    Block blocks[3];
+    ConvW mfa, asp_tdnn, asp_conv, fc;
+    int scale = 8, enc_dim = 0;
+};
+
 struct Model {
     ModelConfig cfg;
     int device = 0;
@@ -119,6 +165,10 @@ struct Model {
     const uint16_t* const* cp_emb_dev = nullptr;
     bool has_codec = false;
     CodecW codec;
+    bool has_codec_encoder = false;    // Qwen3TTSSpeechTokenizer.hasEncoder (SpeechTokenizer.swift:816-818)
+    CodecEncW codec_enc;
+    bool has_speaker_encoder = false;  // Qwen3TTSModel.hasVoiceCloning (Qwen3.swift:61-63)
+    SpeakerEncW speaker;
     int64_t step_weight_bytes = 0;  // distinct weight bytes read by one frame step (roofline)
     std::vector<void*> side_allocs; // pointer tables (absolute addresses; not part of the arena)
 

@@ -28,13 +28,15 @@ class ModelInfo(C.Structure):
                 ("text_vocab_size", C.c_int32), ("num_code_groups", C.c_int32),
                 ("cp_hidden_size", C.c_int32), ("cp_num_layers", C.c_int32), ("cp_vocab_size", C.c_int32),
                 ("codec_eos_token_id", C.c_int32), ("samples_per_frame", C.c_int32), ("max_batch", C.c_int32),
-                ("weight_bytes", C.c_int64)]
+                ("weight_bytes", C.c_int64), ("speaker_embedding_dim", C.c_int32)]
 
 
 class Request(C.Structure):
     _fields_ = [("text_ids", i32p), ("n_text_ids", C.c_int32), ("instruct_ids", i32p),
                 ("n_instruct_ids", C.c_int32), ("target_token_count", C.c_int32), ("speaker", C.c_char_p),
-                ("language", C.c_char_p), ("max_tokens", C.c_int32)]
+                ("language", C.c_char_p), ("max_tokens", C.c_int32),
+                ("ref_audio", f32p), ("n_ref_samples", C.c_int64), ("ref_text_ids", i32p),
+                ("n_ref_text_ids", C.c_int32)]
 
 
 class Sampling(C.Structure):
@@ -63,7 +65,8 @@ class Result(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("prefill_ms", C.c_double), ("decode_ms", C.c_double), ("codec_ms", C.c_double),
-                ("frame_steps", C.c_int32), ("rows", C.c_int32), ("kv_bytes_read", C.c_int64)]
+                ("frame_steps", C.c_int32), ("rows", C.c_int32), ("kv_bytes_read", C.c_int64),
+                ("frontend_ms", C.c_double)]
 
 
 _lib = None
@@ -97,6 +100,10 @@ def lib() -> C.CDLL:
     L.q3tts_result_free.restype = None
     L.q3tts_codec_decode.argtypes = [vp, i32p, i32p, C.c_int32, C.c_int32, f32p, C.POINTER(C.c_int64)]
     L.q3tts_last_timing.argtypes = [vp, C.POINTER(Timing)]
+    L.q3tts_codec_encode.argtypes = [vp, f32p, C.c_int64, i32p, C.c_int32, i32p]
+    L.q3tts_codec_encoded_frames.argtypes = [vp, C.c_int64]
+    L.q3tts_speaker_embedding.argtypes = [vp, f32p, C.c_int64, C.c_int32, f32p, C.c_int32]
+    L.q3tts_debug_frontend_stage.argtypes = [vp, f32p, C.c_int64, C.c_char_p, f32p, C.c_int64, i32p, i32p]
     L.q3tts_debug_prepare_inputs.argtypes = [vp, C.POINTER(Request), u16p, C.c_int32, i32p, u16p, C.c_int32,
                                              i32p, u16p]
     L.q3tts_debug_generate_forced.argtypes = [vp, C.POINTER(Request), C.c_int32, C.POINTER(Sampling), i32p,

@@ -44,6 +44,10 @@ class GenerationRequest:
     speaker: Optional[str] = None
     language: str = "auto"
     max_tokens: int = 2048
+    # voice clone (generateVoiceClone, Qwen3.swift:1009-1020): 24 kHz mono float32 + tokens of
+    # "<|im_start|>assistant\n{referenceText}<|im_end|>\n"
+    ref_audio: Optional[np.ndarray] = None
+    ref_text_ids: Optional[Sequence[int]] = None
 
 
 @dataclass
@@ -151,6 +155,14 @@ class Qwen3TTSModel:
             arr[i].speaker = r.speaker.encode() if r.speaker is not None else None
             arr[i].language = (r.language or "auto").encode()
             arr[i].max_tokens = int(r.max_tokens)
+            if r.ref_audio is not None:
+                ra = np.ascontiguousarray(np.asarray(r.ref_audio, np.float32).reshape(-1))
+                rt = np.ascontiguousarray(r.ref_text_ids if r.ref_text_ids is not None else [], np.int32)
+                keep += [ra, rt]
+                arr[i].ref_audio = ra.ctypes.data_as(L.f32p)
+                arr[i].n_ref_samples = ra.size
+                arr[i].ref_text_ids = rt.ctypes.data_as(L.i32p)
+                arr[i].n_ref_text_ids = rt.size
         return arr, keep
 
     @staticmethod
@@ -241,7 +253,54 @@ class Qwen3TTSModel:
             raise Qwen3TTSError(res[0].status, "Generation failed: No tokens generated")
         yield from events
 
+    def generate_voice_clone(self, text: Optional[str] = None, reference_audio: Optional[np.ndarray] = None,
+                             reference_text: Optional[str] = None, language: str = "auto", temperature: float = 0.9,
+                             top_k: int = 50, top_p: float = 1.0, repetition_penalty: float = 1.5,
+                             max_tokens: int = 2048, *, seed: int = 0, text_ids: Optional[Sequence[int]] = None,
+                             ref_text_ids: Optional[Sequence[int]] = None,
+                             target_token_count: Optional[int] = None) -> np.ndarray:
+        """generateVoiceClone(text:referenceAudio:referenceText:language:...) (Qwen3.swift:1009-1203): repetition
+        penalty defaults to 1.5 on this path. Returns the audio of `text` only."""
+        if text_ids is None:
+            if self.tokenizer is None:
+                raise Qwen3TTSError(1, "Model not initialized: Tokenizer not loaded")  # Qwen3.swift:424-426
+            t = chat_template_ids(self.tokenizer, text)
+            text_ids, target_token_count = t["text_ids"], t["target_token_count"]
+            ref_text_ids = self.tokenizer(f"<|im_start|>assistant\n{reference_text}<|im_end|>\n")
+        req = GenerationRequest(text_ids, int(target_token_count or 0), None, None, language, max_tokens,
+                                ref_audio=reference_audio, ref_text_ids=ref_text_ids)
+        r = self.generate_batch([req], temperature, top_k, top_p, repetition_penalty, seed)[0]
+        if r.status != 0:
+            raise Qwen3TTSError(r.status, "Generation failed: No tokens generated")
+        return r.audio
+
     # -- codec only ------------------------------------------------------------------------------
+    def codec_encode(self, audio: np.ndarray) -> np.ndarray:
+        """Qwen3TTSSpeechTokenizer.encode (SpeechTokenizer.swift:841-846): waveform [S] -> codes [16][T] int32."""
+        a = np.ascontiguousarray(np.asarray(audio, np.float32).reshape(-1))
+        cap = max(1, int(self._lib.q3tts_codec_encoded_frames(self._h, a.size)))
+        codes = np.zeros((16, cap), np.int32)
+        n = C.c_int32(0)
+        self._check(self._lib.q3tts_codec_encode(self._h, a.ctypes.data_as(L.f32p), a.size, codes.ctypes.data_as(L.i32p),
+                                                 cap, C.byref(n)))
+        return codes.reshape(-1)[: 16 * n.value].reshape(16, n.value)
+
+    def extract_speaker_embedding(self, audio: np.ndarray, sample_rate: int = 24000) -> np.ndarray:
+        """extractSpeakerEmbedding (Qwen3.swift:222-249) -> float32 [enc_dim]."""
+        a = np.ascontiguousarray(np.asarray(audio, np.float32).reshape(-1))
+        out = np.zeros(max(1, self.info.speaker_embedding_dim), np.float32)
+        self._check(self._lib.q3tts_speaker_embedding(self._h, a.ctypes.data_as(L.f32p), a.size, sample_rate,
+                                                      out.ctypes.data_as(L.f32p), out.size))
+        return out
+
+    def debug_frontend_stage(self, audio: np.ndarray, stage: str, cap_floats: int = 1 << 26) -> np.ndarray:
+        a = np.ascontiguousarray(np.asarray(audio, np.float32).reshape(-1))
+        out = np.zeros(cap_floats, np.float32)
+        T, Cc = C.c_int32(0), C.c_int32(0)
+        self._check(self._lib.q3tts_debug_frontend_stage(self._h, a.ctypes.data_as(L.f32p), a.size, stage.encode(),
+                                                         out.ctypes.data_as(L.f32p), out.size, C.byref(T), C.byref(Cc)))
+        return out[: T.value * Cc.value].reshape(T.value, Cc.value).copy()
+
     def codec_decode(self, codes: np.ndarray, n_frames: Optional[Sequence[int]] = None):
         """Qwen3TTSSpeechTokenizer.decode (SpeechTokenizer.swift:823-836). codes [B][F][16] int32."""
         codes = np.ascontiguousarray(codes, np.int32)

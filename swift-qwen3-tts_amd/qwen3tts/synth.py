@@ -79,6 +79,38 @@ def _codec_cfg(tiny: bool) -> dict:
                 layer_scale_initial_scale=0.01)
 
 
+def _encoder_cfg(tiny: bool) -> dict:
+    """speech_tokenizer encoder_config (Config.swift:476-504). The tiny variant keeps the 1920-sample hop
+    (ratios 8*6*5*4, stride-2 downsample) and head_dim 64."""
+    if tiny:
+        return dict(frame_rate=12.5, audio_channels=1, codebook_dim=64, codebook_size=128, compress=2,
+                    dilation_growth_rate=2, head_dim=64, hidden_size=128, intermediate_size=256, kernel_size=7,
+                    last_kernel_size=3, layer_scale_initial_scale=0.01, max_position_embeddings=8000,
+                    num_attention_heads=2, num_filters=8, num_hidden_layers=2, num_key_value_heads=2,
+                    num_quantizers=32, num_residual_layers=1, residual_kernel_size=3, rope_theta=10000.0,
+                    sampling_rate=24000, sliding_window=250, upsampling_ratios=[8, 6, 5, 4], use_causal_conv=True,
+                    use_conv_shortcut=False)
+    return dict(frame_rate=12.5, audio_channels=1, codebook_dim=256, codebook_size=2048, compress=2,
+                dilation_growth_rate=2, head_dim=64, hidden_size=512, intermediate_size=2048, kernel_size=7,
+                last_kernel_size=3, layer_scale_initial_scale=0.01, max_position_embeddings=8000,
+                num_attention_heads=8, num_filters=64, num_hidden_layers=8, num_key_value_heads=8,
+                num_quantizers=32, num_residual_layers=1, residual_kernel_size=3, rope_theta=10000.0,
+                sampling_rate=24000, sliding_window=250, upsampling_ratios=[8, 6, 5, 4], use_causal_conv=True,
+                use_conv_shortcut=False)
+
+
+def _speaker_cfg(enc_dim: int, tiny: bool) -> dict:
+    """speaker_encoder_config (Config.swift:80-91). mel_dim stays 128: extractSpeakerEmbedding hard-codes it
+    (Qwen3.swift:232-241). Tiny: 1x1 conv widths stay > 64 for the layout heuristic (Qwen3.swift:1246-1260)."""
+    if tiny:
+        return dict(mel_dim=128, enc_dim=enc_dim, enc_channels=[128, 128, 128, 128, 384], enc_kernel_sizes=[5, 3, 3, 3, 1],
+                    enc_dilations=[1, 2, 3, 4, 1], enc_attention_channels=96, enc_res2net_scale=8, enc_se_channels=96,
+                    sample_rate=24000)
+    return dict(mel_dim=128, enc_dim=enc_dim, enc_channels=[512, 512, 512, 512, 1536], enc_kernel_sizes=[5, 3, 3, 3, 1],
+                enc_dilations=[1, 2, 3, 4, 1], enc_attention_channels=128, enc_res2net_scale=8, enc_se_channels=128,
+                sample_rate=24000)
+
+
 def preset(name: str) -> dict:
     """Returns {"config": <config.json dict>, "speech_tokenizer": <speech_tokenizer/config.json>}.
 
@@ -103,6 +135,16 @@ def preset(name: str) -> dict:
                    tts_pad_token_id=1010, tts_bos_token_id=1011, tts_eos_token_id=1012,
                    sample_rate=24000)
         return {"config": cfg, "speech_tokenizer": {"decoder_config": _codec_cfg(True)}}
+    if name in ("tiny-base", "0.6b-base", "1.7b-base"):
+        # Base checkpoints (voice clone, BASELINE config 4): tts_model_type "base", a speaker encoder in the main
+        # file and an encoder half in speech_tokenizer/ (Qwen3.swift:55-57, 1210-1214; SpeechTokenizer.swift:808-812)
+        tiny = name == "tiny-base"
+        p = preset("tiny-b" if tiny else name[:-5])
+        p["config"]["tts_model_type"] = "base"
+        p["config"]["speaker_encoder_config"] = _speaker_cfg(p["config"]["talker_config"]["hidden_size"], tiny)
+        p["config"]["talker_config"].setdefault("spk_id", spk)
+        p["speech_tokenizer"]["encoder_config"] = _encoder_cfg(tiny)
+        return p
     if name == "tiny-q":
         # like BASELINE config 5 in miniature: MLX affine int4 (group 64) Linears + pruned text vocabulary with a
         # token map (docs/paper.tex:160-178, 232-256); embeddings stay bf16 (no `.scales` keys)
@@ -342,6 +384,94 @@ def codec_tensors(dc: dict, g: _Gen, std: float = 0.02) -> Dict[str, Tuple[str, 
     return out
 
 
+def encoder_tensors(ec: dict, g: _Gen) -> Dict[str, Tuple[str, np.ndarray]]:
+    """speech_tokenizer encoder half with the upstream (HF Mimi style) key names and PyTorch layouts that the
+    sanitiser's encoder branch consumes (Qwen3.swift:1517-1528, 1546-1565, 1592-1700). Fan-in scaled weights so
+    the waveform still drives the codes after ~20 layers."""
+    out: Dict[str, Tuple[str, np.ndarray]] = {}
+    nf, hs = ec["num_filters"], ec["hidden_size"]
+
+    def conv(prefix, cout, cin, k, bias=True):  # torch Conv1d [out, in, k]
+        out[prefix + ".weight"] = _f32(g.normal((cout, cin, k), 1.0 / np.sqrt(cin * k)))
+        if bias:
+            out[prefix + ".bias"] = _f32(g.normal((cout,), 0.02))
+
+    conv("encoder.encoder.layers.0.conv", nf, ec["audio_channels"], ec["kernel_size"])
+    mult, idx = 1, 1
+    for ratio in reversed(ec["upsampling_ratios"]):  # layer indices 1,3 | 4,6 | 7,9 | 10,12 (ELUs in between)
+        c = mult * nf
+        conv(f"encoder.encoder.layers.{idx}.block.1.conv", c // ec["compress"], c, ec["residual_kernel_size"])
+        conv(f"encoder.encoder.layers.{idx}.block.3.conv", c, c // ec["compress"], 1)
+        conv(f"encoder.encoder.layers.{idx + 2}.conv", 2 * c, c, 2 * ratio)
+        mult *= 2
+        idx += 3
+    conv("encoder.encoder.layers.14.conv", hs, mult * nf, ec["last_kernel_size"])
+    nh = ec["num_attention_heads"]
+    hd = hs // nh
+    for l in range(ec["num_hidden_layers"]):
+        p = f"encoder.encoder_transformer.layers.{l}"
+        for nm, n, k in (("q_proj", nh * hd, hs), ("k_proj", ec["num_key_value_heads"] * hd, hs),
+                         ("v_proj", ec["num_key_value_heads"] * hd, hs), ("o_proj", hs, nh * hd)):
+            out[f"{p}.self_attn.{nm}.weight"] = _f32(g.normal((n, k), 1.0 / np.sqrt(k)))
+        out[p + ".mlp.fc1.weight"] = _f32(g.normal((ec["intermediate_size"], hs), 1.0 / np.sqrt(hs)))
+        out[p + ".mlp.fc2.weight"] = _f32(g.normal((hs, ec["intermediate_size"]), 1.0 / np.sqrt(ec["intermediate_size"])))
+        for nm in ("input_layernorm", "post_attention_layernorm"):
+            out[f"{p}.{nm}.weight"] = _f32(g.normal((hs,), 0.05, 1.0))
+            out[f"{p}.{nm}.bias"] = _f32(g.normal((hs,), 0.02))
+        out[p + ".self_attn_layer_scale.scale"] = _f32(g.normal((hs,), 0.002, ec["layer_scale_initial_scale"]))
+        out[p + ".mlp_layer_scale.scale"] = _f32(g.normal((hs,), 0.002, ec["layer_scale_initial_scale"]))
+    enc_rate = ec["sampling_rate"] / int(np.prod(ec["upsampling_ratios"]))
+    ds = int(enc_rate / ec["frame_rate"])
+    conv("encoder.downsample.conv", hs, hs, 2 * ds, bias=False)
+    cd, bins = ec["codebook_dim"], ec["codebook_size"]
+    for nm, nq in (("semantic_residual_vector_quantizer", 1), ("acoustic_residual_vector_quantizer", ec["num_quantizers"] - 1)):
+        q = f"encoder.quantizer.{nm}"
+        out[q + ".input_proj.weight"] = _f32(g.normal((cd, hs, 1), 1.0 / np.sqrt(hs)))
+        out[q + ".output_proj.weight"] = _f32(g.normal((hs, cd, 1), 1.0 / np.sqrt(cd)))
+        for j in range(nq):
+            # residual energy shrinks layer by layer; scale the codebooks with it so later layers stay informative
+            emb = g.normal((bins, cd), 1.0) * np.float32(0.2 * 0.8 ** j)
+            usage = g.uniform((bins,), 0.5, 2.0)
+            usage[::11] = 0.0  # the max(usage, 1e-5) branch (SpeechTokenizerEncoder.swift:739)
+            out[f"{q}.layers.{j}.codebook.cluster_usage"] = _f32(usage)
+            out[f"{q}.layers.{j}.codebook.embed_sum"] = _f32(emb * np.maximum(usage, 1e-5)[:, None])
+            out[f"{q}.layers.{j}.codebook.initialized"] = _f32(np.ones((1,), np.float32))
+    return out
+
+
+def speaker_encoder_tensors(sc: dict, g: _Gen) -> Dict[str, Tuple[str, np.ndarray]]:
+    """ECAPA-TDNN parameters in the main checkpoint: bf16, PyTorch Conv1d layout [out, in, k]; Qwen3TTSModel.sanitize
+    transposes them (Qwen3.swift:1231-1237). Module tree: SpeakerEncoder.swift:283-297, 163-166, 77, 123-124, 219-220."""
+    out: Dict[str, Tuple[str, np.ndarray]] = {}
+    ch, ks = sc["enc_channels"], sc["enc_kernel_sizes"]
+    scale = sc["enc_res2net_scale"]
+
+    def conv(prefix, cout, cin, k, gain=1.0):
+        out[prefix + ".weight"] = _bf16(g.normal((cout, cin, k), gain / np.sqrt(cin * k)))
+        out[prefix + ".bias"] = _bf16(g.normal((cout,), 0.05))
+
+    conv("speaker_encoder.blocks.0.conv", ch[0], sc["mel_dim"], ks[0], gain=0.3)  # log-mel inputs are O(5)
+    for bi in (1, 2, 3):
+        p = f"speaker_encoder.blocks.{bi}"
+        conv(p + ".tdnn1.conv", ch[bi], ch[bi - 1], 1)
+        for j in range(scale - 1):
+            conv(f"{p}.res2net_block.blocks.{j}.conv", ch[bi] // scale, ch[bi] // scale, ks[bi])
+        conv(p + ".tdnn2.conv", ch[bi], ch[bi], 1)
+        conv(p + ".se_block.conv1", sc["enc_se_channels"], ch[bi], 1)
+        conv(p + ".se_block.conv2", ch[bi], sc["enc_se_channels"], 1)
+    conv("speaker_encoder.mfa.conv", ch[4], ch[1] + ch[2] + ch[3], ks[4])
+    conv("speaker_encoder.asp.tdnn.conv", sc["enc_attention_channels"], 3 * ch[4], 1)
+    conv("speaker_encoder.asp.conv", ch[4], sc["enc_attention_channels"], 1)
+    conv("speaker_encoder.fc", sc["enc_dim"], 2 * ch[4], 1, gain=0.01)  # x-vector at the scale of an embedding row
+    return out
+
+
+def synthetic_reference_audio(row: int = 0, seconds: float = 3.0, sample_rate: int = 24000) -> np.ndarray:
+    """BASELINE config 4: white noise x0.1, seed 99 (+row)."""
+    rng = np.random.Generator(np.random.PCG64(99 + row))
+    return (rng.standard_normal(int(seconds * sample_rate), dtype=np.float32) * np.float32(0.1)).astype(np.float32)
+
+
 def write_checkpoint(model_dir: str, name: str = "tiny-a", seed: int = 1234,
                      overrides: dict | None = None) -> dict:
     """Write a synthetic checkpoint for preset `name` into `model_dir`. Returns the preset dict."""
@@ -353,16 +483,21 @@ def write_checkpoint(model_dir: str, name: str = "tiny-a", seed: int = 1234,
             for q in parts[:-1]:
                 d = d[q]
             d[parts[-1]] = v
-    big = name in ("0.6b", "1.7b", "0.6b-q4")
+    big = name in ("0.6b", "1.7b", "0.6b-q4", "0.6b-base", "1.7b-base")
     g = _Gen(seed, big)
     os.makedirs(os.path.join(model_dir, "speech_tokenizer"), exist_ok=True)
     with open(os.path.join(model_dir, "config.json"), "w") as f:
         json.dump(p["config"], f, indent=1)
     with open(os.path.join(model_dir, "speech_tokenizer", "config.json"), "w") as f:
         json.dump(p["speech_tokenizer"], f, indent=1)
-    save_safetensors(os.path.join(model_dir, "model.safetensors"), talker_tensors(p["config"], g))
-    save_safetensors(os.path.join(model_dir, "speech_tokenizer", "model.safetensors"),
-                     codec_tensors(p["speech_tokenizer"]["decoder_config"], g))
+    main = talker_tensors(p["config"], g)
+    codec = codec_tensors(p["speech_tokenizer"]["decoder_config"], g)
+    if p["config"].get("speaker_encoder_config"):
+        main.update(speaker_encoder_tensors(p["config"]["speaker_encoder_config"], g))
+    if p["speech_tokenizer"].get("encoder_config"):
+        codec.update(encoder_tensors(p["speech_tokenizer"]["encoder_config"], g))
+    save_safetensors(os.path.join(model_dir, "model.safetensors"), main)
+    save_safetensors(os.path.join(model_dir, "speech_tokenizer", "model.safetensors"), codec)
     return p
 
 
@@ -376,7 +511,13 @@ def synthetic_prompt(row: int, n_text: int = 32, n_instruct: int = 0, text_vocab
     body = rng.integers(0, text_vocab, size=n_text).astype(np.int32).tolist()
     text_ids = [im_start, assistant, nl] + body + [im_end, nl, im_start, assistant, nl]
     out = {"text_ids": text_ids, "target_token_count": n_text}
+
     if n_instruct:
         ib = rng.integers(0, text_vocab, size=n_instruct).astype(np.int32).tolist()
         out["instruct_ids"] = [im_start, user, nl] + ib + [im_end, nl]
+    # voice clone: tokens of "<|im_start|>assistant\n{refText}<|im_end|>\n" (Qwen3.swift:448-449); own stream so
+    # the ids above do not depend on it
+    rng2 = np.random.Generator(np.random.PCG64(1007 + row))
+    ref_body = rng2.integers(0, text_vocab, size=max(4, n_text // 2)).astype(np.int32).tolist()
+    out["ref_text_ids"] = [im_start, assistant, nl] + ref_body + [im_end, nl]
     return out
