@@ -135,11 +135,15 @@ def preset(name: str) -> dict:
                    tts_pad_token_id=1010, tts_bos_token_id=1011, tts_eos_token_id=1012,
                    sample_rate=24000)
         return {"config": cfg, "speech_tokenizer": {"decoder_config": _codec_cfg(True)}}
-    if name in ("tiny-base", "0.6b-base", "1.7b-base"):
+    if name in ("tiny-base", "tiny-base-fullenc", "0.6b-base", "1.7b-base"):
         # Base checkpoints (voice clone, BASELINE config 4): tts_model_type "base", a speaker encoder in the main
-        # file and an encoder half in speech_tokenizer/ (Qwen3.swift:55-57, 1210-1214; SpeechTokenizer.swift:808-812)
+        # file and an encoder half in speech_tokenizer/ (Qwen3.swift:55-57, 1210-1214; SpeechTokenizer.swift:808-812).
+        # tiny-base-fullenc: tiny talker behind the full-size codec encoder / speaker encoder (real conv shapes).
         tiny = name == "tiny-base"
-        p = preset("tiny-b" if tiny else name[:-5])
+        p = preset("tiny-b" if name.startswith("tiny") else name[:-5])
+        if name == "tiny-base-fullenc":  # encoder codes must index the talker-side embedding tables
+            p["config"]["talker_config"]["code_predictor_config"]["vocab_size"] = 2048
+            p["speech_tokenizer"]["decoder_config"]["codebook_size"] = 2048
         p["config"]["tts_model_type"] = "base"
         p["config"]["speaker_encoder_config"] = _speaker_cfg(p["config"]["talker_config"]["hidden_size"], tiny)
         p["config"]["talker_config"].setdefault("spk_id", spk)

@@ -380,3 +380,68 @@ def test_gpu_clone_errors(engine_base, ckpt_dirs):
             m.codec_encode(ref_audio(0, 0.3))
     finally:
         m.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# GPU: the real front-end shapes (64..1024-channel SEANet, 8x512 transformer, 2048x256 codebooks, 512/1536-wide ECAPA)
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def fullenc(tmp_path_factory):
+    from oracle import oracle as O
+    from qwen3tts import Qwen3TTSModel, synth
+    d = str(tmp_path_factory.mktemp("tiny_base_fullenc"))
+    synth.write_checkpoint(d, "tiny-base-fullenc", seed=77)
+    m = Qwen3TTSModel.from_pretrained(d, max_batch=2, max_frames=64, max_prompt=192)
+    yield m, O.OracleModel(d)
+    m.close()
+
+
+@pytest.mark.gpu
+def test_gpu_full_size_front_end(fullenc):
+    """BASELINE config 4's reference clip (3.0 s, 72 000 samples) through the full-size encoders."""
+    m, o = fullenc
+    a = ref_audio(0, 3.0)
+    st = {}
+    want = o.codec_encode(a, st)
+    assert want.shape == (16, 38)
+    for name in ("init_conv", "layer0", "layer2", "seanet", "transformer", "downsample", "rvq_rest_in"):
+        got = m.debug_frontend_stage(a, name)
+        assert got.shape == st[name].shape, name
+        assert close(got, st[name], 3e-4), (name, float(np.abs(got - st[name]).max()), float(np.abs(st[name]).max()))
+    got = m.codec_encode(a)
+    gaps = st["gaps"]
+    alive = np.ones(want.shape[1], bool)
+    for layer in range(16):
+        if layer == 1:
+            alive[:] = True
+        diff = (got[layer] != want[layer]) & alive
+        assert (gaps[layer][diff] < 1e-4).all(), (layer, gaps[layer][diff])
+        alive &= ~diff
+    assert (got == want).mean() > 0.95
+    st = {}
+    emb = o.speaker_embedding(a, st)
+    for name in ("mel", "h0", "h3", "mfa"):
+        g = m.debug_frontend_stage(a, name)
+        assert g.shape == st[name].shape and close(g, st[name], 5e-4), name
+    assert close(m.extract_speaker_embedding(a), emb, 1e-3)
+    assert m.last_timing().frontend_ms > 0
+
+
+@pytest.mark.gpu
+def test_gpu_full_size_clone_generation(fullenc):
+    """Clone rows with the full-size front end: batch == singles, reference part removed."""
+    from qwen3tts import GenerationRequest
+    m, _ = fullenc
+    reqs = []
+    for row, sec in ((0, 3.0), (1, 1.37)):
+        pr = clone_prompt(row, 8)
+        reqs.append(GenerationRequest(pr["text_ids"], pr["target_token_count"], None, None, "english",
+                                      ref_audio=ref_audio(row, sec), ref_text_ids=pr["ref_text_ids"]))
+    kw = dict(temperature=0.9, top_k=50, repetition_penalty=1.5, seed=9, force_frames=4)
+    both = m.generate_batch(reqs, **kw)
+    first = m.generate_batch(reqs[:1], **kw)[0]
+    assert (both[0].codes == first.codes).all() and np.abs(both[0].audio - first.audio).max() < 1e-5
+    for r, sec in zip(both, (3.0, 1.37)):
+        assert r.status == 0 and r.codes.shape == (4, 16)
+        ref_T = int(np.ceil(sec * 24000 / 1920))
+        assert abs(r.audio.shape[0] - 4 * 1920) <= 1920 and r.audio.shape[0] <= (ref_T + 4) * 1920
