@@ -59,11 +59,16 @@ def reduce_job_stats(dist, elapsed_s: float, frames_done: int, device):
     return float(t.item()), int(f.item())
 
 
-def build_requests(preset: str, lo: int, hi: int, n_text: int, n_instruct: int):
+def build_requests(preset: str, lo: int, hi: int, n_text: int, n_instruct: int, ref_seconds: float = 3.0):
     from qwen3tts import GenerationRequest, synth
     reqs = []
     for row in range(lo, hi):
         p = synth.synthetic_prompt(row, n_text=n_text, n_instruct=n_instruct)
+        if preset.endswith("-base"):  # BASELINE configs[4]: voice clone, 3.0 s synthetic reference clip per row
+            reqs.append(GenerationRequest(p["text_ids"], p["target_token_count"], None, None, "english",
+                                          ref_audio=synth.synthetic_reference_audio(row, ref_seconds),
+                                          ref_text_ids=p["ref_text_ids"]))
+            continue
         reqs.append(GenerationRequest(p["text_ids"], p["target_token_count"], p.get("instruct_ids"),
                                       "aiden" if preset.startswith("0.6b") else None, "english"))
     return reqs
@@ -88,13 +93,17 @@ def cpu_baseline(ckpt: str, preset: str, n_text: int, n_instruct: int, frames: i
     from qwen3tts import synth
     om = O.OracleModel(ckpt)
     p = synth.synthetic_prompt(0, n_text=n_text, n_instruct=n_instruct)
-    req = O.Request(text_ids=p["text_ids"], target_token_count=p["target_token_count"],
-                    instruct_ids=p.get("instruct_ids"), speaker="aiden" if preset.startswith("0.6b") else None,
-                    language="english")
+    if preset.endswith("-base"):
+        req = O.Request(text_ids=p["text_ids"], target_token_count=p["target_token_count"], language="english",
+                        ref_audio=synth.synthetic_reference_audio(0, 3.0), ref_text_ids=p["ref_text_ids"])
+    else:
+        req = O.Request(text_ids=p["text_ids"], target_token_count=p["target_token_count"],
+                        instruct_ids=p.get("instruct_ids"), speaker="aiden" if preset.startswith("0.6b") else None,
+                        language="english")
     t0 = time.time()
     tr = om.generate_codes(req, O.Sampling(temperature=0.0, force_frames=frames))
     t1 = time.time()
-    om.codec_decode(tr.codes)
+    om.codec_decode(tr.codes if tr.ref_codes is None else np.concatenate([tr.ref_codes.T, tr.codes], 0))
     t2 = time.time()
     return {"value": frames / (t2 - t0), "unit": "frames/s", "cores": int(O.lib().o_num_threads()), "kind": "port",
             "sample": f"oracle (C restatement, OpenMP), batch 1, {frames} frames greedy end-to-end: "
@@ -106,8 +115,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--preset", default="1.7b", choices=["1.7b", "0.6b", "0.6b-q4"])
-    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--preset", default="1.7b", choices=["1.7b", "0.6b", "0.6b-q4", "0.6b-base", "1.7b-base"],
+                    help="*-base: voice clone (BASELINE configs[4]): 3 s reference clip per row, repetition penalty 1.5")
+    ap.add_argument("--batch", type=int, default=0, help="utterances per GPU (default 32; 16 for *-base; 64 for 0.6b-q4)")
     ap.add_argument("--frames", type=int, default=200)
     ap.add_argument("--n-text", type=int, default=32)
     ap.add_argument("--cpu-frames", type=int, default=6)
@@ -131,10 +141,12 @@ def main():
 
     from qwen3tts import Qwen3TTSModel
     n_instruct = 16 if args.preset == "1.7b" else 0
+    clone = args.preset.endswith("-base")
     ckpt = ensure_checkpoint(args.preset, rank, dist)
-    B = args.batch
+    B = args.batch or (16 if clone else 64 if args.preset == "0.6b-q4" else 32)
+    rep = 1.5 if clone else 1.05  # generateVoiceClone's default (Qwen3.swift:1017)
     # rank 0 reads the checkpoint; replicas receive the weight arena by one RCCL broadcast over xGMI
-    model = Qwen3TTSModel.from_pretrained(ckpt, device=local, max_batch=B, max_frames=args.frames + 8, max_prompt=128,
+    model = Qwen3TTSModel.from_pretrained(ckpt, device=local, max_batch=B, max_frames=args.frames + 8, max_prompt=192 if clone else 128,
                                           use_graph=not args.no_graph, n_streams=args.streams,
                                           weights_from_broadcast=(world > 1 and rank != 0))
     if world > 1:
@@ -152,7 +164,7 @@ def main():
     temp = 0.0 if args.greedy else 0.9
 
     def step():
-        return model.generate_batch(reqs, temperature=temp, top_k=50, top_p=1.0, repetition_penalty=1.05, seed=1234,
+        return model.generate_batch(reqs, temperature=temp, top_k=50, top_p=1.0, repetition_penalty=rep, seed=1234,
                                     force_frames=args.frames)
 
     def sync_all():
@@ -165,7 +177,7 @@ def main():
         step()
     sync_all()
     t0 = time.perf_counter()
-    dec_ms = pre_ms = codec_ms = 0.0
+    dec_ms = pre_ms = codec_ms = fe_ms = 0.0
     frame_steps = 0
     kv_bytes = 0
     frames_done = 0
@@ -175,6 +187,7 @@ def main():
         pre_ms += tm.prefill_ms
         dec_ms += tm.decode_ms
         codec_ms += tm.codec_ms
+        fe_ms += tm.frontend_ms
         frame_steps += tm.frame_steps
         kv_bytes += tm.kv_bytes_read
         frames_done += sum(r.codes.shape[0] for r in res)
@@ -197,12 +210,14 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16 (int4-g64 weights)" if args.preset.endswith("q4") else "bf16", "data": "synthetic",
         "config": {"workload": f"Qwen3-TTS-{args.preset.upper()} bf16, batch {B}/GPU x {args.frames} frames, "
                                f"{args.n_text} text + {n_instruct} instruct tokens, T={temp} top-k 50, "
-                               "prompt assembly + prefill + hipGraph AR decode + fp32 codec decode -> 24 kHz PCM",
+                               + ("voice clone: 3.0 s reference clip per row -> codec encoder + speaker encoder + ICL prompt, "
+                                  if clone else "")
+                               + "prompt assembly + prefill + hipGraph AR decode + fp32 codec decode -> 24 kHz PCM",
                    "batch_per_gpu": B, "frames_per_utterance": args.frames, "parallelism": f"batch-shard x{world}"},
         "rtf_audio_s_per_wall_s": value * FRAME_SECONDS, "rtf_wall_s_per_audio_s": 1.0 / (value * FRAME_SECONDS),
         "rtf_per_utterance": value * FRAME_SECONDS / (B * world),
-        "phase_ms_per_step": {"prefill": pre_ms / args.steps, "ar_decode": dec_ms / args.steps,
-                              "codec_decode": codec_ms / args.steps},
+        "phase_ms_per_step": {"voice_frontend": fe_ms / args.steps, "prefill": pre_ms / args.steps,
+                              "ar_decode": dec_ms / args.steps, "codec_decode": codec_ms / args.steps},
         "roofline": {"bound": "hbm", "kernel": "frame_step (hipGraph: talker step + 16 code-predictor passes + samplers)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": step_ms},

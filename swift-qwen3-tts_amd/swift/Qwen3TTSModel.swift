@@ -77,6 +77,7 @@ public final class Qwen3TTSModel {
     public var sampleRate: Int { Int(info.sample_rate) }                                    // Qwen3.swift:1262
     public var ttsModelType: String { withUnsafeBytes(of: info.tts_model_type) { String(cString: $0.bindMemory(to: CChar.self).baseAddress!) } }
     public var supportsVoiceCloning: Bool { info.supports_voice_cloning != 0 }                // Qwen3.swift:1210
+    public var hasVoiceCloning: Bool { info.has_voice_cloning != 0 }                          // Qwen3.swift:61
     public var supportedSpeakers: [String] {                                                 // Qwen3.swift:965
         (0..<q3tts_model_num_speakers(handle)).map { String(cString: q3tts_model_speaker_name(handle, $0)) }
     }
@@ -105,8 +106,32 @@ public final class Qwen3TTSModel {
         }
     }
 
+    /// generateVoiceClone(text:referenceAudio:referenceText:language:...) -- Qwen3.swift:1009-1020 (repetition penalty 1.5)
+    public func generateVoiceClone(text: String, referenceAudio: [Float], referenceText: String, language: String = "auto",
+                                   temperature: Float = 0.9, topK: Int = 50, topP: Float = 1.0, repetitionPenalty: Float = 1.5,
+                                   maxTokens: Int = 2048, seed: UInt64 = 0, onToken: ((Int) -> Void)? = nil) throws -> [Float] {
+        guard let tokenizer else { throw AudioGenerationError.modelNotInitialized("Model not initialized: Tokenizer not loaded") }
+        // Qwen3.swift:448-449: the reference transcript in the assistant template
+        let refIds = tokenizer.encode(text: "<|im_start|>assistant\n\(referenceText)<|im_end|>\n").map(Int32.init)
+        return try run(text: text, speaker: nil, instruct: nil, language: language, temperature: temperature, topK: topK,
+                       topP: topP, repetitionPenalty: repetitionPenalty, maxTokens: maxTokens, seed: seed,
+                       referenceAudio: referenceAudio, refTextIds: refIds,
+                       onEvent: onToken.map { cb in { ev in if case .token(let t) = ev { cb(t) } } })
+    }
+
+    /// extractSpeakerEmbedding(_:sampleRate:) -- Qwen3.swift:222-249
+    public func extractSpeakerEmbedding(_ audio: [Float], sampleRate: Int = 24000) throws -> [Float] {
+        var out = [Float](repeating: 0, count: Int(info.speaker_embedding_dim))
+        let st = audio.withUnsafeBufferPointer { a in
+            q3tts_speaker_embedding(handle, a.baseAddress, Int64(a.count), Int32(sampleRate), &out, Int32(out.count))
+        }
+        guard st == Q3TTS_OK else { throw AudioGenerationError.from(st, String(cString: q3tts_last_error(handle))) }
+        return out
+    }
+
     private func run(text: String, speaker: String?, instruct: String?, language: String, temperature: Float, topK: Int,
                      topP: Float, repetitionPenalty: Float, maxTokens: Int, seed: UInt64,
+                     referenceAudio: [Float] = [], refTextIds: [Int32] = [],
                      onEvent: ((Qwen3TTSGeneration) -> Void)?) throws -> [Float] {
         guard let tokenizer else { throw AudioGenerationError.modelNotInitialized("Model not initialized: Tokenizer not loaded") }
         // the three tokenisations of the reference (Qwen3.swift:274-275, 364-365, 822)
@@ -121,12 +146,18 @@ public final class Qwen3TTSModel {
         defer { box.release(); q3tts_result_free(&result, 1) }
         let st: q3tts_status = textIds.withUnsafeBufferPointer { tp in
             instructIds.withUnsafeBufferPointer { ip in
-                withOptionalCString(speaker) { sp in
-                    language.withCString { lp in
-                        var req = q3tts_request(text_ids: tp.baseAddress, n_text_ids: Int32(tp.count),
-                                                instruct_ids: ip.count > 0 ? ip.baseAddress : nil, n_instruct_ids: Int32(ip.count),
-                                                target_token_count: targetCount, speaker: sp, language: lp, max_tokens: Int32(maxTokens))
-                        return q3tts_generate(handle, &req, 1, &sampling, onEvent == nil ? nil : eventTrampoline, box.toOpaque(), &result)
+                referenceAudio.withUnsafeBufferPointer { ra in
+                    refTextIds.withUnsafeBufferPointer { rt in
+                        withOptionalCString(speaker) { sp in
+                            language.withCString { lp in
+                                var req = q3tts_request(text_ids: tp.baseAddress, n_text_ids: Int32(tp.count),
+                                                        instruct_ids: ip.count > 0 ? ip.baseAddress : nil, n_instruct_ids: Int32(ip.count),
+                                                        target_token_count: targetCount, speaker: sp, language: lp, max_tokens: Int32(maxTokens),
+                                                        ref_audio: ra.count > 0 ? ra.baseAddress : nil, n_ref_samples: Int64(ra.count),
+                                                        ref_text_ids: rt.count > 0 ? rt.baseAddress : nil, n_ref_text_ids: Int32(rt.count))
+                                return q3tts_generate(handle, &req, 1, &sampling, onEvent == nil ? nil : eventTrampoline, box.toOpaque(), &result)
+                            }
+                        }
                     }
                 }
             }
