@@ -40,7 +40,36 @@ def main():
                 stage_std=np.array([float(v.std()) for v in stages.values()], np.float64),
                 stage_shapes=np.array([v.shape for v in stages.values()], np.int64))
             print(name, "codes", greedy.codes[0, :4], "pcm std", float(pcm.std()))
+    voice_clone()
+
+
+def voice_clone():
+    """tiny_base.npz: voice-clone vectors from the oracle on the tiny Base checkpoint."""
+    with tempfile.TemporaryDirectory() as d:
+        synth.write_checkpoint(d, "tiny-base", seed=4321)
+        om = O.OracleModel(d)
+        p = synth.synthetic_prompt(0, n_text=10, text_vocab=1000, im_start=1000, im_end=1001)
+        audio = synth.synthetic_reference_audio(0, 1.0)
+        st = {}
+        codes = om.codec_encode(audio, st)
+        sst = {}
+        xvec = om.speaker_embedding(audio, sst)
+        req = O.Request(text_ids=p["text_ids"], target_token_count=10, language="english", ref_audio=audio,
+                        ref_text_ids=p["ref_text_ids"])
+        ie, tr, pad, _ = om.prepare_icl_generation_inputs(req)
+        s = O.Sampling(temperature=0.0, repetition_penalty=1.5, force_frames=5)
+        pcm, gen, _ = om.generate_voice_clone(req, s)
+        np.savez_compressed(
+            os.path.join(OUT, "tiny_base.npz"),
+            text_ids=np.asarray(p["text_ids"], np.int32), ref_text_ids=np.asarray(p["ref_text_ids"], np.int32),
+            ref_codes=codes, rvq_gaps=st["gaps"], seanet=st["seanet"], transformer=st["transformer"],
+            downsample=st["downsample"], mel=sst["mel"], pooled=sst["pooled"], xvec=xvec, input_embeds=ie, tts_pad=pad,
+            clone_codes=gen.codes, clone_pcm=pcm)
+        print("tiny-base ref codes", codes[:3, :4].tolist(), "clone codes", gen.codes[0, :4], "pcm", pcm.shape)
 
 
 if __name__ == "__main__":
-    main()
+    if "--voice-clone-only" in sys.argv:
+        voice_clone()
+    else:
+        main()
