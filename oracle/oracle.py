@@ -54,7 +54,17 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
+        # OpenMP team: the GPU boxes expose every hardware thread but grant a CPU share of about 16 cores; a team as
+        # large as the machine then spends its time in throttled spin-waits (a tiny forward pass took > 60 s once).
+        # Sleep in barriers and cap the team unless the caller chose a size.
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         _lib = C.CDLL(build())
+        if "OMP_NUM_THREADS" not in os.environ:
+            try:
+                ncpu = len(os.sched_getaffinity(0))
+            except AttributeError:
+                ncpu = os.cpu_count() or 1
+            _lib.o_set_num_threads(C.c_int(max(1, min(16, ncpu))))
         _lib.o_gumbel.restype = C.c_float
         _lib.o_gumbel.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
         _lib.o_logf.restype = C.c_float

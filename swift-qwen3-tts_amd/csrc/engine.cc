@@ -49,7 +49,45 @@ Engine::Engine(Model* model, const q3tts_load_opts& opts) : m_(model), opts_(opt
     n_pages_ = Bm_ * max_pages_;
     for (auto& kv : m_->cfg.talker.spk_id) speakers.push_back(kv.first);
     std::sort(speakers.begin(), speakers.end());
+    {   // persistent stack kernel: bf16 weights, uniform layer widths, an instantiated width combination
+        const TalkerConfig& t = m_->cfg.talker;
+        auto uniform = [](const StackW& s) {
+            for (auto& L : s.layers)
+                if (L.inter_p != s.layers[0].inter_p) return false;
+            return !s.layers.empty();
+        };
+        const bool ok = !m_->cfg.has_quantization && uniform(m_->talker) && uniform(m_->cp) &&
+                        stack_persist_supported(t.hidden_size, t.num_attention_heads * kHeadDim, m_->talker.layers[0].inter_p, 0,
+                                                t.num_attention_heads, t.num_key_value_heads) &&
+                        stack_persist_supported(t.cp.hidden_size, t.cp.num_attention_heads * kHeadDim, m_->cp.layers[0].inter_p,
+                                                m_->has_cp_proj ? t.hidden_size : 0, t.cp.num_attention_heads,
+                                                t.cp.num_key_value_heads) &&
+                        t.hidden_size <= 2048 && t.cp.hidden_size <= 2048;
+        const char* env = std::getenv("Q3TTS_PERSISTENT");
+        int want = opts.persistent;
+        if (want < 0 && env) want = std::atoi(env);
+        if (want < 0) want = 0;  // engine default
+        Q3_CHECK(want == 0 || ok || opts.persistent < 0, 3, "Invalid input: the persistent kernel does not support this model configuration");
+        persistent_ = want != 0 && ok;
+        hipDeviceProp_t prop{};
+        Q3_HIP(hipGetDeviceProperties(&prop, m_->device));
+        persist_grid_ = std::min(256, prop.multiProcessorCount);
+        if (const char* g = std::getenv("Q3TTS_PERSIST_GRID")) persist_grid_ = std::max(8, std::min(std::atoi(g), prop.multiProcessorCount));
+    }
     alloc_workspace();
+    if (persistent_) {
+        auto table = [&](const StackW& s, uint16_t* kp, uint16_t* vp, size_t stride, PersistLayer** out) {
+            std::vector<PersistLayer> v(s.layers.size());
+            for (size_t l = 0; l < s.layers.size(); ++l) {
+                const LayerW& L = s.layers[l];
+                v[l] = PersistLayer{L.qkv.w, L.o.w, L.gateup.w, L.down.w, L.ln1, L.ln2, L.qn, L.kn, kp + l * stride, vp + l * stride, L.inter_p};
+            }
+            Q3_HIP(hipMalloc(reinterpret_cast<void**>(out), v.size() * sizeof(PersistLayer)));
+            Q3_HIP(hipMemcpy(*out, v.data(), v.size() * sizeof(PersistLayer), hipMemcpyHostToDevice));
+        };
+        table(m_->talker, kpool_, vpool_, kv_layer_stride_, &tk_layers_dev_);
+        table(m_->cp, cp_kpool_, cp_vpool_, cp_kv_layer_stride_, &cp_layers_dev_);
+    }
     if (m_->has_codec) codec_ = std::make_unique<CodecRunner>(*m_, st_);
     if (m_->has_codec_encoder || m_->has_speaker_encoder) fe_ = std::make_unique<VoiceFrontEnd>(*m_, st_);
 }
@@ -61,6 +99,9 @@ Engine::~Engine() {
     for (void* p : {(void*)ref_audio_dev_, (void*)ref_codes_dev_, (void*)extra_, (void*)spk_f32_, (void*)dec_codes_})
         if (p) (void)hipFree(p);
     if (ws_) (void)hipFree(ws_);
+    if (uc_ws_) (void)hipFree(uc_ws_);
+    if (tk_layers_dev_) (void)hipFree(tk_layers_dev_);
+    if (cp_layers_dev_) (void)hipFree(cp_layers_dev_);
     for (void* p : {(void*)forced_dev_, (void*)sampled_dev_, (void*)tl_dump_, (void*)cl_dump_})
         if (p) (void)hipFree(p);
     for (auto& e : ev_)
@@ -83,24 +124,32 @@ void Engine::alloc_workspace() {
     proj_cap_ = Bm_ * (2 * Pcap_ + 8);  // text + instruct or reference-text ids + the three tts tokens per row
     for (int pass = 0; pass < 2; ++pass) {
         Bump b{pass ? ws_ : nullptr};
+        // persistent path: everything one workgroup writes and another reads inside a launch lives in uncached memory
+        Bump uc{pass ? uc_ws_ : nullptr};
+        Bump& x = persistent_ ? uc : b;
         auto stream = [&](Stream& s, int hid, int q, int k, int inter_p, int vocab) {
             s.ld_qkv = q + 2 * k;
             s.ld_act = inter_p;
             s.ld_logits = vocab;
-            s.h = b.take<uint16_t>(size_t(Mp_) * hid);
-            s.xn = b.take<uint16_t>(size_t(Mp_) * hid);
-            s.ss_a = b.take<float>(size_t(hid / 16) * Mp_);
-            s.ss_b = b.take<float>(size_t(hid / 16) * Mp_);
-            s.qkv = b.take<uint16_t>(size_t(Mp_) * s.ld_qkv);
-            s.ao = b.take<uint16_t>(size_t(Mp_) * q);
-            s.act = b.take<uint16_t>(size_t(Mp_) * inter_p);
+            s.h = x.take<uint16_t>(size_t(Mp_) * hid);
+            s.xn = x.take<uint16_t>(size_t(Mp_) * hid);
+            s.ss_a = x.take<float>(size_t(hid / 16) * Mp_);
+            s.ss_b = x.take<float>(size_t(hid / 16) * Mp_);
+            s.qkv = x.take<uint16_t>(size_t(Mp_) * s.ld_qkv);
+            s.ao = x.take<uint16_t>(size_t(Mp_) * q);
+            s.act = x.take<uint16_t>(size_t(Mp_) * inter_p);
             s.logits = b.take<uint16_t>(size_t(Mp_) * vocab);
         };
         stream(tk_, H, qd, kd, m_->talker.max_inter_p, t.vocab_size);
         stream(cp_, CH, cqd, ckd, m_->cp.max_inter_p, t.cp.vocab_size);
-        cp_x_ = b.take<uint16_t>(size_t(Mp_) * H);
-        cp_x2_ = b.take<uint16_t>(size_t(Mp_) * H);
-        cp_ss2_ = b.take<float>(size_t(Mp_));
+        cp_x_ = x.take<uint16_t>(size_t(Mp_) * H);
+        cp_x2_ = x.take<uint16_t>(size_t(Mp_) * H);
+        cp_ss2_ = x.take<float>(size_t(Mp_));
+        if (persistent_) {
+            sync_flags_ = uc.take<unsigned>(512);
+            sync_epoch_ = uc.take<unsigned>(64);
+            sync_err_ = uc.take<int>(64);
+        }
         kpool_ = b.take<uint16_t>(kv_layer_stride_ * L);
         vpool_ = b.take<uint16_t>(kv_layer_stride_ * L);
         cp_kpool_ = b.take<uint16_t>(cp_kv_layer_stride_ * CL);
@@ -133,6 +182,11 @@ void Engine::alloc_workspace() {
             ws_bytes_ = align_up(b.off, 256);
             Q3_HIP(hipMalloc(reinterpret_cast<void**>(&ws_), ws_bytes_));
             Q3_HIP(hipMemset(ws_, 0, ws_bytes_));
+            if (persistent_) {
+                uc_ws_bytes_ = align_up(uc.off, 256);
+                Q3_HIP(hipExtMallocWithFlags(reinterpret_cast<void**>(&uc_ws_), uc_ws_bytes_, hipDeviceMallocUncached));
+                Q3_HIP(hipMemset(uc_ws_, 0, uc_ws_bytes_));
+            }
         }
     }
     std::vector<int32_t> cbt((size_t)(Bm_));  // code-predictor cache: one private page per row
@@ -205,17 +259,77 @@ void Engine::enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, 
     }
 }
 
-void Engine::enqueue_talker_step(int B) {
+// One stack forward (optional input projection, all layers, optional final norm + head) as one persistent launch.
+void Engine::enqueue_stack_persist(const StackW& s, const PersistLayer* layers_dev, Stream& w, int B, const int32_t* block_table,
+                                   int max_pages, const int32_t* kv_len, const uint8_t* active, int ss_count_in,
+                                   const LinearW* proj, const uint16_t* proj_x, const uint16_t* proj_norm_w,
+                                   const float* proj_ss_in, int proj_ss_count, int proj_norm_dim, float proj_norm_eps,
+                                   const LinearW* head, const uint16_t* head_norm_w) {
+    StackPersistArgs a{};
+    a.layers = layers_dev;
+    a.n_layers = int(s.layers.size());
+    a.H = s.hidden; a.QD = s.n_heads * kHeadDim; a.KD = s.n_kv * kHeadDim; a.I_p = s.layers[0].inter_p;
+    a.n_heads = s.n_heads; a.n_kv = s.n_kv; a.eps = s.eps; a.scale = powf(float(kHeadDim), -0.5f);
+    a.h = w.h; a.qkv = w.qkv; a.ao = w.ao; a.act = w.act; a.ss_a = w.ss_a; a.ss_b = w.ss_b;
+    a.MBL = Mp_ / 16; a.ss_ld = Mp_; a.ld_qkv = w.ld_qkv; a.M = B; a.ss_count_in = ss_count_in;
+    if (proj) {
+        a.proj_W = proj->w; a.proj_bias = proj->bias; a.proj_x = proj_x; a.proj_K = proj->Kp;
+        a.proj_norm_w = proj_norm_w; a.proj_ss_in = proj_ss_in; a.proj_ss_count = proj_ss_count;
+        a.proj_norm_dim = proj_norm_dim; a.proj_norm_eps = proj_norm_eps;
+    }
+    if (head) {
+        a.head_W = head->w; a.head_norm_w = head_norm_w; a.logits = w.logits; a.ld_logits = w.ld_logits; a.head_N = head->Np;
+    }
+    a.rope_cos = s.rope_cos; a.rope_sin = s.rope_sin; a.block_table = block_table; a.max_pages = max_pages;
+    a.kv_len = kv_len; a.active = active;
+    a.flags = sync_flags_; a.epoch = sync_epoch_; a.err = sync_err_;
+    launch_stack_persist(a, persist_grid_, st_);
+}
+
+void Engine::check_persist_error() {
+    if (!persistent_) return;
+    int err = 0;
+    Q3_HIP(hipMemcpy(&err, sync_err_, 4, hipMemcpyDeviceToHost));
+    if (err) {
+        Q3_HIP(hipMemset(sync_err_, 0, 4));
+        throw Error(7, "persistent kernel: a device-wide barrier timed out (" + std::to_string(err) + " workgroups)");
+    }
+}
+
+void Engine::enqueue_talker_step(int B, bool with_head) {
+    if (persistent_) {  // layers (+ final norm + codec_head, Talker.swift:573, 644) in one launch
+        enqueue_stack_persist(m_->talker, tk_layers_dev_, tk_, B, block_table_, max_pages_, kv_len_, active_, 1, nullptr, nullptr,
+                              nullptr, nullptr, 0, 0, 0.f, with_head ? &m_->codec_head : nullptr, m_->talker.final_norm);
+        return;
+    }
     enqueue_layers(m_->talker, tk_, B, kpool_, vpool_, kv_layer_stride_, block_table_, max_pages_, kv_len_, active_, 1);
 }
 
 // One code-predictor pass (CodePredictor.swift:320-339 without the head). `from_talker`: the input is
 // the talker's final-normed hidden state (step 0, first position); otherwise it is the embedding the
 // previous sampler gathered (fragment-major in cp_x_ when a projection follows, else straight in cp_.h).
-void Engine::enqueue_cp_pass(int B, bool from_talker) {
+void Engine::enqueue_cp_pass(int B, bool from_talker, int head) {
     const TalkerConfig& t = m_->cfg.talker;
     const int H = t.hidden_size, CH = m_->cp.hidden, MBL = Mp_ / 16;
     int ss_count = 1;
+    if (persistent_) {  // [projection +] layers [+ final norm + lm_head] in one launch
+        const LinearW* hd = head >= 0 ? &m_->lm_head[size_t(head)] : nullptr;
+        if (m_->has_cp_proj) {
+            enqueue_stack_persist(m_->cp, cp_layers_dev_, cp_, B, cp_block_table_, 1, cp_len_, nullptr, 1, &m_->cp_proj,
+                                  from_talker ? tk_.h : cp_x_, from_talker ? m_->talker.final_norm : nullptr, tk_.ss_a, H / 16, H,
+                                  m_->talker.eps, hd, m_->cp.final_norm);
+        } else {
+            if (from_talker) {
+                NormRowsArgs n{};
+                n.h = tk_.h; n.hMB = MBL; n.w = m_->talker.final_norm; n.eps = m_->talker.eps;
+                n.out = cp_.h; n.outMB = MBL; n.ss_out = cp_.ss_a; n.M = B; n.H = H;
+                launch_norm_rows(n, st_);
+            }
+            enqueue_stack_persist(m_->cp, cp_layers_dev_, cp_, B, cp_block_table_, 1, cp_len_, nullptr, 1, nullptr, nullptr, nullptr,
+                                  nullptr, 0, 0, 0.f, hd, m_->cp.final_norm);
+        }
+        return;
+    }
     if (m_->has_cp_proj) {  // small_to_mtp_projection (biased), CodePredictor.swift:327-330
         GemmArgs p = gemm_args(m_->cp_proj, from_talker ? tk_.h : cp_x_, B);
         p.epi = 3; p.y = cp_.h; p.yMB = MBL; p.resid = 0; p.ss_out = cp_.ss_a;
@@ -237,8 +351,8 @@ void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
     const TalkerConfig& t = m_->cfg.talker;
     const int H = t.hidden_size, V = t.vocab_size, Vc = t.cp.vocab_size, CH = t.cp.hidden_size;
     const int groups = t.num_code_groups, MBL = Mp_ / 16;
-    enqueue_talker_step(B);
-    {   // final norm (prologue) + codec_head (Talker.swift:573, 644)
+    enqueue_talker_step(B, true);
+    if (!persistent_) {   // final norm (prologue) + codec_head (Talker.swift:573, 644)
         GemmArgs hd = gemm_args(m_->codec_head, tk_.h, B);
         hd.epi = 0; hd.y = tk_.logits; hd.ldy = tk_.ld_logits;
         hd.norm_w = m_->talker.final_norm; hd.ss_in = tk_.ss_a; hd.ss_count = H / 16; hd.norm_dim = H; hd.norm_eps = m_->talker.eps;
@@ -262,18 +376,20 @@ void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
     sa.logits_dump = (dbg && dbg->talker_logits) ? tl_dump_ : nullptr; sa.dump_ld = V; sa.dump_off = 0;
     launch_sampler(sa, st_);
     // code predictor, step 0 = [hidden, embed(code0)] run as two positions
-    enqueue_cp_pass(B, true);
+    enqueue_cp_pass(B, true, -1);
     launch_advance_len(cp_len_, nullptr, B, st_);
     if (!m_->has_cp_proj) {  // second position: move the staged embedding (and its sum of squares) into place
         launch_copy_rows(cp_x2_, 0, cp_.h, 0, 1, Mp_ * H, st_);
         launch_copy_rows(reinterpret_cast<const uint16_t*>(cp_ss2_), 0, reinterpret_cast<uint16_t*>(cp_.ss_a), 0, 1, Mp_ * 2, st_);
     }
     for (int i = 0; i < groups - 1; ++i) {
-        enqueue_cp_pass(B, false);
-        GemmArgs lh = gemm_args(m_->lm_head[size_t(i)], cp_.h, B);
-        lh.epi = 0; lh.y = cp_.logits; lh.ldy = cp_.ld_logits;
-        lh.norm_w = m_->cp.final_norm; lh.ss_in = cp_.ss_a; lh.ss_count = CH / 16; lh.norm_dim = CH; lh.norm_eps = m_->cp.eps;
-        launch_gemm_skinny(lh, st_);
+        enqueue_cp_pass(B, false, i);
+        if (!persistent_) {
+            GemmArgs lh = gemm_args(m_->lm_head[size_t(i)], cp_.h, B);
+            lh.epi = 0; lh.y = cp_.logits; lh.ldy = cp_.ld_logits;
+            lh.norm_w = m_->cp.final_norm; lh.ss_in = cp_.ss_a; lh.ss_count = CH / 16; lh.norm_dim = CH; lh.norm_eps = m_->cp.eps;
+            launch_gemm_skinny(lh, st_);
+        }
         SamplerArgs sc{};
         sc.logits = cp_.logits; sc.ldl = cp_.ld_logits; sc.V = Vc; sc.sp = sp_dev_; sc.is_talker = 0;
         sc.eos_id = -1; sc.cb = i + 1; sc.n_frames = n_frames_; sc.max_frames = max_frames_;
@@ -713,6 +829,11 @@ void Engine::generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp
     for (int32_t* p : {kv_len_, cp_len_, n_frames_, trailing_idx_}) Q3_HIP(hipMemsetAsync(p, 0, size_t(n) * 4, st_));
     Q3_HIP(hipMemsetAsync(active_, 0, size_t(n), st_));
     Q3_HIP(hipMemsetAsync(finished_, 0, size_t(n), st_));
+    if (persistent_) {  // barrier sequence restarts with every call (the stream is idle here)
+        Q3_HIP(hipMemsetAsync(sync_flags_, 0, 512 * sizeof(unsigned), st_));
+        Q3_HIP(hipMemsetAsync(sync_epoch_, 0, sizeof(unsigned), st_));
+        Q3_HIP(hipMemsetAsync(sync_err_, 0, sizeof(int), st_));
+    }
     Q3_HIP(hipMemsetAsync(seen_, 0, size_t(n) * V, st_));
     Q3_HIP(hipMemsetAsync(codes_, 0, size_t(n) * Fcap_ * 16 * 4, st_));
     SamplingParams sph{sp.temperature, sp.top_k, sp.top_p, sp.repetition_penalty, sp.seed, row_offset, sp.force_frames > 0 ? 1 : 0};
@@ -745,7 +866,7 @@ void Engine::generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp
         pl.step = s + (Pcap_ - Pmax);
         launch_prefill_load(pl, st_);
         if (s + 1 < Pmax) {
-            enqueue_talker_step(n);
+            enqueue_talker_step(n, false);
             launch_advance_len(kv_len_, active_, n, st_);
         }
     }
@@ -808,6 +929,7 @@ void Engine::generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp
     Q3_HIP(hipEventRecord(ev_[2], st_));
     Q3_HIP(hipMemcpyAsync(h_nframes.data(), n_frames_, size_t(n) * 4, hipMemcpyDeviceToHost, st_));
     Q3_HIP(hipStreamSynchronize(st_));
+    check_persist_error();
     if (dbg) {
         const size_t nf = size_t(n) * dbg->frames;
         if (dbg->sampled) Q3_HIP(hipMemcpy(dbg->sampled, sampled_dev_, nf * 16 * 4, hipMemcpyDeviceToHost));

@@ -133,6 +133,20 @@ class Engine {
     const float* upload_audio(const float* audio, int64_t n);
     void prepare_clone_rows(std::vector<ResolvedRequest>& reqs);
 
+    // persistent stack-forward path (kernels/stack_persist.hip)
+    bool persistent_ = false;
+    int persist_grid_ = 256;
+    uint8_t* uc_ws_ = nullptr;          // uncached device memory: activations exchanged between workgroups + barrier state
+    size_t uc_ws_bytes_ = 0;
+    PersistLayer *tk_layers_dev_ = nullptr, *cp_layers_dev_ = nullptr;
+    unsigned *sync_flags_ = nullptr, *sync_epoch_ = nullptr;
+    int* sync_err_ = nullptr;
+    void enqueue_stack_persist(const StackW& s, const PersistLayer* layers_dev, Stream& w, int B, const int32_t* block_table,
+                               int max_pages, const int32_t* kv_len, const uint8_t* active, int ss_count_in,
+                               const LinearW* proj, const uint16_t* proj_x, const uint16_t* proj_norm_w, const float* proj_ss_in,
+                               int proj_ss_count, int proj_norm_dim, float proj_norm_eps, const LinearW* head,
+                               const uint16_t* head_norm_w);
+    void check_persist_error();
     void alloc_workspace();
     ResolvedRequest resolve(const q3tts_request& r, const q3tts_sampling& sp) const;
     // builds prompt_/trailing_/tts_pad_ for rows [0,n); fills host-side lengths
@@ -141,8 +155,8 @@ class Engine {
     void enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, uint16_t* vpool, size_t layer_stride,
                         const int32_t* block_table, int max_pages, const int32_t* kv_len, const uint8_t* active,
                         int ss_count_in);
-    void enqueue_talker_step(int B);
-    void enqueue_cp_pass(int B, bool from_talker);
+    void enqueue_talker_step(int B, bool with_head);
+    void enqueue_cp_pass(int B, bool from_talker, int head);  // head: lm_head index or -1
     void enqueue_frame(int B, const DebugOpts* dbg);
     hipGraphExec_t frame_graph(int B);
     GemmArgs gemm_args(const LinearW& L, const uint16_t* x, int M) const;

@@ -127,14 +127,52 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
         }
     }
 
+    // 1b. every other operand that does not depend on arithmetic is requested now as well, so that the kernel pays
+    //     ONE memory round trip instead of a chain of three (sums of squares -> x fragments -> residual tile):
+    //     the raw x fragments of the first XG chunks, and (EPI 3) the old hidden-state piece this thread will update.
+    // chunks whose x fragments are prefetched: as many as fit next to the weight registers (16 VGPRs per fragment set)
+    constexpr int kWRegs = CH * NT * (QUANT ? 5 : 16);
+    constexpr int kRoom = (176 - kWRegs) / (MB * 16);
+    constexpr int XG = (CH == 0) ? 0 : (kRoom < 1 ? 1 : (kRoom > 3 ? (CH < 3 ? CH : 3) : (kRoom < CH ? kRoom : CH)));
+    uint4 xr[XG > 0 ? XG : 1][MB][4];
+    if constexpr (XG > 0) {
+#pragma unroll
+        for (int c = 0; c < XG; ++c) {
+            const int kl = wave + c * NW;
+            const int kc = kl < KC ? kl : 0;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const uint4* xp = Xt + ((size_t)(kc * a.xMB + mb) * 4) * 64 + lane;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xr[c][mb][i] = xp[i * 64];
+            }
+        }
+    }
+    uint4 hv_pre = make_uint4(0, 0, 0, 0);
+    if constexpr (EPI == 3) {
+        if (a.resid && threadIdx.x < 32 * MB) {
+            const int o = threadIdx.x, mb = o >> 5, b = (o >> 1) & 15, p = o & 1;
+            hv_pre = *reinterpret_cast<const uint4*>(a.y + act_tiled_offset(16 * mb + b, tile * 16 + 8 * p, a.yMB));
+        }
+    }
+
     // 2. NORM: rstd per row from the producer's per-tile sums of squares, summed in tile order
     float rstd[MB];
     if constexpr (NORM) {
         const int rows = 16 * MB;
         for (int idx = threadIdx.x; idx < rows * 8; idx += NW * 64) {  // (row, part): 8 strided partial sums per row
             const int row = idx % rows, part = idx / rows;
+            float tmp[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {  // all partials of this (row, part) in flight before the first add (H <= 2048)
+                const int j = part + 8 * u;
+                tmp[u] = a.ss_in[(size_t)(j < a.ss_count ? j : 0) * a.ss_ld + row];
+            }
             float s = 0.f;
-            for (int j = part; j < a.ss_count; j += 8) s += a.ss_in[(size_t)j * a.ss_ld + row];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (part + 8 * u < a.ss_count) s += tmp[u];
+            for (int j = part + 128; j < a.ss_count; j += 8) s += a.ss_in[(size_t)j * a.ss_ld + row];
             ssp_s[part][row] = s;
         }
         __syncthreads();
@@ -150,7 +188,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
     }
 
     // 3. x fragments (+ norm) and MFMAs
-    auto chunk = [&](int kc, int c) {
+    auto chunk = [&](int kc, int c, const uint4 (*xpre)[4]) {
         uint4 w[NT][4];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -169,10 +207,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
         }
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
-            const uint4* xp = Xt + ((size_t)(kc * a.xMB + mb) * 4) * 64 + lane;
             uint4 xf[4];
+            if (xpre) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) xf[i] = xp[i * 64];
+                for (int i = 0; i < 4; ++i) xf[i] = xpre[mb][i];
+            } else {
+                const uint4* xp = Xt + ((size_t)(kc * a.xMB + mb) * 4) * 64 + lane;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xf[i] = xp[i * 64];
+            }
             if constexpr (NORM) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) xf[i] = norm8(xf[i], nw[i], rstd[mb]);
@@ -187,12 +230,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const int kl = wave + c * NW;
-            if (kl < KC) chunk(kl, c);  // wave-uniform
+            if (kl < KC) {  // wave-uniform
+                if (c < XG) chunk(kl, c, xr[c < XG ? c : 0]);
+                else chunk(kl, c, nullptr);
+            }
         }
     } else {
         for (int kl = wave; kl < KC; kl += NW) {
             load_w(0, kl);
-            chunk(kl, 0);
+            chunk(kl, 0, nullptr);
         }
     }
 
@@ -242,8 +288,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
             float ss = 0.f;
             const uint32_t yw[4] = {v.x, v.y, v.z, v.w};
             uint32_t ow[4];
-            uint4 hv = make_uint4(0, 0, 0, 0);
-            if (a.resid) hv = *reinterpret_cast<const uint4*>(hp);
+            const uint4 hv = hv_pre;  // o == threadIdx.x here (32 * MB <= 128 threads, one trip)
             const uint32_t hw[4] = {hv.x, hv.y, hv.z, hv.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
