@@ -218,8 +218,9 @@ void Engine::enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, 
                             const int32_t* block_table, int max_pages, const int32_t* kv_len, const uint8_t* active,
                             int ss_count_in) {
     const int H = s.hidden, MBL = Mp_ / 16, tiles = H / 16;
-    // The RMSNorm prologue re-normalises all of x in every workgroup: measured cheaper than a separate launch for
-    // K = 1024 (+2 us vs ~5 us) but not for K = 2048 (+5..10 us), so wide stacks keep a row-norm kernel.
+    // The RMSNorm prologue re-normalises all of x in every workgroup (VALU work that grows with K): measured cheaper
+    // than a separate launch for K = 1024 but not for K = 2048 (4.57 vs 4.48 ms per 1.7B frame), so wide stacks keep
+    // a row-norm kernel.
     const bool prologue = H <= 1024;
     auto norm_into_xn = [&](const uint16_t* nw) {
         NormRowsArgs n{};

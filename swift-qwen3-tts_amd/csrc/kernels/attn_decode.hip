@@ -58,6 +58,24 @@ __global__ __launch_bounds__(NTH) void attn_decode_kernel(AttnArgs a) {
     const int npage = bt[len / kPageTokens];
     const size_t nslot = (((size_t)npage * a.n_kv + kvh) * kPageTokens + (len % kPageTokens)) * D;
 
+    // The first cache rows of every lane group are requested before the q/k work: they depend on nothing computed
+    // here, and a code-predictor cache (<= 16 past tokens) is then covered by ONE memory round trip.
+    constexpr int PF = NTH >= 256 ? 8 : 4;
+    const int g = tid >> 4, c = tid & 15;  // lane group g (16 lanes) strides over positions; lane c owns dims 8c..8c+7
+    uint4 kpre[PF], vpre[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int t = g + u * NG;
+        kpre[u] = make_uint4(0, 0, 0, 0);
+        vpre[u] = make_uint4(0, 0, 0, 0);
+        if (t < len) {
+            const int page = bt[t / kPageTokens];
+            const size_t off = (((size_t)page * a.n_kv + kvh) * kPageTokens + (t % kPageTokens)) * D + 8 * c;
+            kpre[u] = *reinterpret_cast<const uint4*>(a.kpool + off);
+            vpre[u] = *reinterpret_cast<const uint4*>(a.vpool + off);
+        }
+    }
+
     // ---- phase 1: q/k norm + rope, v copy; vectors round-robin over the 4 waves ----
     for (int j = wave; j < REP + 2; j += NWV) {
         if (j < REP) {
@@ -90,7 +108,6 @@ __global__ __launch_bounds__(NTH) void attn_decode_kernel(AttnArgs a) {
     __syncthreads();
 
     // ---- phase 2: online-softmax attention; lane group g (16 lanes) strides over positions ----
-    const int g = tid >> 4, c = tid & 15;  // 16 groups x 16 lanes; lane c owns dims 8c..8c+7
     float q[REP][8];
 #pragma unroll
     for (int h = 0; h < REP; ++h)
@@ -126,14 +143,31 @@ __global__ __launch_bounds__(NTH) void attn_decode_kernel(AttnArgs a) {
         }
     };
 
-    for (int t = g; t < len; t += NG) {
-        const int page = bt[t / kPageTokens];
-        const size_t off = (((size_t)page * a.n_kv + kvh) * kPageTokens + (t % kPageTokens)) * D + 8 * c;
-        const uint4 kr = *reinterpret_cast<const uint4*>(a.kpool + off);
-        const uint4 vr = *reinterpret_cast<const uint4*>(a.vpool + off);
+    auto step_raw = [&](const uint4& kr, const uint4& vr) {
         float kf[8] = {lo_bf(kr.x), hi_bf(kr.x), lo_bf(kr.y), hi_bf(kr.y), lo_bf(kr.z), hi_bf(kr.z), lo_bf(kr.w), hi_bf(kr.w)};
         float vf[8] = {lo_bf(vr.x), hi_bf(vr.x), lo_bf(vr.y), hi_bf(vr.y), lo_bf(vr.z), hi_bf(vr.z), lo_bf(vr.w), hi_bf(vr.w)};
         step(kf, vf);
+    };
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+        if (g + u * NG < len) step_raw(kpre[u], vpre[u]);
+    for (int t0 = g + PF * NG; t0 < len; t0 += PF * NG) {  // later rows, PF at a time (loads first, then the updates)
+        uint4 kr[PF], vr[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int t = t0 + u * NG;
+            kr[u] = make_uint4(0, 0, 0, 0);
+            vr[u] = make_uint4(0, 0, 0, 0);
+            if (t < len) {
+                const int page = bt[t / kPageTokens];
+                const size_t off = (((size_t)page * a.n_kv + kvh) * kPageTokens + (t % kPageTokens)) * D + 8 * c;
+                kr[u] = *reinterpret_cast<const uint4*>(a.kpool + off);
+                vr[u] = *reinterpret_cast<const uint4*>(a.vpool + off);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+            if (t0 + u * NG < len) step_raw(kr[u], vr[u]);
     }
     if (g == (len % NG)) {  // the new token (kept in LDS: it may not be in the cache when !append)
         float kf[8], vf[8];

@@ -135,11 +135,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
     constexpr int kRoom = (176 - kWRegs) / (MB * 16);
     constexpr int XG = (CH == 0) ? 0 : (kRoom < 1 ? 1 : (kRoom > 3 ? (CH < 3 ? CH : 3) : (kRoom < CH ? kRoom : CH)));
     uint4 xr[XG > 0 ? XG : 1][MB][4];
+    uint4 nwr[(NORM && XG > 0) ? XG : 1][4];
     if constexpr (XG > 0) {
 #pragma unroll
         for (int c = 0; c < XG; ++c) {
             const int kl = wave + c * NW;
             const int kc = kl < KC ? kl : 0;
+            if constexpr (NORM) {
+                const uint4* np = reinterpret_cast<const uint4*>(a.norm_w + kc * 128 + 32 * (lane >> 4));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) nwr[c][i] = np[i];
+            }
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
                 const uint4* xp = Xt + ((size_t)(kc * a.xMB + mb) * 4) * 64 + lane;
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
     }
 
     // 3. x fragments (+ norm) and MFMAs
-    auto chunk = [&](int kc, int c, const uint4 (*xpre)[4]) {
+    auto chunk = [&](int kc, int c, const uint4 (*xpre)[4], const uint4* nwpre) {
         uint4 w[NT][4];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -201,9 +207,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
         }
         uint4 nw[4];
         if constexpr (NORM) {
-            const uint4* np = reinterpret_cast<const uint4*>(a.norm_w + kc * 128 + 32 * (lane >> 4));
+            if (nwpre) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) nw[i] = np[i];
+                for (int i = 0; i < 4; ++i) nw[i] = nwpre[i];
+            } else {
+                const uint4* np = reinterpret_cast<const uint4*>(a.norm_w + kc * 128 + 32 * (lane >> 4));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) nw[i] = np[i];
+            }
         }
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
@@ -227,18 +238,42 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
         }
     };
     if constexpr (CH > 0) {
+        // chunks in groups of XG: the first group's fragments are already in flight; each later group is requested as a
+        // whole (one round trip per group) into the same registers
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const int kl = wave + c * NW;
-            if (kl < KC) {  // wave-uniform
-                if (c < XG) chunk(kl, c, xr[c < XG ? c : 0]);
-                else chunk(kl, c, nullptr);
+        for (int g0 = 0; g0 < CH; g0 += XG) {
+            if (g0 > 0) {
+#pragma unroll
+                for (int c = 0; c < XG; ++c) {
+                    if (g0 + c < CH) {
+                        const int kl = wave + (g0 + c) * NW;
+                        const int kc = kl < KC ? kl : 0;
+                        if constexpr (NORM) {
+                            const uint4* np = reinterpret_cast<const uint4*>(a.norm_w + kc * 128 + 32 * (lane >> 4));
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) nwr[c][i] = np[i];
+                        }
+#pragma unroll
+                        for (int mb = 0; mb < MB; ++mb) {
+                            const uint4* xp = Xt + ((size_t)(kc * a.xMB + mb) * 4) * 64 + lane;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) xr[c][mb][i] = xp[i * 64];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < XG; ++c) {
+                if (g0 + c < CH) {
+                    const int kl = wave + (g0 + c) * NW;
+                    if (kl < KC) chunk(kl, g0 + c, xr[c], NORM ? nwr[c] : nullptr);  // wave-uniform
+                }
             }
         }
     } else {
         for (int kl = wave; kl < KC; kl += NW) {
             load_w(0, kl);
-            chunk(kl, 0, nullptr);
+            chunk(kl, 0, nullptr, nullptr);
         }
     }
 

@@ -319,3 +319,28 @@ def test_end_to_end_waveform_matches_oracle(engines, oracles):
     if 0 < valid < ref.size:
         ref = ref[:valid]
     assert res.audio.size == ref.size and np.abs(res.audio - ref).max() <= 1e-4
+
+
+def test_wide_talker_teacher_forced_logits(tmp_path):
+    """A 2048-wide talker (the 1.7B hidden size; 128 per-tile sums of squares feed the RMSNorm prologue, K = 2048 in
+    the qkv / gate-up GEMMs, a 2048 -> 256 small_to_mtp_projection) against the oracle under teacher forcing."""
+    from oracle import oracle as O
+    from qwen3tts import Qwen3TTSModel, synth
+    d = str(tmp_path / "wide")
+    synth.write_checkpoint(d, "tiny-b", seed=99, overrides={"talker_config.hidden_size": 2048,
+                                                            "talker_config.intermediate_size": 768})
+    m = Qwen3TTSModel.from_pretrained(d, max_batch=3, max_frames=16, max_prompt=64)
+    om = O.OracleModel(d)
+    try:
+        rng = np.random.default_rng(8)
+        F = 4
+        forced = np.concatenate([rng.integers(0, 2048, size=(F, 1)), rng.integers(0, 256, size=(F, 15))], -1).astype(np.int32)
+        tr = om.generate_codes(oreq(row=2, n_text=7), O.Sampling(temperature=0.0, force_frames=F), forced_codes=forced,
+                               keep_logits=True)
+        tl, cl, _ = m.debug_generate_forced([greq(row=2, n_text=7)], forced[None], temperature=0.0)
+        for got, exp in ((tl[0], np.stack(tr.talker_logits)), (cl[0], np.stack(tr.cp_logits))):
+            a, b = bf16_to_f32(got), bf16_to_f32(exp)
+            tol = 2 * ULP * np.abs(b).max(axis=-1, keepdims=True)
+            assert (np.abs(a - b) <= tol).all(), float(np.abs(a - b).max())
+    finally:
+        m.close()
