@@ -96,17 +96,21 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
         }
     };
 
-    load_w(0);
-    int buf = 0;
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
+    // input tile of one 32-channel chunk: global -> registers (prologue applied) -> LDS. The registers of chunk c+1 are
+    // requested while the MFMAs of chunk c run, so only the first chunk exposes the global-memory latency (pointwise
+    // convs have a single tap per chunk: their 0.85 us of MFMA work used to sit behind a 1.5 us load every chunk).
+    constexpr int AV = ((BM + MAX_HALO) * 8 + 255) / 256;  // float4 per thread per chunk
+    float4 areg[AV];
+    auto load_a = [&](int chunk) {
         const int c0 = chunk * KC;
-        __syncthreads();  // previous chunk's MFMAs are done with As
-        for (int item = tid; item < rows * 8; item += 256) {
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int item = i * 256 + tid;
             const int r = item >> 3, c4 = (item & 7) * 4;
             int t = t0 - halo + a.shift + r;
             if (a.reflect) t = t < 0 ? -t : (t >= T ? 2 * (T - 1) - t : t);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t >= 0 && t < T && c0 + c4 < a.Cin) {
+            if (r < rows && t >= 0 && t < T && c0 + c4 < a.Cin) {
                 v = *reinterpret_cast<const float4*>(xb + (size_t)t * a.ldx + c0 + c4);
                 if (x2b) {
                     const float4 u = *reinterpret_cast<const float4*>(x2b + (size_t)t * a.ldx2 + c0 + c4);
@@ -128,8 +132,25 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
                     s = sinf(v.w * ea.w); v.w = v.w + ib.w * (s * s);
                 }
             }
-            *reinterpret_cast<float4*>(&As[r * LDS_LD + c4]) = v;
+            areg[i] = v;
         }
+    };
+    auto store_a = [&]() {
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int item = i * 256 + tid;
+            const int r = item >> 3, c4 = (item & 7) * 4;
+            if (r < rows) *reinterpret_cast<float4*>(&As[r * LDS_LD + c4]) = areg[i];
+        }
+    };
+
+    load_w(0);
+    load_a(0);
+    int buf = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        __syncthreads();  // previous chunk's MFMAs are done with As
+        store_a();
+        if (chunk + 1 < nchunks) load_a(chunk + 1);
         for (int tap = 0; tap < a.K; ++tap) {
             const int step = chunk * a.K + tap;
             store_w(buf);
@@ -137,22 +158,37 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
             if (step + 1 < steps) load_w(step + 1);
             const float* arow = &As[(wm * 64 + tap * a.dil + (lane & 15)) * LDS_LD + 4 * (lane >> 4)];
             const float* wrow = &Ws0[(buf * BN + wn * (BN / 2) + (lane & 15)) * LDS_LD + 4 * (lane >> 4)];
+            // both k16 halves' fragments are read from LDS before the first MFMA of the step: the second half's reads
+            // complete under the first half's 64 MFMAs instead of in front of its own
+            float4 xa[2][4], wa[2][CT];
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
-                float4 xa[4], wa[CT];
 #pragma unroll
-                for (int p = 0; p < 4; ++p) xa[p] = *reinterpret_cast<const float4*>(arow + p * 16 * LDS_LD + g * 16);
+                for (int p = 0; p < 4; ++p) xa[g][p] = *reinterpret_cast<const float4*>(arow + p * 16 * LDS_LD + g * 16);
 #pragma unroll
-                for (int c = 0; c < CT; ++c) wa[c] = *reinterpret_cast<const float4*>(wrow + c * 16 * LDS_LD + g * 16);
+                for (int c = 0; c < CT; ++c) wa[g][c] = *reinterpret_cast<const float4*>(wrow + c * 16 * LDS_LD + g * 16);
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                // k-step outermost: consecutive MFMAs hit different accumulators (a dependent v_mfma_f32_16x16x4_f32
+                // issues after 40 cycles, an independent one after 32: MI355X_MICROARCH.md). Each accumulator still sees
+                // its k-steps in the order x, y, z, w, so the fmaf chain and the results are unchanged.
 #pragma unroll
                 for (int p = 0; p < 4; ++p)
 #pragma unroll
-                    for (int c = 0; c < CT; ++c) {
-                        acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c].x, xa[p].x, acc[p][c], 0, 0, 0);
-                        acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c].y, xa[p].y, acc[p][c], 0, 0, 0);
-                        acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c].z, xa[p].z, acc[p][c], 0, 0, 0);
-                        acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[c].w, xa[p].w, acc[p][c], 0, 0, 0);
-                    }
+                    for (int c = 0; c < CT; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[g][c].x, xa[g][p].x, acc[p][c], 0, 0, 0);
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[g][c].y, xa[g][p].y, acc[p][c], 0, 0, 0);
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[g][c].z, xa[g][p].z, acc[p][c], 0, 0, 0);
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[p][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[g][c].w, xa[g][p].w, acc[p][c], 0, 0, 0);
             }
             buf ^= 1;
         }
