@@ -71,3 +71,32 @@ def test_quantized_model_matches_oracle(q_ckpt):
     assert m.info.weight_bytes < 0.4 * 2 * sum(v.size for k, v in O.dequantize_mlx_affine(O.load_safetensors_dir(q_ckpt)).items()
                                                if k.endswith("proj.weight") or "lm_head" in k or "codec_head" in k)
     m.close()
+
+
+@pytest.mark.gpu
+def test_gpu_per_layer_intermediate_sizes(tmp_path):
+    """Neuron-pruned "lite" checkpoints carry per_layer_intermediate_sizes (Config.swift:224, 297; Talker.swift:514-518):
+    non-uniform and not multiples of 16 / 128. The loader pads each layer's gate/up/down tiles; logits must still match
+    the oracle, which uses the unpadded sizes."""
+    from oracle import oracle as O
+    from qwen3tts import GenerationRequest, Qwen3TTSModel, synth
+    from conftest import bf16_to_f32, tiny_request
+    d = str(tmp_path / "pruned")
+    synth.write_checkpoint(d, "tiny-b", seed=31, overrides={"talker_config.num_hidden_layers": 3,
+                                                            "talker_config.per_layer_intermediate_sizes": [200, 512, 88]})
+    m = Qwen3TTSModel.from_pretrained(d, max_batch=2, max_frames=16, max_prompt=64)
+    om = O.OracleModel(d)
+    try:
+        r = tiny_request(row=1, n_text=8)
+        rng = np.random.default_rng(4)
+        F = 3
+        forced = np.concatenate([rng.integers(0, 2048, size=(F, 1)), rng.integers(0, 256, size=(F, 15))], -1).astype(np.int32)
+        oreq = O.Request(text_ids=r["text_ids"], target_token_count=r["target_token_count"], speaker=r["speaker"], language=r["language"])
+        tr = om.generate_codes(oreq, O.Sampling(temperature=0.0, force_frames=F), forced_codes=forced, keep_logits=True)
+        greq = GenerationRequest(r["text_ids"], r["target_token_count"], None, r["speaker"], r["language"])
+        tl, cl, _ = m.debug_generate_forced([greq], forced[None], temperature=0.0)
+        for got, exp in ((tl[0], np.stack(tr.talker_logits)), (cl[0], np.stack(tr.cp_logits))):
+            a, b = bf16_to_f32(got), bf16_to_f32(exp)
+            assert (np.abs(a - b) <= 2 * 2.0 ** -7 * np.abs(b).max(axis=-1, keepdims=True)).all(), float(np.abs(a - b).max())
+    finally:
+        m.close()
