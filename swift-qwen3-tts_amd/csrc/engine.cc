@@ -216,7 +216,7 @@ GemmArgs Engine::gemm_args(const LinearW& L, const uint16_t* x, int M) const {
 // entering a layer (`ss_count_in` partials for the first layer), ss_b those after o_proj.
 void Engine::enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, uint16_t* vpool, size_t layer_stride,
                             const int32_t* block_table, int max_pages, const int32_t* kv_len, const uint8_t* active,
-                            int ss_count_in) {
+                            int ss_count_in, int fixed_len) {
     const int H = s.hidden, MBL = Mp_ / 16, tiles = H / 16;
     // The RMSNorm prologue re-normalises all of x in every workgroup (VALU work that grows with K): measured cheaper
     // than a separate launch for K = 1024 but not for K = 2048 (4.57 vs 4.48 ms per 1.7B frame), so wide stacks keep
@@ -242,6 +242,7 @@ void Engine::enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, 
         at.kpool = kpool + l * layer_stride; at.vpool = vpool + l * layer_stride;
         at.block_table = block_table; at.max_pages = max_pages; at.kv_len = kv_len; at.active = active;
         at.out = w.ao; at.outMB = MBL; at.n_heads = s.n_heads; at.n_kv = s.n_kv; at.B = B;
+        at.fixed_len = fixed_len; at.identity_pages = fixed_len >= 0 ? 1 : 0;
         at.scale = powf(float(kHeadDim), -0.5f);  // Talker.swift:179
         launch_attn_decode(at, st_);
         GemmArgs o = gemm_args(L.o, w.ao, B);
@@ -303,13 +304,13 @@ void Engine::enqueue_talker_step(int B, bool with_head) {
                               nullptr, nullptr, 0, 0, 0.f, with_head ? &m_->codec_head : nullptr, m_->talker.final_norm);
         return;
     }
-    enqueue_layers(m_->talker, tk_, B, kpool_, vpool_, kv_layer_stride_, block_table_, max_pages_, kv_len_, active_, 1);
+    enqueue_layers(m_->talker, tk_, B, kpool_, vpool_, kv_layer_stride_, block_table_, max_pages_, kv_len_, active_, 1, -1);
 }
 
 // One code-predictor pass (CodePredictor.swift:320-339 without the head). `from_talker`: the input is
 // the talker's final-normed hidden state (step 0, first position); otherwise it is the embedding the
 // previous sampler gathered (fragment-major in cp_x_ when a projection follows, else straight in cp_.h).
-void Engine::enqueue_cp_pass(int B, bool from_talker, int head) {
+void Engine::enqueue_cp_pass(int B, bool from_talker, int head, int cp_pos) {
     const TalkerConfig& t = m_->cfg.talker;
     const int H = t.hidden_size, CH = m_->cp.hidden, MBL = Mp_ / 16;
     int ss_count = 1;
@@ -345,7 +346,8 @@ void Engine::enqueue_cp_pass(int B, bool from_talker, int head) {
         n.out = cp_.h; n.outMB = MBL; n.ss_out = cp_.ss_a; n.M = B; n.H = H;
         launch_norm_rows(n, st_);
     }  // else: the sampler wrote cp_.h and cp_.ss_a[0] itself
-    enqueue_layers(m_->cp, cp_, B, cp_kpool_, cp_vpool_, cp_kv_layer_stride_, cp_block_table_, 1, cp_len_, nullptr, ss_count);
+    // every row's predictor cache holds cp_pos tokens at this point (cp_len_ advances in lock-step, finished rows included)
+    enqueue_layers(m_->cp, cp_, B, cp_kpool_, cp_vpool_, cp_kv_layer_stride_, cp_block_table_, 1, cp_len_, nullptr, ss_count, cp_pos);
 }
 
 void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
@@ -377,14 +379,14 @@ void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
     sa.logits_dump = (dbg && dbg->talker_logits) ? tl_dump_ : nullptr; sa.dump_ld = V; sa.dump_off = 0;
     launch_sampler(sa, st_);
     // code predictor, step 0 = [hidden, embed(code0)] run as two positions
-    enqueue_cp_pass(B, true, -1);
+    enqueue_cp_pass(B, true, -1, 0);
     launch_advance_len(cp_len_, nullptr, B, st_);
     if (!m_->has_cp_proj) {  // second position: move the staged embedding (and its sum of squares) into place
         launch_copy_rows(cp_x2_, 0, cp_.h, 0, 1, Mp_ * H, st_);
         launch_copy_rows(reinterpret_cast<const uint16_t*>(cp_ss2_), 0, reinterpret_cast<uint16_t*>(cp_.ss_a), 0, 1, Mp_ * 2, st_);
     }
     for (int i = 0; i < groups - 1; ++i) {
-        enqueue_cp_pass(B, false, i);
+        enqueue_cp_pass(B, false, i, i + 1);
         if (!persistent_) {
             GemmArgs lh = gemm_args(m_->lm_head[size_t(i)], cp_.h, B);
             lh.epi = 0; lh.y = cp_.logits; lh.ldy = cp_.ld_logits;

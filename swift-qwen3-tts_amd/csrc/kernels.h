@@ -121,6 +121,9 @@ struct AttnArgs {
     int outMB;
     int n_heads, n_kv, B;
     float scale;
+    int fixed_len;       // >= 0: every row's cache holds exactly this many tokens (code predictor: the pass index is known
+                         // when the launch is enqueued), so nothing has to be loaded before the cache rows are requested
+    int identity_pages;  // 1: row b owns page b (the code predictor's one-page-per-row cache)
 };
 void launch_attn_decode(const AttnArgs& a, hipStream_t st);
 

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(NTH) void attn_decode_kernel(AttnArgs a) {
 
     const int kvh = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int len = a.kv_len[b];  // position of the new token
+    const int len = a.fixed_len >= 0 ? a.fixed_len : a.kv_len[b];  // position of the new token
     const bool append = a.active ? (a.active[b] != 0) : true;
     const uint16_t* row = a.qkv + (size_t)b * a.ld;
     const uint16_t* cosr = a.rope_cos + (size_t)len * D;
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(NTH) void attn_decode_kernel(AttnArgs a) {
 
     // new-token page slot
     const int32_t* bt = a.block_table + (size_t)b * a.max_pages;
-    const int npage = bt[len / kPageTokens];
+    const int npage = a.identity_pages ? b : bt[len / kPageTokens];
     const size_t nslot = (((size_t)npage * a.n_kv + kvh) * kPageTokens + (len % kPageTokens)) * D;
 
     // The first cache rows of every lane group are requested before the q/k work: they depend on nothing computed
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(NTH) void attn_decode_kernel(AttnArgs a) {
         kpre[u] = make_uint4(0, 0, 0, 0);
         vpre[u] = make_uint4(0, 0, 0, 0);
         if (t < len) {
-            const int page = bt[t / kPageTokens];
+            const int page = a.identity_pages ? b : bt[t / kPageTokens];
             const size_t off = (((size_t)page * a.n_kv + kvh) * kPageTokens + (t % kPageTokens)) * D + 8 * c;
             kpre[u] = *reinterpret_cast<const uint4*>(a.kpool + off);
             vpre[u] = *reinterpret_cast<const uint4*>(a.vpool + off);
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(NTH) void attn_decode_kernel(AttnArgs a) {
             kr[u] = make_uint4(0, 0, 0, 0);
             vr[u] = make_uint4(0, 0, 0, 0);
             if (t < len) {
-                const int page = bt[t / kPageTokens];
+                const int page = a.identity_pages ? b : bt[t / kPageTokens];
                 const size_t off = (((size_t)page * a.n_kv + kvh) * kPageTokens + (t % kPageTokens)) * D + 8 * c;
                 kr[u] = *reinterpret_cast<const uint4*>(a.kpool + off);
                 vr[u] = *reinterpret_cast<const uint4*>(a.vpool + off);
