@@ -130,12 +130,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the N > 1 path on a one-GPU box: every rank on device 0, gloo instead of RCCL (which needs one
+    # device per rank). The driver's runs use neither variable.
+    if os.environ.get("Q3TTS_BENCH_ONE_DEVICE") == "1":
+        local = 0
+    backend = os.environ.get("Q3TTS_BENCH_BACKEND", "nccl")
     dist = None
     if world > 1:
         import torch
         import torch.distributed as dist_mod
         torch.cuda.set_device(local)
-        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist_mod.init_process_group(backend)
         dist = dist_mod
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for N > 1"
 
@@ -159,6 +167,12 @@ def main():
         arena = torch.as_tensor(_Arena(), device=torch.device("cuda", local))
         broadcast_weights(dist, arena, src=0)
         torch.cuda.synchronize()
+        # every replica now holds rank 0's bytes: compare a checksum of the arena across ranks
+        ck = arena.view(torch.int32)[: arena.numel() // 4].to(torch.int64).sum().reshape(1)
+        lo_ck, hi_ck = ck.clone(), ck.clone()
+        dist.all_reduce(lo_ck, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_ck, op=dist.ReduceOp.MAX)
+        assert int(lo_ck.item()) == int(hi_ck.item()), "weight arena differs between ranks after the broadcast"
     lo, hi = shard_rows(B * world, rank, world)
     reqs = build_requests(args.preset, lo, hi, args.n_text, n_instruct)
     temp = 0.0 if args.greedy else 0.9
