@@ -41,7 +41,7 @@ Engine::Engine(Model* model, const q3tts_load_opts& opts) : m_(model), opts_(opt
     for (auto& e : burst_ev_) Q3_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : ev_fe_) Q3_HIP(hipEventCreate(&e));
     Bm_ = opts.max_batch;
-    Mp_ = int(align_up(size_t(Bm_), 16));
+    Mp_ = 64;  // activation rows: up to 64 (batch rows x positions per launch), whatever the batch
     Pcap_ = opts.max_prompt;
     Tcap_ = opts.max_prompt;
     Fcap_ = opts.max_frames;
@@ -216,21 +216,23 @@ GemmArgs Engine::gemm_args(const LinearW& L, const uint16_t* x, int M) const {
 // entering a layer (`ss_count_in` partials for the first layer), ss_b those after o_proj.
 void Engine::enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, uint16_t* vpool, size_t layer_stride,
                             const int32_t* block_table, int max_pages, const int32_t* kv_len, const uint8_t* active,
-                            int ss_count_in, int fixed_len) {
+                            int ss_count_in, int fixed_len, int chunk, const int32_t* chunk_n_prompt, int chunk_r_base) {
     const int H = s.hidden, MBL = Mp_ / 16, tiles = H / 16;
+    const int M = B * (chunk > 1 ? chunk : 1);  // GEMM rows: chunk element p of batch row b is row p * B + b
+    Q3_CHECK(M <= Mp_, 7, "internal error: chunk does not fit the activation buffers");
     // The RMSNorm prologue re-normalises all of x in every workgroup (VALU work that grows with K): measured cheaper
     // than a separate launch for K = 1024 but not for K = 2048 (4.57 vs 4.48 ms per 1.7B frame), so wide stacks keep
     // a row-norm kernel.
     const bool prologue = H <= 1024;
     auto norm_into_xn = [&](const uint16_t* nw) {
         NormRowsArgs n{};
-        n.h = w.h; n.hMB = MBL; n.w = nw; n.eps = s.eps; n.out = w.xn; n.outMB = MBL; n.M = B; n.H = H;
+        n.h = w.h; n.hMB = MBL; n.w = nw; n.eps = s.eps; n.out = w.xn; n.outMB = MBL; n.M = M; n.H = H;
         launch_norm_rows(n, st_);
     };
     for (size_t l = 0; l < s.layers.size(); ++l) {
         const LayerW& L = s.layers[l];
         if (!prologue) norm_into_xn(L.ln1);
-        GemmArgs q = gemm_args(L.qkv, prologue ? w.h : w.xn, B);
+        GemmArgs q = gemm_args(L.qkv, prologue ? w.h : w.xn, M);
         q.epi = 0; q.y = w.qkv; q.ldy = w.ld_qkv;
         if (prologue) {
             q.norm_w = L.ln1; q.ss_in = w.ss_a; q.ss_count = (l == 0) ? ss_count_in : tiles; q.norm_dim = H; q.norm_eps = s.eps;
@@ -243,19 +245,20 @@ void Engine::enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, 
         at.block_table = block_table; at.max_pages = max_pages; at.kv_len = kv_len; at.active = active;
         at.out = w.ao; at.outMB = MBL; at.n_heads = s.n_heads; at.n_kv = s.n_kv; at.B = B;
         at.fixed_len = fixed_len; at.identity_pages = fixed_len >= 0 ? 1 : 0;
+        at.chunk = chunk; at.chunk_n_prompt = chunk_n_prompt; at.chunk_r_base = chunk_r_base;
         at.scale = powf(float(kHeadDim), -0.5f);  // Talker.swift:179
         launch_attn_decode(at, st_);
-        GemmArgs o = gemm_args(L.o, w.ao, B);
+        GemmArgs o = gemm_args(L.o, w.ao, M);
         o.epi = 3; o.y = w.h; o.yMB = MBL; o.resid = 1; o.ss_out = w.ss_b;
         launch_gemm_skinny(o, st_);
         if (!prologue) norm_into_xn(L.ln2);
-        GemmArgs g = gemm_args(L.gateup, prologue ? w.h : w.xn, B);
+        GemmArgs g = gemm_args(L.gateup, prologue ? w.h : w.xn, M);
         g.epi = 2; g.y = w.act; g.yMB = MBL;
         if (prologue) {
             g.norm_w = L.ln2; g.ss_in = w.ss_b; g.ss_count = tiles; g.norm_dim = H; g.norm_eps = s.eps;
         }
         launch_gemm_skinny(g, st_);
-        GemmArgs d = gemm_args(L.down, w.act, B);
+        GemmArgs d = gemm_args(L.down, w.act, M);
         d.epi = 3; d.y = w.h; d.yMB = MBL; d.resid = 1; d.ss_out = w.ss_a;
         launch_gemm_skinny(d, st_);
     }
@@ -304,7 +307,7 @@ void Engine::enqueue_talker_step(int B, bool with_head) {
                               nullptr, nullptr, 0, 0, 0.f, with_head ? &m_->codec_head : nullptr, m_->talker.final_norm);
         return;
     }
-    enqueue_layers(m_->talker, tk_, B, kpool_, vpool_, kv_layer_stride_, block_table_, max_pages_, kv_len_, active_, 1, -1);
+    enqueue_layers(m_->talker, tk_, B, kpool_, vpool_, kv_layer_stride_, block_table_, max_pages_, kv_len_, active_, 1, -1, 1, nullptr, 0);
 }
 
 // One code-predictor pass (CodePredictor.swift:320-339 without the head). `from_talker`: the input is
@@ -314,40 +317,39 @@ void Engine::enqueue_cp_pass(int B, bool from_talker, int head, int cp_pos) {
     const TalkerConfig& t = m_->cfg.talker;
     const int H = t.hidden_size, CH = m_->cp.hidden, MBL = Mp_ / 16;
     int ss_count = 1;
+    // The talker's final norm (Talker.swift:573) is always a row kernel, so that every way of scheduling step 0 (two
+    // passes, one two-position pass, the persistent kernel) rounds it identically.
+    auto talker_norm_into = [&](uint16_t* dst, float* ss_out) {
+        NormRowsArgs n{};
+        n.h = tk_.h; n.hMB = MBL; n.w = m_->talker.final_norm; n.eps = m_->talker.eps;
+        n.out = dst; n.outMB = MBL; n.ss_out = ss_out; n.M = B; n.H = H;
+        launch_norm_rows(n, st_);
+    };
     if (persistent_) {  // [projection +] layers [+ final norm + lm_head] in one launch
         const LinearW* hd = head >= 0 ? &m_->lm_head[size_t(head)] : nullptr;
         if (m_->has_cp_proj) {
+            // cp_x_ already holds embed(code0) for the second position: the normed hidden state goes to cp_x2_
+            if (from_talker) talker_norm_into(cp_x2_, nullptr);
             enqueue_stack_persist(m_->cp, cp_layers_dev_, cp_, B, cp_block_table_, 1, cp_len_, nullptr, 1, &m_->cp_proj,
-                                  from_talker ? tk_.h : cp_x_, from_talker ? m_->talker.final_norm : nullptr, tk_.ss_a, H / 16, H,
-                                  m_->talker.eps, hd, m_->cp.final_norm);
+                                  from_talker ? cp_x2_ : cp_x_, nullptr, nullptr, 0, 0, 0.f, hd, m_->cp.final_norm);
         } else {
-            if (from_talker) {
-                NormRowsArgs n{};
-                n.h = tk_.h; n.hMB = MBL; n.w = m_->talker.final_norm; n.eps = m_->talker.eps;
-                n.out = cp_.h; n.outMB = MBL; n.ss_out = cp_.ss_a; n.M = B; n.H = H;
-                launch_norm_rows(n, st_);
-            }
+            if (from_talker) talker_norm_into(cp_.h, cp_.ss_a);
             enqueue_stack_persist(m_->cp, cp_layers_dev_, cp_, B, cp_block_table_, 1, cp_len_, nullptr, 1, nullptr, nullptr, nullptr,
                                   nullptr, 0, 0, 0.f, hd, m_->cp.final_norm);
         }
         return;
     }
     if (m_->has_cp_proj) {  // small_to_mtp_projection (biased), CodePredictor.swift:327-330
-        GemmArgs p = gemm_args(m_->cp_proj, from_talker ? tk_.h : cp_x_, B);
+        if (from_talker) talker_norm_into(cp_x2_, nullptr);  // cp_x_ already holds embed(code0) for the second position
+        GemmArgs p = gemm_args(m_->cp_proj, from_talker ? cp_x2_ : cp_x_, B);
         p.epi = 3; p.y = cp_.h; p.yMB = MBL; p.resid = 0; p.ss_out = cp_.ss_a;
-        if (from_talker) {  // talker final norm (Talker.swift:573) in the prologue
-            p.norm_w = m_->talker.final_norm; p.ss_in = tk_.ss_a; p.ss_count = H / 16; p.norm_dim = H; p.norm_eps = m_->talker.eps;
-        }
         launch_gemm_skinny(p, st_);
         ss_count = CH / 16;
     } else if (from_talker) {
-        NormRowsArgs n{};
-        n.h = tk_.h; n.hMB = MBL; n.w = m_->talker.final_norm; n.eps = m_->talker.eps;
-        n.out = cp_.h; n.outMB = MBL; n.ss_out = cp_.ss_a; n.M = B; n.H = H;
-        launch_norm_rows(n, st_);
+        talker_norm_into(cp_.h, cp_.ss_a);
     }  // else: the sampler wrote cp_.h and cp_.ss_a[0] itself
     // every row's predictor cache holds cp_pos tokens at this point (cp_len_ advances in lock-step, finished rows included)
-    enqueue_layers(m_->cp, cp_, B, cp_kpool_, cp_vpool_, cp_kv_layer_stride_, cp_block_table_, 1, cp_len_, nullptr, ss_count, cp_pos);
+    enqueue_layers(m_->cp, cp_, B, cp_kpool_, cp_vpool_, cp_kv_layer_stride_, cp_block_table_, 1, cp_len_, nullptr, ss_count, cp_pos, 1, nullptr, 0);
 }
 
 void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
@@ -364,6 +366,10 @@ void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
     // where the samplers put the next code-predictor input
     uint16_t* next_x = m_->has_cp_proj ? cp_x_ : cp_.h;
     float* next_ss = m_->has_cp_proj ? nullptr : cp_.ss_a;
+    // Predictor step 0 takes two positions, [talker hidden, embed(code0)] (Qwen3.swift:884-887). When 2 * B rows fit the
+    // activation buffers they go through the stack together (rows 0..B-1 and B..2B-1, chunk attention), which saves a
+    // whole pass of launches per frame; otherwise (and on the persistent path) they are two passes.
+    const bool pair = !persistent_ && 2 * B <= Mp_;
     SamplerArgs sa{};
     sa.logits = tk_.logits; sa.ldl = tk_.ld_logits; sa.V = V; sa.sp = sp_dev_; sa.is_talker = 1;
     sa.suppress_lo = V - 1024; sa.suppress_hi = V; sa.eos_id = t.codec_eos_token_id;  // Qwen3.swift:829-835
@@ -372,29 +378,55 @@ void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
     sa.cur_codes = cur_codes_; sa.codes = codes_; sa.Fmax = Fcap_;
     sa.forced = dbg ? forced_dev_ : nullptr; sa.forced_frames = dbg ? dbg->frames : 0;
     sa.sampled = dbg ? sampled_dev_ : nullptr;
-    // the embedding of code 0 is the SECOND position of predictor step 0 (Qwen3.swift:884-887). Without a projection a
-    // pass takes its input in cp_.h, which the first position (the talker hidden state) still needs: stage it in cp_x2_
-    sa.emb = m_->codec_emb; sa.emb_ld = H; sa.next_x = m_->has_cp_proj ? cp_x_ : cp_x2_; sa.next_MB = MBL;
-    sa.next_ss = m_->has_cp_proj ? nullptr : cp_ss2_; sa.H = H; sa.B = B;
+    sa.emb = m_->codec_emb; sa.emb_ld = H; sa.next_MB = MBL; sa.H = H; sa.B = B;
+    if (pair) {  // embed(code0) goes straight to the second row block of the pass input
+        sa.next_x = next_x; sa.next_row0 = B; sa.next_ss = next_ss ? next_ss + B : nullptr;
+    } else {
+        // Without a projection a pass takes its input in cp_.h, which the first position (the talker hidden state) still
+        // needs: stage the embedding in cp_x2_
+        sa.next_x = m_->has_cp_proj ? cp_x_ : cp_x2_; sa.next_ss = m_->has_cp_proj ? nullptr : cp_ss2_;
+    }
     sa.logits_dump = (dbg && dbg->talker_logits) ? tl_dump_ : nullptr; sa.dump_ld = V; sa.dump_off = 0;
-    launch_sampler(sa, st_);
-    // code predictor, step 0 = [hidden, embed(code0)] run as two positions
-    enqueue_cp_pass(B, true, -1, 0);
-    launch_advance_len(cp_len_, nullptr, B, st_);
-    if (!m_->has_cp_proj) {  // second position: move the staged embedding (and its sum of squares) into place
-        launch_copy_rows(cp_x2_, 0, cp_.h, 0, 1, Mp_ * H, st_);
-        launch_copy_rows(reinterpret_cast<const uint16_t*>(cp_ss2_), 0, reinterpret_cast<uint16_t*>(cp_.ss_a), 0, 1, Mp_ * 2, st_);
+    if (pair) {
+        // first position: the talker's final-normed hidden state (Talker.swift:573), materialised next to the embedding
+        NormRowsArgs n{};
+        n.h = tk_.h; n.hMB = MBL; n.w = m_->talker.final_norm; n.eps = m_->talker.eps;
+        n.out = next_x; n.outMB = MBL; n.ss_out = next_ss; n.M = B; n.H = H;
+        launch_norm_rows(n, st_);
+        launch_sampler(sa, st_);
+        int ss_count = 1;
+        if (m_->has_cp_proj) {  // small_to_mtp_projection over both positions (CodePredictor.swift:327-330)
+            GemmArgs p = gemm_args(m_->cp_proj, cp_x_, 2 * B);
+            p.epi = 3; p.y = cp_.h; p.yMB = MBL; p.resid = 0; p.ss_out = cp_.ss_a;
+            launch_gemm_skinny(p, st_);
+            ss_count = CH / 16;
+        }
+        enqueue_layers(m_->cp, cp_, B, cp_kpool_, cp_vpool_, cp_kv_layer_stride_, cp_block_table_, 1, cp_len_, nullptr, ss_count, 0, 2,
+                       nullptr, 0);
+        launch_advance_len(cp_len_, nullptr, B, st_);
+    } else {
+        launch_sampler(sa, st_);
+        // code predictor, step 0 = [hidden, embed(code0)] run as two positions
+        enqueue_cp_pass(B, true, -1, 0);
+        launch_advance_len(cp_len_, nullptr, B, st_);
+        if (!m_->has_cp_proj) {  // second position: move the staged embedding (and its sum of squares) into place
+            launch_copy_rows(cp_x2_, 0, cp_.h, 0, 1, Mp_ * H, st_);
+            launch_copy_rows(reinterpret_cast<const uint16_t*>(cp_ss2_), 0, reinterpret_cast<uint16_t*>(cp_.ss_a), 0, 1, Mp_ * 2, st_);
+        }
     }
     for (int i = 0; i < groups - 1; ++i) {
-        enqueue_cp_pass(B, false, i, i + 1);
+        const bool second_of_pair = pair && i == 0;  // its stack forward already ran above; rows B..2B-1 hold it
+        const int Mh = second_of_pair ? 2 * B : B;
+        if (!second_of_pair) enqueue_cp_pass(B, false, i, i + 1);
         if (!persistent_) {
-            GemmArgs lh = gemm_args(m_->lm_head[size_t(i)], cp_.h, B);
+            GemmArgs lh = gemm_args(m_->lm_head[size_t(i)], cp_.h, Mh);
             lh.epi = 0; lh.y = cp_.logits; lh.ldy = cp_.ld_logits;
             lh.norm_w = m_->cp.final_norm; lh.ss_in = cp_.ss_a; lh.ss_count = CH / 16; lh.norm_dim = CH; lh.norm_eps = m_->cp.eps;
             launch_gemm_skinny(lh, st_);
         }
         SamplerArgs sc{};
-        sc.logits = cp_.logits; sc.ldl = cp_.ld_logits; sc.V = Vc; sc.sp = sp_dev_; sc.is_talker = 0;
+        sc.logits = cp_.logits + (second_of_pair ? size_t(B) * cp_.ld_logits : 0); sc.ldl = cp_.ld_logits; sc.V = Vc; sc.sp = sp_dev_;
+        sc.is_talker = 0;
         sc.eos_id = -1; sc.cb = i + 1; sc.n_frames = n_frames_; sc.max_frames = max_frames_;
         sc.finished = finished_; sc.active = active_; sc.kv_len = cp_len_; sc.advance = 1; sc.advance_gate = nullptr;
         sc.cur_codes = cur_codes_; sc.codes = codes_; sc.Fmax = Fcap_;
@@ -864,14 +896,33 @@ void Engine::generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp
     PrefillLoadArgs pl{};
     pl.prompt = prompt_; pl.n_prompt = n_prompt_; pl.Pmax = Pcap_; pl.H = H; pl.B = n; pl.h = tk_.h; pl.hMB = Mp_ / 16;
     pl.ss_out = tk_.ss_a; pl.active = active_;
-    // prompt_ rows are laid out with stride Pcap_; right alignment is relative to the longest prompt
-    for (int s = 0; s < Pmax; ++s) {
-        pl.step = s + (Pcap_ - Pmax);
-        launch_prefill_load(pl, st_);
-        if (s + 1 < Pmax) {
-            enqueue_talker_step(n, false);
-            launch_advance_len(kv_len_, active_, n, st_);
+    // prompt_ rows are laid out with stride Pcap_; right alignment is relative to the longest prompt.
+    // Positions 0 .. Pmax-2 go through the decode kernels C at a time (C * n <= 64 activation rows: the GEMMs stream
+    // the weights once per chunk instead of once per position); rows whose prompt is shorter start inside a chunk.
+    {
+        const int P1 = Pmax - 1;  // positions before the one the first frame step consumes
+        int C = std::max(1, std::min(8, Mp_ / n));
+        if (persistent_) C = 1;   // the persistent stack kernel takes one position per launch
+        const int S = (P1 + C - 1) / C;
+        for (int s = 0; s < S; ++s) {
+            // element p of row b in chunk s is prompt position r = s*C - S*C + (n_prompt[b] - 1) + p
+            const int r_base = s * C - S * C - 1;
+            if (C == 1) {
+                pl.step = s + (Pcap_ - Pmax);
+                launch_prefill_load(pl, st_);
+                enqueue_talker_step(n, false);
+                launch_advance_len(kv_len_, active_, n, st_);
+            } else {
+                PrefillLoadArgs pc = pl;
+                pc.step = r_base;
+                launch_prefill_chunk_load(pc, C, st_);
+                enqueue_layers(m_->talker, tk_, n, kpool_, vpool_, kv_layer_stride_, block_table_, max_pages_, kv_len_, nullptr, 1, -1,
+                               C, n_prompt_, r_base);
+                launch_advance_len_chunk(kv_len_, n_prompt_, r_base, C, n, st_);
+            }
         }
+        pl.step = (Pmax - 1) + (Pcap_ - Pmax);  // the last prompt position: consumed by the first frame step
+        launch_prefill_load(pl, st_);
     }
     Q3_HIP(hipEventRecord(ev_[1], st_));
 

@@ -154,7 +154,7 @@ class Engine {
     void project_rows(const std::vector<int32_t>& ids, int rows);  // ids -> proj_out_[rows][H]
     void enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, uint16_t* vpool, size_t layer_stride,
                         const int32_t* block_table, int max_pages, const int32_t* kv_len, const uint8_t* active,
-                        int ss_count_in, int fixed_len);
+                        int ss_count_in, int fixed_len, int chunk, const int32_t* chunk_n_prompt, int chunk_r_base);
     void enqueue_talker_step(int B, bool with_head);
     void enqueue_cp_pass(int B, bool from_talker, int head, int cp_pos);  // head: lm_head index or -1; cp_pos: tokens already cached
     void enqueue_frame(int B, const DebugOpts* dbg);

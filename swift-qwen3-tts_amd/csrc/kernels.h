@@ -124,6 +124,12 @@ struct AttnArgs {
     int fixed_len;       // >= 0: every row's cache holds exactly this many tokens (code predictor: the pass index is known
                          // when the launch is enqueued), so nothing has to be loaded before the cache rows are requested
     int identity_pages;  // 1: row b owns page b (the code predictor's one-page-per-row cache)
+    // chunk > 1: `chunk` consecutive positions per batch row in this launch; qkv / out row of element p of row b is
+    // p * B + b. chunk_n_prompt != nullptr: right-aligned prompt chunks, element p of row b is prompt position
+    // chunk_r_base + chunk_n_prompt[b] + p and is skipped while that is negative; nullptr: every element is live.
+    int chunk;
+    const int32_t* chunk_n_prompt;
+    int chunk_r_base;
 };
 void launch_attn_decode(const AttnArgs& a, hipStream_t st);
 
@@ -163,6 +169,7 @@ struct SamplerArgs {
     int emb_ld;
     uint16_t* next_x;        // fragment-major [B][H] or nullptr
     int next_MB;
+    int next_row0;           // row b is written at row b + next_row0 of next_x (second position of predictor step 0)
     float* next_ss;          // [B] sum of squares of the gathered row (norm prologue of the consumer) or nullptr
     int H;
     int B;
@@ -194,6 +201,9 @@ struct PrefillLoadArgs {
 };
 void launch_prefill_load(const PrefillLoadArgs& a, hipStream_t st);
 void launch_advance_len(int32_t* kv_len, const uint8_t* active, int B, hipStream_t st);
+// chunked prefill: C positions per row per step; a.step carries r_base (prompt index of element 0 = r_base + n_prompt[b])
+void launch_prefill_chunk_load(const PrefillLoadArgs& a, int C, hipStream_t st);
+void launch_advance_len_chunk(int32_t* kv_len, const int32_t* n_prompt, int r_base, int C, int B, hipStream_t st);
 
 struct FrameEndArgs {  // Qwen3.swift:919-935 + loop bookkeeping
     const int32_t* cur_codes;     // [B][16]

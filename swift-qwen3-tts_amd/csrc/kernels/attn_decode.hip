@@ -213,12 +213,178 @@ __global__ __launch_bounds__(NTH) void attn_decode_kernel(AttnArgs a) {
     }
 }
 
+// Several consecutive positions of every row in one launch (chunked prompt prefill; the code predictor's step 0,
+// whose two positions [hidden, embed(code0)] arrive together: Qwen3.swift:884-887). Row m = p * B + b carries chunk
+// element p of batch row b. Elements p < p0(b) are padding in front of a right-aligned prompt and are skipped; element p
+// sits at cache position len0 + (p - p0). A query attends to the cache and to the chunk elements up to itself, which are
+// kept in LDS; every lane group walks its positions (t mod NG) in increasing order exactly as the one-position kernel
+// would if the elements arrived one launch at a time, so the results do not depend on where a chunk boundary falls.
+template <int REP, int NTH, int CMAX>
+__global__ __launch_bounds__(NTH) void attn_chunk_kernel(AttnArgs a) {
+    constexpr int NG = NTH / 16;
+    constexpr int NWV = NTH / 64;
+    __shared__ __attribute__((aligned(16))) float q_s[CMAX][REP][D];
+    __shared__ float k_s[CMAX][D];
+    __shared__ float v_s[CMAX][D];
+    __shared__ float m_s[NG][REP];
+    __shared__ float l_s[NG][REP];
+    __shared__ float acc_s[NG][REP][D];
+    __shared__ __attribute__((aligned(16))) uint16_t out_s[REP * D];
+
+    const int kvh = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = a.chunk;
+    const int len0 = a.fixed_len >= 0 ? a.fixed_len : a.kv_len[b];
+    const int r0 = a.chunk_n_prompt ? a.chunk_r_base + a.chunk_n_prompt[b] : 0;  // prompt index of chunk element 0
+    const int p0 = r0 < 0 ? (-r0 < C ? -r0 : C) : 0;
+    const int qdim = a.n_heads * D, kdim = a.n_kv * D;
+    const int32_t* bt = a.block_table + (size_t)b * a.max_pages;
+
+    // ---- phase 1: q/k norm + rope, v copy, cache append for every live element; vectors round-robin over the waves ----
+    for (int vtx = wave; vtx < (C - p0) * (REP + 2); vtx += NWV) {
+        const int p = p0 + vtx / (REP + 2), j = vtx % (REP + 2);
+        const int pos = len0 + (p - p0);
+        const uint16_t* row = a.qkv + (size_t)(p * a.B + b) * a.ld;
+        const uint16_t* cosr = a.rope_cos + (size_t)pos * D;
+        const uint16_t* sinr = a.rope_sin + (size_t)pos * D;
+        const int npage = a.identity_pages ? b : bt[pos / kPageTokens];
+        const size_t nslot = (((size_t)npage * a.n_kv + kvh) * kPageTokens + (pos % kPageTokens)) * D;
+        if (j < REP) {
+            const uint16_t* qp = row + (size_t)(kvh * REP + j) * D;
+            float o0, o1;
+            norm_rope(bf2f(qp[lane]), bf2f(qp[lane + 64]), a.qn_w, a.eps, cosr, sinr, lane, o0, o1);
+            q_s[p][j][lane] = o0;
+            q_s[p][j][lane + 64] = o1;
+        } else if (j == REP) {
+            const uint16_t* kp = row + qdim + (size_t)kvh * D;
+            float o0, o1;
+            norm_rope(bf2f(kp[lane]), bf2f(kp[lane + 64]), a.kn_w, a.eps, cosr, sinr, lane, o0, o1);
+            k_s[p][lane] = o0;
+            k_s[p][lane + 64] = o1;
+            a.kpool[nslot + lane] = f2bf(o0);
+            a.kpool[nslot + lane + 64] = f2bf(o1);
+        } else {
+            const uint16_t* vp = row + qdim + kdim + (size_t)kvh * D;
+            const uint16_t v0 = vp[lane], v1 = vp[lane + 64];
+            v_s[p][lane] = bf2f(v0);
+            v_s[p][lane + 64] = bf2f(v1);
+            a.vpool[nslot + lane] = v0;
+            a.vpool[nslot + lane + 64] = v1;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: one query after the other ----
+    const int g = tid >> 4, c = tid & 15;
+    for (int p = p0; p < C; ++p) {
+        float q[REP][8];
+#pragma unroll
+        for (int h = 0; h < REP; ++h)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) q[h][j] = q_s[p][h][8 * c + j];
+        float m[REP], l[REP], acc[REP][8];
+#pragma unroll
+        for (int h = 0; h < REP; ++h) {
+            m[h] = -INFINITY;
+            l[h] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[h][j] = 0.f;
+        }
+        auto step = [&](const float (&kf)[8], const float (&vf)[8]) {
+#pragma unroll
+            for (int h = 0; h < REP; ++h) {
+                float d = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d += q[h][j] * kf[j];
+                d += __shfl_xor(d, 1, 64);
+                d += __shfl_xor(d, 2, 64);
+                d += __shfl_xor(d, 4, 64);
+                d += __shfl_xor(d, 8, 64);
+                const float sc = d * a.scale;
+                const float mn = fmaxf(m[h], sc);
+                const float alpha = __expf(m[h] - mn);
+                const float pr = __expf(sc - mn);
+                l[h] = l[h] * alpha + pr;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[h][j] = acc[h][j] * alpha + pr * vf[j];
+                m[h] = mn;
+            }
+        };
+        const int len = len0 + (p - p0);  // tokens before this query: len0 from the cache, the rest from this chunk
+        for (int t = g; t <= len; t += NG) {
+            float kf[8], vf[8];
+            if (t < len0) {
+                const int page = a.identity_pages ? b : bt[t / kPageTokens];
+                const size_t off = (((size_t)page * a.n_kv + kvh) * kPageTokens + (t % kPageTokens)) * D + 8 * c;
+                const uint4 kr = *reinterpret_cast<const uint4*>(a.kpool + off);
+                const uint4 vr = *reinterpret_cast<const uint4*>(a.vpool + off);
+                kf[0] = lo_bf(kr.x); kf[1] = hi_bf(kr.x); kf[2] = lo_bf(kr.y); kf[3] = hi_bf(kr.y);
+                kf[4] = lo_bf(kr.z); kf[5] = hi_bf(kr.z); kf[6] = lo_bf(kr.w); kf[7] = hi_bf(kr.w);
+                vf[0] = lo_bf(vr.x); vf[1] = hi_bf(vr.x); vf[2] = lo_bf(vr.y); vf[3] = hi_bf(vr.y);
+                vf[4] = lo_bf(vr.z); vf[5] = hi_bf(vr.z); vf[6] = lo_bf(vr.w); vf[7] = hi_bf(vr.w);
+            } else {
+                const int e = p0 + (t - len0);  // chunk element that sits at position t
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    kf[j] = k_s[e][8 * c + j];
+                    vf[j] = v_s[e][8 * c + j];
+                }
+            }
+            step(kf, vf);
+        }
+#pragma unroll
+        for (int h = 0; h < REP; ++h) {
+            if (c == 0) {
+                m_s[g][h] = m[h];
+                l_s[g][h] = l[h];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc_s[g][h][8 * c + j] = acc[h][j];
+        }
+        __syncthreads();
+        for (int o = tid; o < REP * D; o += NTH) {
+            const int h = o / D, d = o % D;
+            float M = -INFINITY;
+#pragma unroll
+            for (int gg = 0; gg < NG; ++gg) M = fmaxf(M, m_s[gg][h]);
+            float num = 0.f, den = 0.f;
+#pragma unroll
+            for (int gg = 0; gg < NG; ++gg) {
+                const float w = (m_s[gg][h] == -INFINITY) ? 0.f : __expf(m_s[gg][h] - M);
+                num += acc_s[gg][h][d] * w;
+                den += l_s[gg][h] * w;
+            }
+            out_s[o] = f2bf(num / den);
+        }
+        __syncthreads();
+        for (int pc = tid; pc < REP * D / 8; pc += NTH) {
+            const int col = (kvh * REP) * D + 8 * pc;
+            *reinterpret_cast<uint4*>(a.out + act_tiled_offset(p * a.B + b, col, a.outMB)) = *reinterpret_cast<const uint4*>(out_s + 8 * pc);
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 void launch_attn_decode(const AttnArgs& a, hipStream_t st) {
     const int rep = a.n_heads / a.n_kv;
     Q3_CHECK(rep * a.n_kv == a.n_heads && rep >= 1 && rep <= kMaxRep, 3, "attn_decode: unsupported GQA ratio");
     dim3 grid(a.n_kv, a.B);
+    if (a.chunk > 1) {
+        Q3_CHECK(a.chunk <= 8, 3, "attn_decode: at most 8 positions per launch");
+#define Q3_ATTNC(R) \
+        if (a.max_pages == 1) hipLaunchKernelGGL((attn_chunk_kernel<R, 64, 8>), grid, dim3(64), 0, st, a); \
+        else hipLaunchKernelGGL((attn_chunk_kernel<R, 256, 8>), grid, dim3(256), 0, st, a)
+        switch (rep) {
+            case 1: Q3_ATTNC(1); break;
+            case 2: Q3_ATTNC(2); break;
+            case 3: Q3_ATTNC(3); break;
+            case 4: Q3_ATTNC(4); break;
+        }
+#undef Q3_ATTNC
+        return;
+    }
     // short caches (the code predictor never holds more than 17 tokens): one wave per (row, kv head), so the
     // workgroup barriers are free and nothing waits on other waves; long caches: 4 waves split the positions
 #define Q3_ATTN(R) \

@@ -167,6 +167,34 @@ __global__ __launch_bounds__(256) void prefill_load_kernel(PrefillLoadArgs a) {
     if (threadIdx.x == 0) a.ss_out[b] = tot;
 }
 
+// Chunked prefill: element p of row b is prompt position r = r_base + n_prompt[b] + p (right-aligned so that the last
+// chunk ends at the row's second-to-last prompt position); r < 0 is padding. Row m = p * B + b of the residual stream.
+__global__ __launch_bounds__(256) void prefill_chunk_load_kernel(PrefillLoadArgs a) {
+    __shared__ float sh[4];
+    const int b = blockIdx.x, p = blockIdx.y;
+    const int r = a.step + a.n_prompt[b] + p;  // `step` carries r_base
+    const bool on = r >= 0;
+    const int m = p * a.B + b;
+    const uint4* src = reinterpret_cast<const uint4*>(a.prompt + ((size_t)b * a.Pmax + (on ? r : 0)) * a.H);
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < a.H / 8; i += 256) {
+        const uint4 v = on ? src[i] : make_uint4(0, 0, 0, 0);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ss += lo_bf(w[j]) * lo_bf(w[j]) + hi_bf(w[j]) * hi_bf(w[j]);
+        *reinterpret_cast<uint4*>(a.h + act_tiled_offset(m, 8 * i, a.hMB)) = v;
+    }
+    const float tot = block_sum_256(ss, sh);
+    if (threadIdx.x == 0) a.ss_out[m] = tot;
+}
+__global__ void advance_len_chunk_kernel(int32_t* kv_len, const int32_t* n_prompt, int r_base, int C, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int r0 = r_base + n_prompt[b];
+    const int p0 = r0 < 0 ? (-r0 < C ? -r0 : C) : 0;
+    kv_len[b] += C - p0;
+}
+
 __global__ void advance_len_kernel(int32_t* kv_len, const uint8_t* active, int B) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B && (!active || active[b])) kv_len[b] += 1;
@@ -281,6 +309,12 @@ void launch_copy_rows(const uint16_t* src, int lds, uint16_t* dst, int ldd, int 
 }
 void launch_prefill_load(const PrefillLoadArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(prefill_load_kernel, dim3(a.B), dim3(256), 0, st, a);
+}
+void launch_prefill_chunk_load(const PrefillLoadArgs& a, int C, hipStream_t st) {
+    hipLaunchKernelGGL(prefill_chunk_load_kernel, dim3(a.B, C), dim3(256), 0, st, a);
+}
+void launch_advance_len_chunk(int32_t* kv_len, const int32_t* n_prompt, int r_base, int C, int B, hipStream_t st) {
+    hipLaunchKernelGGL(advance_len_chunk_kernel, dim3(1), dim3(64), 0, st, kv_len, n_prompt, r_base, C, B);
 }
 void launch_advance_len(int32_t* kv_len, const uint8_t* active, int B, hipStream_t st) {
     hipLaunchKernelGGL(advance_len_kernel, dim3(1), dim3(64), 0, st, kv_len, active, B);

@@ -351,7 +351,7 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(SamplerArgs a) {
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) ss += lo_bf(w[j]) * lo_bf(w[j]) + hi_bf(w[j]) * hi_bf(w[j]);
-            *reinterpret_cast<uint4*>(a.next_x + act_tiled_offset(b, 8 * i, a.next_MB)) = v;
+            *reinterpret_cast<uint4*>(a.next_x + act_tiled_offset(b + a.next_row0, 8 * i, a.next_MB)) = v;
         }
         if (a.next_ss) {  // sum of squares of the row: first (and only) partial of the consumer's norm prologue
             ss = wave_sum(ss);
