@@ -60,20 +60,22 @@ void launch_out_conv(const float* x, int C, const float* ea, const float* ib, co
 
 // ---- voice-clone front end (kernels/voice_frontend.hip) ------------------------------------------
 // first SEANet conv: 1 -> C channels, causal k taps (SpeechTokenizerEncoder.swift:404-414). w [C][K], out [S][C]
-void launch_enc_init_conv(const float* audio, int64_t S, const float* w, const float* bias, int C, int K, float* out,
-                          hipStream_t st);
+void launch_enc_init_conv(const float* audio, int64_t S, int B, const float* w, const float* bias, int C, int K, float* out,
+                          int64_t out_bstride, hipStream_t st);
 // LayerNorm with bias over the last dim (EncoderTransformerLayer norm1/norm2, :559-560)
-void launch_layernorm_f32(const float* x, const float* w, const float* b, float eps, int C, int T, float* out,
-                          hipStream_t st);
+void launch_layernorm_f32(const float* x, int64_t x_bstride, const float* w, const float* b, float eps, int C, int T, int B,
+                          float* out, int64_t out_bstride, hipStream_t st);
 // MLXNN.RoPE(traditional: false) on the q and k thirds of qkv [T][3*heads*64], in place (:505-508).
 // cos/sin [T][32] fp32 tables.
-void launch_rope_qk_f32(float* qkv, int heads, int T, const float* cos_t, const float* sin_t, hipStream_t st);
+void launch_rope_qk_f32(float* qkv, int heads, int T, int B, const float* cos_t, const float* sin_t, hipStream_t st);
 // causal variant of launch_attn_full_f32 (mask built at :1039-1043)
-void launch_attn_causal_f32(const float* qkv, int heads, int T, float* out, hipStream_t st);
+void launch_attn_causal_f32(const float* qkv, int heads, int T, int B, float* out, hipStream_t st);
 // EncoderResidualVectorQuantization.encode (:816-829) over `n_layers` codebooks: r -= emb[argmin(c2 - r.emb)].
-// x [T][ldx] (dim columns used), cb/c2 device pointer tables, codes out [(layer0 + j) * T + t].
-void launch_rvq_encode(const float* x, int ldx, int T, int dim, int bins, const float* const* cb, const float* const* c2,
-                       int n_layers, int32_t* codes, hipStream_t st);
+// x [T][ldx] (dim columns used), cb = device table of TRANSPOSED codebooks [dim][bins], c2 table, codes out [j * T + t].
+// Batch: row b has valid[b] frames (the batch is padded to Tmax) and writes codes[code_off[b] + (layer0 + j) * valid[b] + t].
+void launch_rvq_encode(const float* x, int ldx, int64_t x_bstride, int Tmax, int B, const int32_t* valid, const int64_t* code_off,
+                       int dim, int bins, const float* const* cb, const float* const* c2, int n_layers, int layer0,
+                       int32_t* codes, hipStream_t st);
 // power spectrum -> mel -> log (SpeakerEncoder.swift:437-452). spec [T][ld]: re in [0,nfreq), im in [nfreq,2*nfreq)
 void launch_log_mel(const float* spec, int ld, int T, int nfreq, const float* fb, int n_mels, float* out, hipStream_t st);
 // per-channel mean / variance over time (SqueezeExcitationBlock :146, AttentiveStatisticsPooling :243-245)
@@ -85,6 +87,8 @@ void launch_scale_res(const float* x, int ldx, const float* se, const float* res
 void launch_asp_concat(const float* x, const float* mean, const float* stdv, int T, int C, float* out, hipStream_t st);
 // softmax over time of att [T][C], weighted mean / std of x -> pooled [2C] (:262-270)
 void launch_asp_pool(const float* att, const float* x, int T, int C, float eps, float* pooled, hipStream_t st);
+// rows valid[b] .. Tpad-1 of clip b <- 0 (clips of a padded batch end at different positions)
+void launch_mask_tail(float* x, int64_t bstride, const int32_t* valid, int Tpad, int C, int B, hipStream_t st);
 void launch_copy2d_f32(const float* src, int lds, float* dst, int ldd, int T, int C, hipStream_t st);
 
 }  // namespace q3

@@ -40,6 +40,7 @@ Engine::Engine(Model* model, const q3tts_load_opts& opts) : m_(model), opts_(opt
     for (auto& e : ev_) Q3_HIP(hipEventCreate(&e));
     for (auto& e : burst_ev_) Q3_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : ev_fe_) Q3_HIP(hipEventCreate(&e));
+    Q3_HIP(hipEventCreateWithFlags(&fe_uploaded_, hipEventDisableTiming));
     Bm_ = opts.max_batch;
     Mp_ = 64;  // activation rows: up to 64 (batch rows x positions per launch), whatever the batch
     Pcap_ = opts.max_prompt;
@@ -96,6 +97,12 @@ Engine::~Engine() {
     for (auto& g : graphs_) (void)hipGraphExecDestroy(g.second);
     codec_.reset();
     fe_.reset();
+    for (auto& L : fe_lanes_) {
+        L.fe.reset();
+        if (L.spk) (void)hipFree(L.spk);
+        if (L.done) (void)hipEventDestroy(L.done);
+        if (L.st) (void)hipStreamDestroy(L.st);
+    }
     for (void* p : {(void*)ref_audio_dev_, (void*)ref_codes_dev_, (void*)extra_, (void*)spk_f32_, (void*)dec_codes_})
         if (p) (void)hipFree(p);
     if (ws_) (void)hipFree(ws_);
@@ -110,6 +117,7 @@ Engine::~Engine() {
         if (e) (void)hipEventDestroy(e);
     for (auto& e : ev_fe_)
         if (e) (void)hipEventDestroy(e);
+    if (fe_uploaded_) (void)hipEventDestroy(fe_uploaded_);
     if (st_) (void)hipStreamDestroy(st_);
 }
 
@@ -701,21 +709,69 @@ void Engine::prepare_clone_rows(std::vector<ResolvedRequest>& reqs) {
         Q3_HIP(hipMalloc(reinterpret_cast<void**>(&extra_), total_rows * H * 2));
         extra_cap_ = total_rows;
     }
-    if (!spk_f32_) Q3_HIP(hipMalloc(reinterpret_cast<void**>(&spk_f32_), size_t(H) * 4));
+    int n_clone = 0;
+    for (auto& r : reqs) n_clone += r.clone ? 1 : 0;
+    const int K = std::min(4, n_clone);
+    while (int(fe_lanes_.size()) < K) {
+        FeLane L;
+        Q3_HIP(hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking));
+        Q3_HIP(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+        L.fe = std::make_unique<VoiceFrontEnd>(*m_, L.st);
+        Q3_HIP(hipMalloc(reinterpret_cast<void**>(&L.spk), size_t(H) * 4));
+        fe_lanes_.push_back(std::move(L));
+    }
+    // every clip zero-padded to the longest one: the (causal) codec encoder then runs ONCE over all of them
+    int64_t S_max = 0;
+    for (auto& r : reqs)
+        if (r.clone) S_max = std::max<int64_t>(S_max, r.n_ref_samples);
+    if (size_t(S_max) * n_clone > ref_audio_cap_) {
+        Q3_HIP(hipStreamSynchronize(st_));
+        if (ref_audio_dev_) Q3_HIP(hipFree(ref_audio_dev_));
+        ref_audio_dev_ = nullptr;
+        Q3_HIP(hipMalloc(reinterpret_cast<void**>(&ref_audio_dev_), size_t(S_max) * n_clone * 4));
+        ref_audio_cap_ = size_t(S_max) * n_clone;
+    }
+    Q3_HIP(hipMemsetAsync(ref_audio_dev_, 0, size_t(S_max) * n_clone * 4, st_));
+    std::vector<int64_t> valid, offs;  // samples per clip, offset of its codes
+    int i = 0;
     for (auto& r : reqs) {
         if (!r.clone) continue;
-        const float* a = upload_audio(r.ref_audio, r.n_ref_samples);
-        const int T = fe_->encode(a, r.n_ref_samples, ref_codes_dev_ + r.ref_off);
-        Q3_CHECK(T == r.ref_T, 7, "internal error: reference frame count");
-        uint16_t* rows = extra_ + size_t(r.extra_base) * H;
-        if (m_->has_speaker_encoder) {
-            // The x-vector is fp32; it enters the prompt in the talker's storage dtype like every other row
-            // (DESIGN.md section 3: the reference's MLX concat would instead promote the prompt to fp32).
-            fe_->speaker_embedding(a, r.n_ref_samples, spk_f32_);
-            launch_f32_to_bf16(spk_f32_, rows, H, st_);
-        }
-        launch_ref_embed_rows(ref_codes_dev_ + r.ref_off, T, 16, m_->codec_emb, m_->cp_emb_dev, H, rows + H, H, st_);
+        Q3_HIP(hipMemcpyAsync(ref_audio_dev_ + size_t(i) * S_max, r.ref_audio, size_t(r.n_ref_samples) * 4, hipMemcpyHostToDevice, st_));
+        valid.push_back(r.n_ref_samples);
+        offs.push_back(r.ref_off);
+        ++i;
     }
+    Q3_HIP(hipEventRecord(fe_uploaded_, st_));
+    // speaker x-vectors: not causal (reflect padding, statistics over the whole clip), so one clip at a time, a few side by side
+    if (m_->has_speaker_encoder) {
+        i = 0;
+        for (auto& r : reqs) {
+            if (!r.clone) continue;
+            FeLane& L = fe_lanes_[size_t(i % K)];
+            if (i < K) Q3_HIP(hipStreamWaitEvent(L.st, fe_uploaded_, 0));
+            // The x-vector is fp32; it enters the prompt in the talker's storage dtype like every other row
+            // (DESIGN.md section 7: the reference's MLX concat would instead promote the prompt to fp32).
+            L.fe->speaker_embedding(ref_audio_dev_ + size_t(i) * S_max, r.n_ref_samples, L.spk);
+            launch_f32_to_bf16(L.spk, extra_ + size_t(r.extra_base) * H, H, L.st);
+            ++i;
+        }
+    }
+    const size_t per_clip = size_t(S_max) * 64 * 4 * 3 + (size_t(1) << 20);  // rough scratch per clip (bytes)
+    const int rows_per_pass = int(std::max<size_t>(1, std::min<size_t>(VoiceFrontEnd::kMaxClips, (size_t(16) << 30) / per_clip)));
+    for (int lo = 0; lo < n_clone; lo += rows_per_pass) {
+        const int nb = std::min(rows_per_pass, n_clone - lo);
+        fe_->encode_batch(ref_audio_dev_ + size_t(lo) * S_max, nb, S_max, valid.data() + lo, offs.data() + lo, ref_codes_dev_);
+    }
+    for (auto& r : reqs) {
+        if (!r.clone) continue;
+        launch_ref_embed_rows(ref_codes_dev_ + r.ref_off, r.ref_T, 16, m_->codec_emb, m_->cp_emb_dev, H,
+                              extra_ + size_t(r.extra_base + 1) * H, H, st_);
+    }
+    if (m_->has_speaker_encoder)
+        for (int k = 0; k < K; ++k) {  // the prompt assembly on st_ follows every lane
+            Q3_HIP(hipEventRecord(fe_lanes_[size_t(k)].done, fe_lanes_[size_t(k)].st));
+            Q3_HIP(hipStreamWaitEvent(st_, fe_lanes_[size_t(k)].done, 0));
+        }
 }
 
 int Engine::encoded_frames(int64_t n_samples) const {

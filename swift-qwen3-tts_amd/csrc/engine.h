@@ -86,6 +86,7 @@ class Engine {
     hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t burst_ev_[2] = {nullptr, nullptr};
     hipEvent_t ev_fe_[2] = {nullptr, nullptr};
+    hipEvent_t fe_uploaded_ = nullptr;
     int Bm_ = 0, Mp_ = 0;  // max batch, padded to 16
     int Pcap_ = 0, Tcap_ = 0, Fcap_ = 0, max_pages_ = 0, n_pages_ = 0;
 
@@ -130,6 +131,15 @@ class Engine {
     float* spk_f32_ = nullptr;
     int32_t* dec_codes_ = nullptr;  // [n][Fdec][16]: reference ++ generated codes for the decoder
     size_t dec_codes_cap_ = 0;
+    // Clone rows are independent and their front-end kernels are small: a few of them run side by side, each on its
+    // own stream with its own scratch.
+    struct FeLane {
+        hipStream_t st = nullptr;
+        hipEvent_t done = nullptr;
+        std::unique_ptr<VoiceFrontEnd> fe;
+        float* spk = nullptr;
+    };
+    std::vector<FeLane> fe_lanes_;
     const float* upload_audio(const float* audio, int64_t n);
     void prepare_clone_rows(std::vector<ResolvedRequest>& reqs);
 

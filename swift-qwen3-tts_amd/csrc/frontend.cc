@@ -33,14 +33,14 @@ struct Carver {  // bump allocator over the scratch block; first pass (base == n
 }  // namespace
 
 VoiceFrontEnd::VoiceFrontEnd(const Model& m, hipStream_t st) : m_(m), st_(st) {
-    const int32_t one = 1;
-    Q3_HIP(hipMalloc(reinterpret_cast<void**>(&one_dev_), 4));
-    Q3_HIP(hipMemcpy(one_dev_, &one, 4, hipMemcpyHostToDevice));
+    std::vector<int32_t> ones(size_t(kMaxClips), 1);
+    Q3_HIP(hipMalloc(reinterpret_cast<void**>(&ones_dev_), ones.size() * 4));
+    Q3_HIP(hipMemcpy(ones_dev_, ones.data(), ones.size() * 4, hipMemcpyHostToDevice));
 }
 
 VoiceFrontEnd::~VoiceFrontEnd() {
     if (buf_) (void)hipFree(buf_);
-    if (one_dev_) (void)hipFree(one_dev_);
+    if (ones_dev_) (void)hipFree(ones_dev_);
 }
 
 void VoiceFrontEnd::ensure(size_t bytes) {
@@ -68,22 +68,41 @@ int VoiceFrontEnd::encoded_frames(int64_t n_samples) const {
     return streamable_out_len(T, 2 * e.ds, e.ds, 1);
 }
 
-// One conv_gemm launch over a single utterance of T positions.
-static void conv1(const ConvW& w, const float* x, int ldx, int T, float* out, int ldo, hipStream_t st, const int32_t* one,
-                  int act = 0, int pre_act = 0, const float* res = nullptr, int ldr = 0, int shift = 0, int reflect = 0,
-                  const float* x2 = nullptr, int ldx2 = 0) {
+// One conv_gemm launch over B utterances of T positions each (row b at x + b * x_bstride).
+static void convB(const ConvW& w, const float* x, int ldx, int64_t x_bs, int T, int B, float* out, int ldo, int64_t out_bs,
+                  hipStream_t st, const int32_t* ones, int act = 0, int pre_act = 0, const float* res = nullptr, int ldr = 0,
+                  int64_t res_bs = 0, int shift = 0, int reflect = 0, const float* x2 = nullptr, int ldx2 = 0) {
     ConvGemmArgs a{};
-    a.x = x; a.ldx = ldx; a.w = w.w; a.bias = w.bias; a.scale = w.scale; a.res = res; a.ldr = ldr;
-    a.out = out; a.ldo = ldo; a.frames = one; a.ppf = T; a.Tmax = T; a.B = 1;
+    a.x = x; a.ldx = ldx; a.x_bstride = x_bs; a.w = w.w; a.bias = w.bias; a.scale = w.scale;
+    a.res = res; a.ldr = ldr; a.res_bstride = res_bs;
+    a.out = out; a.ldo = ldo; a.out_bstride = out_bs; a.frames = ones; a.ppf = T; a.Tmax = T; a.B = B;
     a.Cin = w.Cin; a.N = w.N; a.K = w.K; a.dil = w.dil; a.act = act; a.pre_act = pre_act;
     a.shift = shift; a.reflect = reflect; a.x2 = x2; a.ldx2 = ldx2;
     launch_conv_gemm(a, st);
 }
+static void conv1(const ConvW& w, const float* x, int ldx, int T, float* out, int ldo, hipStream_t st, const int32_t* one,
+                  int act = 0, int pre_act = 0, const float* res = nullptr, int ldr = 0, int shift = 0, int reflect = 0,
+                  const float* x2 = nullptr, int ldx2 = 0) {
+    convB(w, x, ldx, 0, T, 1, out, ldo, 0, st, one, act, pre_act, res, ldr, 0, shift, reflect, x2, ldx2);
+}
 
 int VoiceFrontEnd::encode(const float* audio_dev, int64_t n_samples, int32_t* codes_dev, StageCapture* cap) {
+    const int64_t off = 0;
+    encode_batch(audio_dev, 1, n_samples, &n_samples, &off, codes_dev, cap);
+    return encoded_frames(n_samples);
+}
+
+// The encoder is causal end to end (SEANet convs, transformer mask, downsample conv; the RVQ search is per frame), so
+// clips of different lengths can share one pass: each is zero-padded on the right to the longest (the reference pads
+// its own clip with zeros on the right as well, SpeechTokenizerEncoder.swift:184) and only its first valid_T[b] frames
+// are searched and written. Every launch then covers all clips: the small weight-bound GEMMs of the transformer and the
+// late SEANet stages stream their weights once instead of once per clip.
+void VoiceFrontEnd::encode_batch(const float* audio_dev, int B, int64_t n_samples, const int64_t* clip_samples,
+                                 const int64_t* code_off, int32_t* codes_dev, StageCapture* cap) {
     const CodecEncW& e = m_.codec_enc;
     Q3_CHECK(m_.has_codec_encoder, 1, "Model not initialized: Speech tokenizer encoder not available");  // Qwen3.swift:432-434
     Q3_CHECK(n_samples >= 1 && n_samples <= (int64_t(1) << 24), 3, "Invalid input: reference audio must hold 1 .. 2^24 samples");
+    Q3_CHECK(B >= 1 && B <= kMaxClips, 3, "Invalid input: too many clips in one encoder pass");
     const int S = int(n_samples);
     // ---- lengths per stage
     std::vector<int> Ts{S};
@@ -97,8 +116,8 @@ int VoiceFrontEnd::encode(const float* audio_dev, int64_t n_samples, int32_t* co
     Q3_CHECK(Tq == (Te + e.ds - 1) / e.ds, 7, "internal error: downsample length");
     Q3_CHECK(Te <= e.max_T, 3, "Invalid input: reference audio longer than the encoder's max_position_embeddings");
     const int H = e.hidden, I = e.tlayers.empty() ? H : e.tlayers[0].fc1.N;
-    // ---- scratch
-    size_t pp = 0;  // floats of the larger SEANet tensor, with room for one padded row group
+    // ---- scratch: per-clip strides leave room for one padded row group behind the data
+    size_t pp = 0;
     {
         int C = e.init_C;
         for (size_t i = 0; i < e.layers.size(); ++i) {
@@ -109,65 +128,88 @@ int VoiceFrontEnd::encode(const float* audio_dev, int64_t n_samples, int32_t* co
     }
     Carver cv;
     float *bufA, *bufB, *xn, *qkv, *ao, *h1, *proj;
+    int32_t* valid_dev;  // [stages + 2][B]: each clip's own length at every stage
+    int64_t* off_dev;
+    const int NS = int(e.layers.size()) + 2;
     auto carve = [&]() {
-        bufA = cv.f32(pp);
-        bufB = cv.f32(pp);
-        xn = cv.f32(size_t(Te) * H);
-        qkv = cv.f32(size_t(Te) * 3 * H);
-        ao = cv.f32(size_t(Te) * H);
-        h1 = cv.f32(size_t(Te) * I);
-        proj = cv.f32(size_t(Tq) * 2 * e.dim);
+        bufA = cv.f32(pp * B);
+        bufB = cv.f32(pp * B);
+        xn = cv.f32(size_t(Te) * H * B);
+        qkv = cv.f32(size_t(Te) * 3 * H * B);
+        ao = cv.f32(size_t(Te) * H * B);
+        h1 = cv.f32(size_t(Te) * I * B);
+        proj = cv.f32(size_t(Tq) * 2 * e.dim * B);
+        valid_dev = reinterpret_cast<int32_t*>(cv.f32(size_t(B) * NS));
+        off_dev = reinterpret_cast<int64_t*>(cv.f32(size_t(2) * B));
     };
     carve();
     ensure(cv.off);
     cv = Carver{buf_, 0};
     carve();
+    std::vector<int32_t> valid(size_t(B) * NS);  // stage 0: samples; 1..4: after each SEANet layer; last: output frames
+    for (int b = 0; b < B; ++b) {
+        Q3_CHECK(clip_samples[b] >= 1 && clip_samples[b] <= n_samples, 7, "internal error: clip longer than the padded batch");
+        int v = int(clip_samples[b]);
+        valid[size_t(b)] = v;
+        for (size_t i = 0; i < e.layers.size(); ++i) {
+            v = streamable_out_len(v, 2 * e.layers[i].ratio, e.layers[i].ratio, 1);
+            valid[(i + 1) * B + b] = v;
+        }
+        valid[size_t(NS - 1) * B + b] = streamable_out_len(v, 2 * e.ds, e.ds, 1);
+    }
+    Q3_HIP(hipMemcpyAsync(valid_dev, valid.data(), valid.size() * 4, hipMemcpyHostToDevice, st_));
+    Q3_HIP(hipMemcpyAsync(off_dev, code_off, size_t(B) * 8, hipMemcpyHostToDevice, st_));
+    Q3_HIP(hipStreamSynchronize(st_));  // caller memory
+    const int64_t bs = int64_t(pp);     // clip stride of the two big buffers, in floats
+    // rows behind each clip's own end, up to the whole stride group the next strided conv reads
+    auto zero_tail = [&](float* base, int stage, int Tpad, int C) { launch_mask_tail(base, bs, valid_dev + size_t(stage) * B, Tpad, C, B, st_); };
 
     // ---- SEANet (SpeechTokenizerEncoder.swift:436-443)
     float *cur = bufA, *oth = bufB;
-    launch_enc_init_conv(audio_dev, S, e.init_w, e.init_b, e.init_C, e.init_K, cur, st_);
+    launch_enc_init_conv(audio_dev, S, B, e.init_w, e.init_b, e.init_C, e.init_K, cur, bs, st_);
     capture(cap, "init_conv", cur, S, e.init_C, e.init_C);
     for (size_t i = 0; i < e.layers.size(); ++i) {
         const auto& L = e.layers[i];
         const int T = Ts[i], Tn = Ts[i + 1], C = L.C;
-        conv1(L.res1, cur, C, T, oth, L.res1.N, st_, one_dev_, 0, /*ELU*/ 1);              // :338-339, k3
-        conv1(L.res2, oth, L.res1.N, T, cur, C, st_, one_dev_, 0, 1, /*skip*/ cur, C);        // k1 + residual (:345)
-        if (Tn * L.ratio > T)  // right zero padding up to a whole stride group (:114-118, :184)
-            Q3_HIP(hipMemsetAsync(cur + size_t(T) * C, 0, size_t(Tn * L.ratio - T) * C * sizeof(float), st_));
-        conv1(L.down, cur, L.ratio * C, Tn, oth, L.down.N, st_, one_dev_, 0, 1);              // ELU, k=2r stride r (:389)
+        convB(L.res1, cur, C, bs, T, B, oth, L.res1.N, bs, st_, ones_dev_, 0, /*ELU*/ 1);                 // :338-339, k3
+        convB(L.res2, oth, L.res1.N, bs, T, B, cur, C, bs, st_, ones_dev_, 0, 1, /*skip*/ cur, C, bs);     // k1 + residual (:345)
+        zero_tail(cur, int(i), Tn * L.ratio, C);  // right zero padding up to a whole stride group (:114-118, :184)
+        convB(L.down, cur, L.ratio * C, bs, Tn, B, oth, L.down.N, bs, st_, ones_dev_, 0, 1);              // ELU, k=2r stride r (:389)
         std::swap(cur, oth);
         if (cap && cap->name == "layer" + std::to_string(i)) capture(cap, cap->name.c_str(), cur, Tn, L.down.N, L.down.N);
     }
-    conv1(e.final_conv, cur, e.final_conv.Cin, Te, oth, H, st_, one_dev_, 0, 1);  // ELU + k3 (:441-442)
+    convB(e.final_conv, cur, e.final_conv.Cin, bs, Te, B, oth, H, bs, st_, ones_dev_, 0, 1);  // ELU + k3 (:441-442)
     std::swap(cur, oth);
     capture(cap, "seanet", cur, Te, H, H);
 
-    // ---- causal transformer (:571-590), x lives in `cur`
+    // ---- causal transformer (:571-590), x lives in `cur` (clip stride bs); the other tensors are dense [B][Te][.]
+    const int64_t ts = int64_t(Te);
     for (const auto& L : e.tlayers) {
-        launch_layernorm_f32(cur, L.ln1_w, L.ln1_b, 1e-5f, H, Te, xn, st_);
-        conv1(L.qkv, xn, H, Te, qkv, 3 * H, st_, one_dev_);
-        launch_rope_qk_f32(qkv, e.heads, Te, e.rope_cos, e.rope_sin, st_);
-        launch_attn_causal_f32(qkv, e.heads, Te, ao, st_);
-        conv1(L.o, ao, H, Te, cur, H, st_, one_dev_, 0, 0, cur, H);  // x + layer_scale_1 * o_proj(attn)
-        launch_layernorm_f32(cur, L.ln2_w, L.ln2_b, 1e-5f, H, Te, xn, st_);
-        conv1(L.fc1, xn, H, Te, h1, I, st_, one_dev_, /*gelu tanh*/ 2);
-        conv1(L.fc2, h1, I, Te, cur, H, st_, one_dev_, 0, 0, cur, H);  // x + layer_scale_2 * linear2(...)
+        launch_layernorm_f32(cur, bs, L.ln1_w, L.ln1_b, 1e-5f, H, Te, B, xn, ts * H, st_);
+        convB(L.qkv, xn, H, ts * H, Te, B, qkv, 3 * H, ts * 3 * H, st_, ones_dev_);
+        launch_rope_qk_f32(qkv, e.heads, Te, B, e.rope_cos, e.rope_sin, st_);
+        launch_attn_causal_f32(qkv, e.heads, Te, B, ao, st_);
+        convB(L.o, ao, H, ts * H, Te, B, cur, H, bs, st_, ones_dev_, 0, 0, cur, H, bs);  // x + layer_scale_1 * o_proj(attn)
+        launch_layernorm_f32(cur, bs, L.ln2_w, L.ln2_b, 1e-5f, H, Te, B, xn, ts * H, st_);
+        convB(L.fc1, xn, H, ts * H, Te, B, h1, I, ts * I, st_, ones_dev_, /*gelu tanh*/ 2);
+        convB(L.fc2, h1, I, ts * I, Te, B, cur, H, bs, st_, ones_dev_, 0, 0, cur, H, bs);  // x + layer_scale_2 * linear2(...)
     }
     capture(cap, "transformer", cur, Te, H, H);
 
     // ---- stride-ds conv (no bias) and the two input projections (:1049-1052, :870-875)
-    if (Tq * e.ds > Te) Q3_HIP(hipMemsetAsync(cur + size_t(Te) * H, 0, size_t(Tq * e.ds - Te) * H * sizeof(float), st_));
-    conv1(e.down, cur, e.ds * H, Tq, oth, H, st_, one_dev_);
+    zero_tail(cur, int(e.layers.size()), Tq * e.ds, H);
+    convB(e.down, cur, e.ds * H, bs, Tq, B, oth, H, bs, st_, ones_dev_);
     capture(cap, "downsample", oth, Tq, H, H);
-    conv1(e.rvq_in, oth, H, Tq, proj, 2 * e.dim, st_, one_dev_);
+    const int64_t ps = int64_t(Tq) * 2 * e.dim;
+    convB(e.rvq_in, oth, H, bs, Tq, B, proj, 2 * e.dim, ps, st_, ones_dev_);
     capture(cap, "rvq_first_in", proj, Tq, e.dim, 2 * e.dim);
     capture(cap, "rvq_rest_in", proj + e.dim, Tq, e.dim, 2 * e.dim);
     // ---- nearest-neighbour search: the semantic layer on its projection, the acoustic layers on theirs (:934-941)
-    launch_rvq_encode(proj, 2 * e.dim, Tq, e.dim, e.bins, e.cb_dev, e.c2_dev, 1, codes_dev, st_);
+    const int32_t* vq = valid_dev + size_t(NS - 1) * B;
+    launch_rvq_encode(proj, 2 * e.dim, ps, Tq, B, vq, off_dev, e.dim, e.bins, e.cb_dev, e.c2_dev, 1, 0, codes_dev, st_);
     if (e.n_layers > 1)
-        launch_rvq_encode(proj + e.dim, 2 * e.dim, Tq, e.dim, e.bins, e.cb_dev + 1, e.c2_dev + 1, e.n_layers - 1,
-                          codes_dev + Tq, st_);
-    return Tq;
+        launch_rvq_encode(proj + e.dim, 2 * e.dim, ps, Tq, B, vq, off_dev, e.dim, e.bins, e.cb_dev + 1, e.c2_dev + 1,
+                          e.n_layers - 1, 1, codes_dev, st_);
 }
 
 void VoiceFrontEnd::speaker_embedding(const float* audio_dev, int64_t n_samples, float* emb_dev, StageCapture* cap) {
@@ -208,14 +250,14 @@ void VoiceFrontEnd::speaker_embedding(const float* audio_dev, int64_t n_samples,
     // ---- log-mel (SpeakerEncoder.swift:410-456): frames are overlapping rows of the padded signal (row stride = hop)
     Q3_HIP(hipMemsetAsync(padded, 0, size_t(P) * sizeof(float), st_));
     Q3_HIP(hipMemcpyAsync(padded + s.n_fft / 2, audio_dev, size_t(S) * sizeof(float), hipMemcpyDeviceToDevice, st_));
-    conv1(s.dft, padded, s.hop, T, spec, s.dft.N, st_, one_dev_);
+    conv1(s.dft, padded, s.hop, T, spec, s.dft.N, st_, ones_dev_);
     launch_log_mel(spec, s.dft.N, T, s.nfreq, s.mel_fb, s.n_mels, mel, st_);
     capture(cap, "mel", mel, T, s.n_mels, s.n_mels);
 
     // ---- ECAPA-TDNN (SpeakerEncoder.swift:364-394). TimeDelayNetBlock = reflect pad + conv + ReLU (:62-69)
     auto tdnn = [&](const ConvW& w, const float* x, int ldx, float* out, int ldo, const float* x2 = nullptr, int ldx2 = 0, int act = 3) {
         const int pad = (w.K - 1) * w.dil / 2;
-        conv1(w, x, ldx, T, out, ldo, st_, one_dev_, act, 0, nullptr, 0, pad, pad > 0 ? 1 : 0, x2, ldx2);
+        conv1(w, x, ldx, T, out, ldo, st_, ones_dev_, act, 0, nullptr, 0, pad, pad > 0 ? 1 : 0, x2, ldx2);
     };
     tdnn(s.b0, mel, s.n_mels, h0, C);
     capture(cap, "h0", h0, T, C, C);
@@ -231,8 +273,8 @@ void VoiceFrontEnd::speaker_embedding(const float* audio_dev, int64_t n_samples,
         tdnn(B.tdnn2, b2, C, b1, C);
         // SqueezeExcitationBlock (:143-155): mean over time -> conv1 + ReLU -> conv2 + sigmoid
         launch_time_stats(b1, C, T, C, v_mean, nullptr, 0.f, st_);
-        conv1(B.se1, v_mean, C, 1, v_s1, SE, st_, one_dev_, 3);
-        conv1(B.se2, v_s1, SE, 1, v_se, C, st_, one_dev_, 4);
+        conv1(B.se1, v_mean, C, 1, v_s1, SE, st_, ones_dev_, 3);
+        conv1(B.se2, v_s1, SE, 1, v_se, C, st_, ones_dev_, 4);
         float* hout = cat + bi * C;
         launch_scale_res(b1, C, v_se, hin, ld_in, hout, 3 * C, T, C, st_);  // x * se + residual (:154, :210)
         if (cap && cap->name == "h" + std::to_string(bi + 1)) capture(cap, cap->name.c_str(), hout, T, C, 3 * C);
@@ -245,10 +287,10 @@ void VoiceFrontEnd::speaker_embedding(const float* audio_dev, int64_t n_samples,
     launch_time_stats(mfa, C4, T, C4, v_mean, v_std, 1e-12f, st_);
     launch_asp_concat(mfa, v_mean, v_std, T, C4, att_in, st_);
     tdnn(s.asp_tdnn, att_in, 3 * C4, a1, A, nullptr, 0, /*tanh(relu)*/ 5);
-    conv1(s.asp_conv, a1, A, T, a2, C4, st_, one_dev_);
+    conv1(s.asp_conv, a1, A, T, a2, C4, st_, ones_dev_);
     launch_asp_pool(a2, mfa, T, C4, 1e-12f, pooled, st_);
     capture(cap, "pooled", pooled, 1, 2 * C4, 2 * C4);
-    conv1(s.fc, pooled, 2 * C4, 1, emb_dev, s.enc_dim, st_, one_dev_);  // :385-391
+    conv1(s.fc, pooled, 2 * C4, 1, emb_dev, s.enc_dim, st_, ones_dev_);  // :385-391
 }
 
 }  // namespace q3

@@ -24,6 +24,12 @@ class VoiceFrontEnd {
     int encoded_frames(int64_t n_samples) const;
     // audio_dev [n_samples] fp32 on the device -> codes_dev [16][T] int32 (row-major by code row); returns T
     int encode(const float* audio_dev, int64_t n_samples, int32_t* codes_dev, StageCapture* cap = nullptr);
+    // B clips in one pass: audio_dev [B][n_samples], every clip zero-padded on the right to n_samples; clip b holds
+    // clip_samples[b] samples and its encoded_frames(clip_samples[b]) frames are written as [16][frames] at
+    // codes_dev + code_off[b] (host arrays)
+    static constexpr int kMaxClips = 64;
+    void encode_batch(const float* audio_dev, int B, int64_t n_samples, const int64_t* clip_samples, const int64_t* code_off,
+                      int32_t* codes_dev, StageCapture* cap = nullptr);
     // audio_dev -> emb_dev [enc_dim] fp32
     void speaker_embedding(const float* audio_dev, int64_t n_samples, float* emb_dev, StageCapture* cap = nullptr);
 
@@ -32,7 +38,7 @@ class VoiceFrontEnd {
     hipStream_t st_;
     uint8_t* buf_ = nullptr;
     size_t buf_bytes_ = 0;
-    int32_t* one_dev_ = nullptr;  // frames[0] = 1: conv_gemm addresses rows as frames[b] * ppf
+    int32_t* ones_dev_ = nullptr;  // frames[b] = 1: conv_gemm addresses rows as frames[b] * ppf
     void ensure(size_t bytes);
     void capture(StageCapture* cap, const char* name, const float* t, int T, int C, int ld);
 };

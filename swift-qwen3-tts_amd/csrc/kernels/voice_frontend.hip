@@ -7,6 +7,8 @@
 // (codec_conv.hip). These stages run once per request on a few hundred positions: they are written for
 // correctness and coalesced access, not tuned against a roofline.
 // Activations are fp32 channels-last [T][C], one utterance at a time.
+#include <algorithm>
+
 #include "../common.h"
 #include "../codec_kernels.h"
 
@@ -23,8 +25,10 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {  // blockDim.x 
 
 // out[t][c] = bias[c] + sum_k w[c][k] * audio[t - (K-1) + k]   (zero left padding; stride 1 needs no right padding)
 __global__ __launch_bounds__(256) void enc_init_conv_kernel(const float* audio, int64_t S, const float* w, const float* bias,
-                                                            int C, int K, float* out) {
+                                                            int C, int K, float* out, int64_t out_bstride) {
     __shared__ float xs[256 + 16];
+    audio += (int64_t)blockIdx.y * S;
+    out += (int64_t)blockIdx.y * out_bstride;
     const int64_t t0 = (int64_t)blockIdx.x * 256;
     for (int i = threadIdx.x; i < 256 + K - 1; i += 256) {
         const int64_t t = t0 - (K - 1) + i;
@@ -40,11 +44,11 @@ __global__ __launch_bounds__(256) void enc_init_conv_kernel(const float* audio, 
     }
 }
 
-__global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* x, const float* w, const float* b, float eps, int C,
-                                                            float* out) {
+__global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* x, int64_t x_bstride, const float* w, const float* b,
+                                                            float eps, int C, float* out, int64_t out_bstride) {
     __shared__ float sh[4];
-    const float* xr = x + (size_t)blockIdx.x * C;
-    float* orow = out + (size_t)blockIdx.x * C;
+    const float* xr = x + (size_t)blockIdx.y * x_bstride + (size_t)blockIdx.x * C;
+    float* orow = out + (size_t)blockIdx.y * out_bstride + (size_t)blockIdx.x * C;
     float s = 0.f;
     for (int i = threadIdx.x; i < C; i += 256) s += xr[i];
     const float mean = block_sum(s, sh) / (float)C;
@@ -62,7 +66,7 @@ __global__ void rope_qk_f32_kernel(float* qkv, int heads, int T, const float* co
     if (idx >= T * per_t) return;
     const int t = idx / per_t, r = idx % per_t;
     const int hh = r >> 5, d = r & 31;  // hh in [0, 2*heads): q heads then k heads (contiguous in qkv)
-    float* p = qkv + (size_t)t * 3 * heads * 64 + hh * 64;
+    float* p = qkv + ((size_t)blockIdx.y * T + t) * 3 * heads * 64 + hh * 64;
     const float c = cos_t[t * 32 + d], s = sin_t[t * 32 + d];
     const float x1 = p[d], x2 = p[d + 32];
     p[d] = x1 * c - x2 * s;
@@ -77,6 +81,8 @@ __global__ __launch_bounds__(64) void attn_causal_f32_kernel(const float* qkv, i
     const int h = blockIdx.y;
     const int q0 = blockIdx.x * 64;
     const int ld = 3 * heads * Dh;
+    qkv += (size_t)blockIdx.z * T * ld;
+    out += (size_t)blockIdx.z * T * heads * Dh;
     const int qi = q0 + threadIdx.x;
     const bool qvalid = qi < T;
     float q[Dh], acc[Dh];
@@ -124,32 +130,68 @@ __global__ __launch_bounds__(64) void attn_causal_f32_kernel(const float* qkv, i
     }
 }
 
-// One workgroup per frame. The residual lives in LDS; every thread scans bins tid, tid+256, ... with the
-// oracle's summation order (sequential, unfused multiply-add), then the block picks the smallest distance,
-// lowest index on ties (argMin), and subtracts that code vector.
-__global__ __launch_bounds__(256) void rvq_encode_kernel(const float* x, int ldx, int T, int dim, int bins,
-                                                         const float* const* cb, const float* const* c2, int n_layers,
-                                                         int32_t* codes) {
+// One workgroup per frame. The residual lives in LDS; every thread scans bins tid, tid+256, ... with the oracle's
+// summation order (sequential over the dimensions, unfused multiply-add), then the block picks the smallest distance,
+// lowest index on ties (argMin), and subtracts that code vector. The codebooks are stored transposed, [dim][bins], so
+// that the 64 lanes of a wave read 64 consecutive floats per dimension (row-major rows are 1 KiB apart: one cache
+// line per lane per load made this kernel 40 % of the encoder's time).
+__global__ __launch_bounds__(256) void rvq_encode_kernel(const float* x, int ldx, int64_t x_bstride, const int32_t* valid,
+                                                         const int64_t* code_off, int dim, int bins,
+                                                         const float* const* cbt, const float* const* c2, int n_layers,
+                                                         int layer0, int32_t* codes) {
     extern __shared__ float rs[];  // [dim]
     __shared__ float bv[4];
     __shared__ int bi[4];
     __shared__ int best_s;
-    const int t = blockIdx.x;
+    const int t = blockIdx.x, row = blockIdx.y;
+    const int T = valid[row];  // frames of this clip (the batch is padded to a common length)
+    if (t >= T) return;
+    x += (size_t)row * x_bstride;
+    codes += code_off[row] + (size_t)layer0 * T;
     for (int d = threadIdx.x; d < dim; d += 256) rs[d] = x[(size_t)t * ldx + d];
     __syncthreads();
     for (int layer = 0; layer < n_layers; ++layer) {
-        const float* emb = cb[layer];
+        const float* embt = cbt[layer];
         const float* cc = c2[layer];
         float best = INFINITY;
         int besti = 0x7fffffff;
-        for (int j = threadIdx.x; j < bins; j += 256) {
-            const float* e = emb + (size_t)j * dim;
-            float dot = 0.f;
-            for (int d = 0; d < dim; ++d) dot = __fadd_rn(dot, __fmul_rn(rs[d], e[d]));
-            const float dist = __fsub_rn(cc[j], dot);
-            if (dist < best) {  // j ascends per thread: strict < keeps the lowest index
-                best = dist;
-                besti = j;
+        for (int j0 = 0; j0 < bins; j0 += 1024) {  // four bins per thread at a time: four independent add chains
+            float dot[4] = {0.f, 0.f, 0.f, 0.f};
+            int jj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) jj[u] = j0 + u * 256 + threadIdx.x;
+            int d = 0;
+            for (; d + 8 <= dim; d += 8) {  // 32 loads in flight, then the adds in dimension order
+                float e[8][4];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float* row = embt + (size_t)(d + k) * bins;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) e[k][u] = jj[u] < bins ? row[jj[u]] : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float r = rs[d + k];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) dot[u] = __fadd_rn(dot[u], __fmul_rn(r, e[k][u]));
+                }
+            }
+            for (; d < dim; ++d) {
+                const float r = rs[d];
+                const float* row = embt + (size_t)d * bins;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (jj[u] < bins) dot[u] = __fadd_rn(dot[u], __fmul_rn(r, row[jj[u]]));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (jj[u] < bins) {
+                    const float dist = __fsub_rn(cc[jj[u]], dot[u]);
+                    if (dist < best) {  // bins ascend per thread: strict < keeps the lowest index
+                        best = dist;
+                        besti = jj[u];
+                    }
+                }
             }
         }
 #pragma unroll
@@ -178,8 +220,7 @@ __global__ __launch_bounds__(256) void rvq_encode_kernel(const float* x, int ldx
             codes[(size_t)layer * T + t] = i;
         }
         __syncthreads();
-        const float* e = emb + (size_t)best_s * dim;
-        for (int d = threadIdx.x; d < dim; d += 256) rs[d] = __fsub_rn(rs[d], e[d]);
+        for (int d = threadIdx.x; d < dim; d += 256) rs[d] = __fsub_rn(rs[d], embt[(size_t)d * bins + best_s]);
         __syncthreads();
     }
 }
@@ -268,6 +309,16 @@ __global__ void asp_pool_kernel(const float* att, const float* x, int T, int C, 
     pooled[C + c] = sqrtf(fmaxf(var, eps));
 }
 
+// zero rows valid[b] .. Tpad-1 of clip b: what lies behind a clip's own end must be the zero padding the reference adds
+// in front of a strided conv (SpeechTokenizerEncoder.swift:114-118, :184), not the activations of the padded batch
+__global__ void mask_tail_kernel(float* x, int64_t bstride, const int32_t* valid, int Tpad, int C) {
+    const int b = blockIdx.y;
+    const int t0 = valid[b];
+    const int64_t n = (int64_t)(Tpad - t0) * C;
+    float* p = x + (size_t)b * bstride + (size_t)t0 * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+
 __global__ void copy2d_f32_kernel(const float* src, int lds, float* dst, int ldd, int T, int C) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= T * C) return;
@@ -279,32 +330,33 @@ inline int blocks_for(int64_t n, int per) { return (int)((n + per - 1) / per); }
 
 }  // namespace
 
-void launch_enc_init_conv(const float* audio, int64_t S, const float* w, const float* bias, int C, int K, float* out,
-                          hipStream_t st) {
+void launch_enc_init_conv(const float* audio, int64_t S, int B, const float* w, const float* bias, int C, int K, float* out,
+                          int64_t out_bstride, hipStream_t st) {
     Q3_CHECK(K >= 1 && K <= 17, 3, "enc_init_conv: kernel size out of range");
-    if (S <= 0) return;
-    hipLaunchKernelGGL(enc_init_conv_kernel, dim3(blocks_for(S, 256)), dim3(256), 0, st, audio, S, w, bias, C, K, out);
+    if (S <= 0 || B <= 0) return;
+    hipLaunchKernelGGL(enc_init_conv_kernel, dim3(blocks_for(S, 256), B), dim3(256), 0, st, audio, S, w, bias, C, K, out, out_bstride);
 }
-void launch_layernorm_f32(const float* x, const float* w, const float* b, float eps, int C, int T, float* out,
-                          hipStream_t st) {
-    if (T <= 0) return;
-    hipLaunchKernelGGL(layernorm_f32_kernel, dim3(T), dim3(256), 0, st, x, w, b, eps, C, out);
+void launch_layernorm_f32(const float* x, int64_t x_bstride, const float* w, const float* b, float eps, int C, int T, int B,
+                          float* out, int64_t out_bstride, hipStream_t st) {
+    if (T <= 0 || B <= 0) return;
+    hipLaunchKernelGGL(layernorm_f32_kernel, dim3(T, B), dim3(256), 0, st, x, x_bstride, w, b, eps, C, out, out_bstride);
 }
-void launch_rope_qk_f32(float* qkv, int heads, int T, const float* cos_t, const float* sin_t, hipStream_t st) {
+void launch_rope_qk_f32(float* qkv, int heads, int T, int B, const float* cos_t, const float* sin_t, hipStream_t st) {
     const int64_t n = (int64_t)T * 2 * heads * 32;
-    if (n <= 0) return;
-    hipLaunchKernelGGL(rope_qk_f32_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, qkv, heads, T, cos_t, sin_t);
+    if (n <= 0 || B <= 0) return;
+    hipLaunchKernelGGL(rope_qk_f32_kernel, dim3(blocks_for(n, 256), B), dim3(256), 0, st, qkv, heads, T, cos_t, sin_t);
 }
-void launch_attn_causal_f32(const float* qkv, int heads, int T, float* out, hipStream_t st) {
-    if (T <= 0) return;
-    hipLaunchKernelGGL(attn_causal_f32_kernel, dim3((T + 63) / 64, heads), dim3(64), 0, st, qkv, heads, T, out);
+void launch_attn_causal_f32(const float* qkv, int heads, int T, int B, float* out, hipStream_t st) {
+    if (T <= 0 || B <= 0) return;
+    hipLaunchKernelGGL(attn_causal_f32_kernel, dim3((T + 63) / 64, heads, B), dim3(64), 0, st, qkv, heads, T, out);
 }
-void launch_rvq_encode(const float* x, int ldx, int T, int dim, int bins, const float* const* cb, const float* const* c2,
-                       int n_layers, int32_t* codes, hipStream_t st) {
-    if (T <= 0 || n_layers <= 0) return;
+void launch_rvq_encode(const float* x, int ldx, int64_t x_bstride, int Tmax, int B, const int32_t* valid, const int64_t* code_off,
+                       int dim, int bins, const float* const* cb, const float* const* c2, int n_layers, int layer0,
+                       int32_t* codes, hipStream_t st) {
+    if (Tmax <= 0 || n_layers <= 0 || B <= 0) return;
     Q3_CHECK(dim <= 4096, 3, "rvq_encode: codebook dimension too large");
-    hipLaunchKernelGGL(rvq_encode_kernel, dim3(T), dim3(256), size_t(dim) * sizeof(float), st, x, ldx, T, dim, bins, cb, c2,
-                       n_layers, codes);
+    hipLaunchKernelGGL(rvq_encode_kernel, dim3(Tmax, B), dim3(256), size_t(dim) * sizeof(float), st, x, ldx, x_bstride, valid,
+                       code_off, dim, bins, cb, c2, n_layers, layer0, codes);
 }
 void launch_log_mel(const float* spec, int ld, int T, int nfreq, const float* fb, int n_mels, float* out, hipStream_t st) {
     if (T <= 0) return;
@@ -323,6 +375,11 @@ void launch_asp_concat(const float* x, const float* mean, const float* stdv, int
 }
 void launch_asp_pool(const float* att, const float* x, int T, int C, float eps, float* pooled, hipStream_t st) {
     hipLaunchKernelGGL(asp_pool_kernel, dim3((C + 63) / 64), dim3(64), 0, st, att, x, T, C, eps, pooled);
+}
+void launch_mask_tail(float* x, int64_t bstride, const int32_t* valid, int Tpad, int C, int B, hipStream_t st) {
+    if (Tpad <= 0 || B <= 0) return;
+    const int blocks = (int)std::min<int64_t>(1024, ((int64_t)Tpad * C + 255) / 256);
+    hipLaunchKernelGGL(mask_tail_kernel, dim3(blocks, B), dim3(256), 0, st, x, bstride, valid, Tpad, C);
 }
 void launch_copy2d_f32(const float* src, int lds, float* dst, int ldd, int T, int C, hipStream_t st) {
     hipLaunchKernelGGL(copy2d_f32_kernel, dim3(blocks_for((int64_t)T * C, 256)), dim3(256), 0, st, src, lds, dst, ldd, T, C);

@@ -836,7 +836,14 @@ void build_codec_encoder(Builder& b, const TMap& t, const CodecEncoderConfig& ec
                 c2.data[size_t(r)] = float(acc) / 2.0f;
             }
         }
-        e.cb[size_t(j)] = b.put_f32(emb);
+        HostTensor embt;  // [dim][bins]: the search kernel reads one dimension of 64 consecutive codes per wave load
+        embt.shape = {e.dim, e.bins};
+        if (!emb.data.empty()) {
+            embt.data.resize(emb.data.size());
+            for (int r = 0; r < e.bins; ++r)
+                for (int d = 0; d < e.dim; ++d) embt.data[size_t(d) * e.bins + r] = emb.data[size_t(r) * e.dim + d];
+        }
+        e.cb[size_t(j)] = b.put_f32(embt);
         e.c2[size_t(j)] = b.put_f32(c2);
     }
     e.cb_dev = b.put_side<const float*>(e.cb.data(), e.cb.size());

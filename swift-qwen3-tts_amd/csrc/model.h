@@ -126,7 +126,7 @@ struct CodecEncW {
     int ds = 2;
     ConvW rvq_in;  // rows: rvq_first.input_proj | rvq_rest.input_proj
     int dim = 0, bins = 0, n_layers = 0;  // layers that reach the output (16: 1 semantic + 15 acoustic)
-    std::vector<const float*> cb, c2;
+    std::vector<const float*> cb, c2;  // cb: TRANSPOSED codebooks [dim][bins] (voice_frontend.hip rvq_encode_kernel)
     const float* const* cb_dev = nullptr;
     const float* const* c2_dev = nullptr;
 };
