@@ -228,10 +228,11 @@ void Engine::enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, 
     const int H = s.hidden, MBL = Mp_ / 16, tiles = H / 16;
     const int M = B * (chunk > 1 ? chunk : 1);  // GEMM rows: chunk element p of batch row b is row p * B + b
     Q3_CHECK(M <= Mp_, 7, "internal error: chunk does not fit the activation buffers");
-    // The RMSNorm prologue re-normalises all of x in every workgroup (VALU work that grows with K): measured cheaper
-    // than a separate launch for K = 1024 but not for K = 2048 (4.57 vs 4.48 ms per 1.7B frame), so wide stacks keep
-    // a row-norm kernel.
-    const bool prologue = H <= 1024;
+    // The RMSNorm prologue re-normalises all of x in every workgroup: VALU work that grows with K and with the number
+    // of workgroups. Measured against a separate row-norm launch (4.8 us): +1 us at K = 1024; at K = 2048 +2.7 us in the
+    // qkv GEMM (256 workgroups) but +6.5 us in the gate/up GEMM (384 workgroups, two rounds on 256 CUs). So a 2048-wide
+    // stack norms in the qkv prologue and keeps a row-norm kernel in front of gate/up.
+    const bool prologue_qkv = H <= 2048, prologue_mlp = H <= 1024;
     auto norm_into_xn = [&](const uint16_t* nw) {
         NormRowsArgs n{};
         n.h = w.h; n.hMB = MBL; n.w = nw; n.eps = s.eps; n.out = w.xn; n.outMB = MBL; n.M = M; n.H = H;
@@ -239,10 +240,10 @@ void Engine::enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, 
     };
     for (size_t l = 0; l < s.layers.size(); ++l) {
         const LayerW& L = s.layers[l];
-        if (!prologue) norm_into_xn(L.ln1);
-        GemmArgs q = gemm_args(L.qkv, prologue ? w.h : w.xn, M);
+        if (!prologue_qkv) norm_into_xn(L.ln1);
+        GemmArgs q = gemm_args(L.qkv, prologue_qkv ? w.h : w.xn, M);
         q.epi = 0; q.y = w.qkv; q.ldy = w.ld_qkv;
-        if (prologue) {
+        if (prologue_qkv) {
             q.norm_w = L.ln1; q.ss_in = w.ss_a; q.ss_count = (l == 0) ? ss_count_in : tiles; q.norm_dim = H; q.norm_eps = s.eps;
         }
         launch_gemm_skinny(q, st_);
@@ -259,10 +260,10 @@ void Engine::enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, 
         GemmArgs o = gemm_args(L.o, w.ao, M);
         o.epi = 3; o.y = w.h; o.yMB = MBL; o.resid = 1; o.ss_out = w.ss_b;
         launch_gemm_skinny(o, st_);
-        if (!prologue) norm_into_xn(L.ln2);
-        GemmArgs g = gemm_args(L.gateup, prologue ? w.h : w.xn, M);
+        if (!prologue_mlp) norm_into_xn(L.ln2);
+        GemmArgs g = gemm_args(L.gateup, prologue_mlp ? w.h : w.xn, M);
         g.epi = 2; g.y = w.act; g.yMB = MBL;
-        if (prologue) {
+        if (prologue_mlp) {
             g.norm_w = L.ln2; g.ss_in = w.ss_b; g.ss_count = tiles; g.norm_dim = H; g.norm_eps = s.eps;
         }
         launch_gemm_skinny(g, st_);
@@ -272,7 +273,6 @@ void Engine::enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, 
     }
 }
 
-// One stack forward (optional input projection, all layers, optional final norm + head) as one persistent launch.
 void Engine::enqueue_stack_persist(const StackW& s, const PersistLayer* layers_dev, Stream& w, int B, const int32_t* block_table,
                                    int max_pages, const int32_t* kv_len, const uint8_t* active, int ss_count_in,
                                    const LinearW* proj, const uint16_t* proj_x, const uint16_t* proj_norm_w,
