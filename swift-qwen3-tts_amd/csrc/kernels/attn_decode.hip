@@ -76,18 +76,44 @@ __global__ __launch_bounds__(NTH) void attn_decode_kernel(AttnArgs a) {
         }
     }
 
-    // ---- phase 1: q/k norm + rope, v copy; vectors round-robin over the 4 waves ----
-    for (int j = wave; j < REP + 2; j += NWV) {
+    // ---- phase 1: q/k norm + rope, v copy; vectors round-robin over the waves. Every vector a wave owns, the norm
+    // weights and the RoPE row are loaded before the first store: the compiler cannot move a load above the cache
+    // append (it may alias), and a single-wave workgroup would otherwise pay one L2 round trip per vector ----
+    constexpr int VPW = (REP + 2 + NWV - 1) / NWV;  // vectors per wave
+    uint16_t raw0[VPW], raw1[VPW];
+#pragma unroll
+    for (int u = 0; u < VPW; ++u) {
+        const int j = wave + u * NWV;
+        raw0[u] = 0;
+        raw1[u] = 0;
+        if (j < REP + 2) {
+            const uint16_t* vp = row + (j < REP ? (size_t)(kvh * REP + j) * D : (j == REP ? qdim + (size_t)kvh * D : qdim + kdim + (size_t)kvh * D));
+            raw0[u] = vp[lane];
+            raw1[u] = vp[lane + 64];
+        }
+    }
+    const uint16_t qw0 = a.qn_w[lane], qw1 = a.qn_w[lane + 64], kw0 = a.kn_w[lane], kw1 = a.kn_w[lane + 64];
+    const uint16_t c0 = cosr[lane], c1 = cosr[lane + 64], s0 = sinr[lane], s1 = sinr[lane + 64];
+    auto norm_rope_r = [&](float x0, float x1, uint16_t w0, uint16_t w1, float& o0, float& o1) {
+        const float ss = wave_sum(x0 * x0 + x1 * x1);
+        const float rstd = 1.0f / sqrtf(ss / (float)D + a.eps);
+        const float y0 = rbf(rbf(x0 * rstd) * bf2f(w0));
+        const float y1 = rbf(rbf(x1 * rstd) * bf2f(w1));
+        o0 = rbf(rbf(y0 * bf2f(c0)) + rbf(-y1 * bf2f(s0)));
+        o1 = rbf(rbf(y1 * bf2f(c1)) + rbf(y0 * bf2f(s1)));
+    };
+#pragma unroll
+    for (int u = 0; u < VPW; ++u) {
+        const int j = wave + u * NWV;
+        if (j >= REP + 2) continue;
         if (j < REP) {
-            const uint16_t* qp = row + (size_t)(kvh * REP + j) * D;
             float o0, o1;
-            norm_rope(bf2f(qp[lane]), bf2f(qp[lane + 64]), a.qn_w, a.eps, cosr, sinr, lane, o0, o1);
+            norm_rope_r(bf2f(raw0[u]), bf2f(raw1[u]), qw0, qw1, o0, o1);
             q_s[j][lane] = o0;
             q_s[j][lane + 64] = o1;
         } else if (j == REP) {
-            const uint16_t* kp = row + qdim + (size_t)kvh * D;
             float o0, o1;
-            norm_rope(bf2f(kp[lane]), bf2f(kp[lane + 64]), a.kn_w, a.eps, cosr, sinr, lane, o0, o1);
+            norm_rope_r(bf2f(raw0[u]), bf2f(raw1[u]), kw0, kw1, o0, o1);
             k_s[lane] = o0;
             k_s[lane + 64] = o1;
             if (append) {
@@ -95,13 +121,11 @@ __global__ __launch_bounds__(NTH) void attn_decode_kernel(AttnArgs a) {
                 a.kpool[nslot + lane + 64] = f2bf(o1);
             }
         } else {
-            const uint16_t* vp = row + qdim + kdim + (size_t)kvh * D;
-            uint16_t v0 = vp[lane], v1 = vp[lane + 64];
-            v_s[lane] = bf2f(v0);
-            v_s[lane + 64] = bf2f(v1);
+            v_s[lane] = bf2f(raw0[u]);
+            v_s[lane + 64] = bf2f(raw1[u]);
             if (append) {
-                a.vpool[nslot + lane] = v0;
-                a.vpool[nslot + lane + 64] = v1;
+                a.vpool[nslot + lane] = raw0[u];
+                a.vpool[nslot + lane + 64] = raw1[u];
             }
         }
     }

@@ -344,3 +344,22 @@ def test_wide_talker_teacher_forced_logits(tmp_path):
             assert (np.abs(a - b) <= tol).all(), float(np.abs(a - b).max())
     finally:
         m.close()
+
+
+def test_scheduling_modes_agree(ckpt_dirs):
+    """The same request gives the same codes and PCM whichever way its steps are scheduled: batch 3 (prefill 8 positions
+    per launch, the predictor's step 0 as one two-position pass) vs batch 40 (one position per launch, step 0 as two
+    passes, four row blocks per GEMM)."""
+    from qwen3tts import Qwen3TTSModel
+    for name in ("tiny-a", "tiny-b"):
+        m = Qwen3TTSModel.from_pretrained(ckpt_dirs[name], max_batch=40, max_frames=24, max_prompt=64)
+        try:
+            reqs = [greq(row=i, n_text=5 + (i * 7) % 11) for i in range(40)]
+            kw = dict(temperature=0.9, top_k=30, repetition_penalty=1.05, seed=21, force_frames=10)
+            big = m.generate_batch(reqs, **kw)
+            small = m.generate_batch(reqs[:3], **kw)
+            for a, b in zip(small, big[:3]):
+                assert (a.codes == b.codes).all()
+                assert a.audio.shape == b.audio.shape and np.abs(a.audio - b.audio).max() < 1e-6
+        finally:
+            m.close()
