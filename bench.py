@@ -215,6 +215,11 @@ def main():
             dist.destroy_process_group()
         return
     value = frames_done / elapsed
+    # memory-side bytes per frame step from the PMC passes committed under profiles/ (default workload only)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01e_frame_traffic.json")
+    if args.preset == "1.7b" and B == 32 and os.path.exists(tpath):
+        traffic = json.load(open(tpath))["traffic_bytes_per_frame_step"]
     step_ms = dec_ms / max(frame_steps, 1)
     algo_bytes = model.info.weight_bytes + kv_bytes / max(frame_steps, 1)
     achieved = algo_bytes / (step_ms * 1e-3) / 1e9
@@ -234,7 +239,9 @@ def main():
                               "ar_decode": dec_ms / args.steps, "codec_decode": codec_ms / args.steps},
         "roofline": {"bound": "hbm", "kernel": "frame_step (hipGraph: talker step + 16 code-predictor passes + samplers)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": step_ms},
+                     "traffic": traffic, "traffic_source": "profiles/r01e_frame_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, "
+                     "Infinity-Cache hits included)" if traffic else None,
+                     "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": step_ms},
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ckpt, args.preset, args.n_text, n_instruct, args.cpu_frames)
