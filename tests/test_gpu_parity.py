@@ -363,3 +363,21 @@ def test_scheduling_modes_agree(ckpt_dirs):
                 assert a.audio.shape == b.audio.shape and np.abs(a.audio - b.audio).max() < 1e-6
         finally:
             m.close()
+
+
+def test_long_sequence_crosses_kv_pages(engines, oracles):
+    """90 teacher-forced frames behind a 24-position prompt: the talker cache grows past the 64-token page size (paged
+    pool, block table) and the last frames attend over two pages; logits stay within the bar against the oracle's
+    contiguous cache at every frame."""
+    from oracle import oracle as O
+    m, om = engines["tiny-a"], oracles["tiny-a"]
+    F = 90
+    rng = np.random.default_rng(12)
+    forced = np.concatenate([rng.integers(0, 2048, size=(F, 1)), rng.integers(0, 256, size=(F, 15))], -1).astype(np.int32)
+    tr = om.generate_codes(oreq(row=4, n_text=14), O.Sampling(temperature=0.0, force_frames=F), forced_codes=forced, keep_logits=True)
+    tl, cl, _ = m.debug_generate_forced([greq(row=4, n_text=14)], forced[None], temperature=0.0)
+    a, b = bf16_to_f32(tl[0]), bf16_to_f32(np.stack(tr.talker_logits))
+    tol = 2 * ULP * np.abs(b).max(axis=-1, keepdims=True)
+    assert (np.abs(a - b) <= tol).all(), (int(np.argmax((np.abs(a - b) > tol).any(-1))), float(np.abs(a - b).max()))
+    a, b = bf16_to_f32(cl[0]), bf16_to_f32(np.stack(tr.cp_logits))
+    assert (np.abs(a - b) <= 2 * ULP * np.abs(b).max(axis=-1, keepdims=True)).all()
