@@ -188,6 +188,16 @@ int32_t q3tts_codec_encoded_frames(const q3tts_model* m, int64_t n_samples);
 q3tts_status q3tts_speaker_embedding(q3tts_model* m, const float* audio, int64_t n_samples, int32_t sample_rate,
                                      float* out, int32_t cap);
 
+/* Text tokeniser: the Qwen2 byte-level BPE that the checkpoints ship as tokenizer.json (or vocab.json + merges.txt),
+ * which the reference loads through swift-transformers (`AutoTokenizer.from(modelFolder:)`, Models/Qwen3.swift:1458) and
+ * calls at :274-275, :364-365, :448-457, :822. Optional: callers that tokenise themselves never touch it. `path` is a
+ * model directory or a tokenizer.json file. encode = tokenizer.encode(text:) (no special tokens are added by the Qwen2
+ * post-processor); ids == NULL only counts. Host code, no GPU. */
+typedef struct q3tts_tokenizer q3tts_tokenizer;
+q3tts_status q3tts_tokenizer_load(const char* path, q3tts_tokenizer** out);
+void q3tts_tokenizer_free(q3tts_tokenizer* t);
+q3tts_status q3tts_tokenizer_encode(const q3tts_tokenizer* t, const char* utf8, int32_t* ids, int32_t cap, int32_t* n);
+
 /* Timing of the last q3tts_generate / q3tts_codec_decode on this handle, measured with HIP events
  * on the engine's own stream (bench.py's roofline object reads these). */
 typedef struct {

@@ -3,11 +3,15 @@
 #include <cstring>
 
 #include "engine.h"
+#include "tokenizer.h"
 
 using q3::EngineGroup;
 
 struct q3tts_model {
     std::unique_ptr<EngineGroup> eng;
+};
+struct q3tts_tokenizer {
+    q3::BpeTokenizer tok;
 };
 
 namespace {
@@ -189,6 +193,27 @@ q3tts_status q3tts_debug_frontend_stage(q3tts_model* m, const float* audio, int6
     return guarded(m, [&] {
         Q3_CHECK(m && audio && stage && out && T && C, 3, "Invalid input: null argument");
         m->eng->lane0().debug_frontend_stage(audio, n_samples, stage, out, cap_floats, T, C);
+    });
+}
+
+q3tts_status q3tts_tokenizer_load(const char* path, q3tts_tokenizer** out) {
+    return guarded(nullptr, [&] {
+        Q3_CHECK(path && out, 3, "Invalid input: null argument");
+        auto t = std::make_unique<q3tts_tokenizer>();
+        const std::string p = path;
+        if (p.size() > 5 && p.compare(p.size() - 5, 5, ".json") == 0) t->tok.load_json_file(p);
+        else t->tok.load(p);
+        *out = t.release();
+    });
+}
+void q3tts_tokenizer_free(q3tts_tokenizer* t) { delete t; }
+q3tts_status q3tts_tokenizer_encode(const q3tts_tokenizer* t, const char* utf8, int32_t* ids, int32_t cap, int32_t* n) {
+    return guarded(nullptr, [&] {
+        Q3_CHECK(t && utf8 && n, 3, "Invalid input: null argument");
+        const std::vector<int32_t> v = t->tok.encode(utf8);
+        *n = int32_t(v.size());
+        Q3_CHECK(ids == nullptr || cap >= *n, 3, "Invalid input: output buffer too small for the token ids");
+        if (ids) std::memcpy(ids, v.data(), v.size() * 4);
     });
 }
 

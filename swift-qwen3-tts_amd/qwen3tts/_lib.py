@@ -104,6 +104,10 @@ def lib() -> C.CDLL:
     L.q3tts_codec_encoded_frames.argtypes = [vp, C.c_int64]
     L.q3tts_speaker_embedding.argtypes = [vp, f32p, C.c_int64, C.c_int32, f32p, C.c_int32]
     L.q3tts_debug_frontend_stage.argtypes = [vp, f32p, C.c_int64, C.c_char_p, f32p, C.c_int64, i32p, i32p]
+    L.q3tts_tokenizer_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.q3tts_tokenizer_free.argtypes = [vp]
+    L.q3tts_tokenizer_free.restype = None
+    L.q3tts_tokenizer_encode.argtypes = [vp, C.c_char_p, i32p, C.c_int32, i32p]
     L.q3tts_debug_prepare_inputs.argtypes = [vp, C.POINTER(Request), u16p, C.c_int32, i32p, u16p, C.c_int32,
                                              i32p, u16p]
     L.q3tts_debug_generate_forced.argtypes = [vp, C.POINTER(Request), C.c_int32, C.POINTER(Sampling), i32p,

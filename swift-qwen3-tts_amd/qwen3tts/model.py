@@ -9,6 +9,7 @@ Core/GenerationTypes.swift:51-58. Tokenisation stays outside the engine like in 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Callable, Iterator, List, Optional, Sequence, Tuple
 
@@ -94,7 +95,11 @@ class Qwen3TTSModel:
         st = lib.q3tts_model_load(model_path.encode(), C.byref(o), C.byref(h))
         if st != 0:
             raise Qwen3TTSError(st, (lib.q3tts_last_error(None) or b"").decode())
-        return cls(h, lib)
+        m = cls(h, lib)
+        # AutoTokenizer.from(modelFolder:) in postLoadHook (Qwen3.swift:1456-1459): the engine's own BPE when the files exist
+        if any(os.path.exists(os.path.join(model_path, f)) for f in ("tokenizer.json", "vocab.json")):
+            m.tokenizer = NativeTokenizer(model_path)
+        return m
 
     def close(self):
         if self._h:
@@ -382,3 +387,37 @@ class Qwen3TTSModel:
         self._check(self._lib.q3tts_debug_codec_stage(self._h, codes.ctypes.data_as(L.i32p), F, stage.encode(),
                                                       out.ctypes.data_as(L.f32p), cap, C.byref(T), C.byref(Cc)))
         return out[: T.value * Cc.value].reshape(T.value, Cc.value).copy()
+
+
+class NativeTokenizer:
+    """The engine's own Qwen2 byte-level BPE (csrc/tokenizer.cc) behind q3tts_tokenizer_*: a callable text -> ids, usable
+    as `Qwen3TTSModel.tokenizer`. `path` is a model directory or a tokenizer.json file."""
+
+    def __init__(self, path: str):
+        self._lib = L.lib()
+        h = C.c_void_p()
+        st = self._lib.q3tts_tokenizer_load(path.encode(), C.byref(h))
+        if st != 0:
+            raise Qwen3TTSError(st, (self._lib.q3tts_last_error(None) or b"").decode())
+        self._h = h
+
+    def __call__(self, text: str) -> List[int]:
+        n = C.c_int32(0)
+        raw = text.encode("utf-8")
+        cap = max(16, len(raw) + 8)  # a token covers at least one byte
+        ids = np.zeros(cap, np.int32)
+        st = self._lib.q3tts_tokenizer_encode(self._h, raw, ids.ctypes.data_as(L.i32p), cap, C.byref(n))
+        if st != 0:
+            raise Qwen3TTSError(st, (self._lib.q3tts_last_error(None) or b"").decode())
+        return ids[: n.value].tolist()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.q3tts_tokenizer_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
