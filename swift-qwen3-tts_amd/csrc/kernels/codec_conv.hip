@@ -48,8 +48,8 @@ template <int BN>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
     constexpr int CT = BN / 32;  // 16-channel tiles per wave (wave tile = 64 positions x BN/2 channels)
     extern __shared__ __attribute__((aligned(16))) float smem[];  // > 64 KiB for BN = 128: dynamic LDS
-    float* As = smem;                                        // [(BM + MAX_HALO)][LDS_LD]
-    float* Ws0 = smem + (BM + MAX_HALO) * LDS_LD;            // [2][BN][LDS_LD]
+    float* As = smem;                                        // [(BM + halo)][LDS_LD]: sized by this conv's own halo, so that
+    float* Ws0 = smem + (BM + (a.K - 1) * a.dil) * LDS_LD;   // [2][BN][LDS_LD]  three workgroups fit a CU when it is short
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;  // position half, channel half
@@ -244,7 +244,7 @@ void launch_conv_gemm(const ConvGemmArgs& a, hipStream_t st) {
     else if (a.N % 96 == 0) BN = 96;
     else if (a.N > 128 && (a.N % 64) != 0) BN = 128;
     dim3 grid((a.N + BN - 1) / BN, mt, a.B), block(256);
-    const size_t smem = size_t(BM + MAX_HALO + 2 * BN) * LDS_LD * sizeof(float);
+    const size_t smem = size_t(BM + (a.K - 1) * a.dil + 2 * BN) * LDS_LD * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {  // 160 KiB of LDS per CU on gfx950; the default static cap is 64 KiB
         Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
