@@ -2,6 +2,7 @@
 #include "codec.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "codec_kernels.h"
 
@@ -14,6 +15,8 @@ constexpr size_t kScratchBudget = size_t(24) << 30;  // activation scratch per c
 CodecRunner::CodecRunner(const Model& m, hipStream_t st) : m_(m), st_(st) {
     up_ = m.cfg.codec.total_upsample();
     Q3_CHECK(m.cfg.codec.head_dim == 64, 6, "codec transformer head_dim must be 64");
+    const char* e = std::getenv("Q3TTS_CODEC_FP32");
+    fp32_mfma_ = e && e[0] == '1';
 }
 
 CodecRunner::~CodecRunner() {
@@ -89,7 +92,7 @@ int CodecRunner::decode(const int32_t* codes_dev, int code_stride_frames, const 
                         int act, int out_mul = 1) {
             ConvGemmArgs a{};
             a.x = x; a.ldx = cw.Cin; a.x_bstride = int64_t(Tmax) * cw.Cin;
-            a.w = cw.w; a.bias = cw.bias; a.scale = cw.scale;
+            a.w = cw.w; a.w3 = fp32_mfma_ ? nullptr : cw.w3; a.bias = cw.bias; a.scale = cw.scale;
             a.res = res; a.ldr = cw.N; a.res_bstride = int64_t(Tmax) * cw.N;
             a.out = out; a.ldo = cw.N; a.out_bstride = int64_t(Tmax) * cw.N;
             a.snake_ea = sn ? sn->ea : nullptr; a.snake_ib = sn ? sn->ib : nullptr;

@@ -25,6 +25,7 @@ class CodecRunner {
     const Model& m_;
     hipStream_t st_;
     int up_ = 1920;
+    bool fp32_mfma_ = false;  // Q3TTS_CODEC_FP32=1: contract on the fp32 matrix-core path instead of the bf16x3 one
     uint8_t* buf_ = nullptr;
     size_t buf_bytes_ = 0;
     int32_t* lens_dev_ = nullptr;

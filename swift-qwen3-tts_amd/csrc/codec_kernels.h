@@ -13,6 +13,8 @@ struct ConvGemmArgs {
     int ldx;
     int64_t x_bstride;
     const float* w;      // [N][K][Cin]
+    const uint16_t* w3;  // optional: w split into three bf16 planes (hi | mid | lo, exact), [K][ceil(Cin/32)][N][3][32];
+                         // selects the bf16x3 kernel (six bf16 MFMAs per product block instead of eight fp32 ones)
     const float* bias;   // [N] or nullptr
     const float* scale;  // [N] or nullptr
     const float* res;    // residual or nullptr

@@ -230,6 +230,205 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
     }
 }
 
+// ---- bf16x3 variant ---------------------------------------------------------------------------------
+// The same contraction with every fp32 operand written as an exact sum of three bf16 values (hi + mid + lo, 3 x 8
+// significand bits) and each product block evaluated as six v_mfma_f32_16x16x32_bf16 -- lo*hi, hi*lo, mid*mid, mid*hi,
+// hi*mid, hi*hi, smallest first -- accumulated in fp32. The three dropped cross terms are below 3 * 2^-24 of the product,
+// i.e. the result carries fp32-level rounding noise (PCM differs from the fp32-MFMA kernel by ~1e-7, tests/
+// test_gpu_parity.py), while the matrix cores spend 6 x 16 cycles per 16x16x32 block instead of 8 x 32: 2.67x less.
+// Weights are split once at load (model.cc attach_split), activations while they are staged into LDS. An LDS row holds
+// the three planes of 32 input channels (3 x 64 B) + 32 B of padding = 14 sixteen-byte units: 14 = 2 (mod 4) keeps the
+// ds_read_b128 lane groups of MI355X_MICROARCH.md on distinct banks. Weight tiles are single-buffered so that two
+// workgroups (70 KiB each at the widest halo) share a CU.
+constexpr int ROW3 = 56;  // dwords per LDS row
+
+__device__ __forceinline__ void split3(float x, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(h);
+    m = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(m);
+    l = __float_as_uint(r2) & 0xffff0000u;
+}
+
+__device__ __forceinline__ f32x4 mfma_bf16(const uint4& a, const uint4& b, f32x4 c) {
+    bf16x8 av, bv;
+    __builtin_memcpy(&av, &a, 16);
+    __builtin_memcpy(&bv, &b, 16);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, c, 0, 0, 0);
+}
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvGemmArgs a) {
+    constexpr int CT = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem3[];
+    const int halo = (a.K - 1) * a.dil;
+    uint32_t* As = smem3;                        // [(BM + halo)][ROW3]
+    uint32_t* Ws = smem3 + (BM + halo) * ROW3;   // [BN][ROW3]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int b = blockIdx.z;
+    const int n0 = blockIdx.x * BN;
+    const int t0 = blockIdx.y * BM;
+    const int T = a.frames[b] * a.ppf;
+    if (t0 >= T) return;
+    const int rows = BM + halo;
+    const float* xb = a.x + (size_t)b * a.x_bstride;
+    const float* x2b = a.x2;
+    const int nchunks = (a.Cin + KC - 1) / KC;
+    const int steps = nchunks * a.K;
+
+    f32x4 acc[4][CT];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // weight tile of one (tap, chunk) step: BN x 12 sixteen-byte pieces, contiguous in global memory
+    constexpr int WV = (BN * 12 + 255) / 256;
+    uint4 wreg[WV];
+    auto load_w = [&](int step) {
+        const int chunk = step / a.K, tap = step % a.K;
+        const uint4* src = reinterpret_cast<const uint4*>(a.w3 + ((size_t)(tap * nchunks + chunk) * a.N + n0) * 96);
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int item = i * 256 + tid;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (item < BN * 12 && n0 + item / 12 < a.N) v = src[item];
+            wreg[i] = v;
+        }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int item = i * 256 + tid;
+            if (item < BN * 12) *reinterpret_cast<uint4*>(&Ws[(item / 12) * ROW3 + (item % 12) * 4]) = wreg[i];
+        }
+    };
+
+    constexpr int AV = ((BM + MAX_HALO) * 8 + 255) / 256;
+    float4 areg[AV];
+    auto load_a = [&](int chunk) {
+        const int c0 = chunk * KC;
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int item = i * 256 + tid;
+            const int r = item >> 3, c4 = (item & 7) * 4;
+            int t = t0 - halo + a.shift + r;
+            if (a.reflect) t = t < 0 ? -t : (t >= T ? 2 * (T - 1) - t : t);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < rows && t >= 0 && t < T && c0 + c4 < a.Cin) {
+                v = *reinterpret_cast<const float4*>(xb + (size_t)t * a.ldx + c0 + c4);
+                if (x2b) {
+                    const float4 u = *reinterpret_cast<const float4*>(x2b + (size_t)t * a.ldx2 + c0 + c4);
+                    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                }
+                if (a.pre_act == 1) {
+                    v.x = v.x > 0.f ? v.x : expf(v.x) - 1.0f;
+                    v.y = v.y > 0.f ? v.y : expf(v.y) - 1.0f;
+                    v.z = v.z > 0.f ? v.z : expf(v.z) - 1.0f;
+                    v.w = v.w > 0.f ? v.w : expf(v.w) - 1.0f;
+                }
+                if (a.snake_ea) {
+                    const float4 ea = *reinterpret_cast<const float4*>(a.snake_ea + c0 + c4);
+                    const float4 ib = *reinterpret_cast<const float4*>(a.snake_ib + c0 + c4);
+                    float s;
+                    s = sinf(v.x * ea.x); v.x = v.x + ib.x * (s * s);
+                    s = sinf(v.y * ea.y); v.y = v.y + ib.y * (s * s);
+                    s = sinf(v.z * ea.z); v.z = v.z + ib.z * (s * s);
+                    s = sinf(v.w * ea.w); v.w = v.w + ib.w * (s * s);
+                }
+            }
+            areg[i] = v;
+        }
+    };
+    auto store_a = [&]() {
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int item = i * 256 + tid;
+            const int r = item >> 3, c4 = (item & 7) * 4;
+            if (r >= rows) continue;
+            uint32_t h[4], m[4], l[4];
+            split3(areg[i].x, h[0], m[0], l[0]);
+            split3(areg[i].y, h[1], m[1], l[1]);
+            split3(areg[i].z, h[2], m[2], l[2]);
+            split3(areg[i].w, h[3], m[3], l[3]);
+            uint32_t* dst = &As[r * ROW3 + (c4 >> 1)];
+            *reinterpret_cast<uint2*>(dst) = make_uint2((h[0] >> 16) | h[1], (h[2] >> 16) | h[3]);
+            *reinterpret_cast<uint2*>(dst + 16) = make_uint2((m[0] >> 16) | m[1], (m[2] >> 16) | m[3]);
+            *reinterpret_cast<uint2*>(dst + 32) = make_uint2((l[0] >> 16) | l[1], (l[2] >> 16) | l[3]);
+        }
+    };
+
+    load_w(0);
+    load_a(0);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        __syncthreads();  // the previous chunk's MFMAs are done with As and Ws
+        store_a();
+        if (chunk + 1 < nchunks) load_a(chunk + 1);
+        for (int tap = 0; tap < a.K; ++tap) {
+            const int step = chunk * a.K + tap;
+            if (tap > 0) __syncthreads();  // the previous tap's reads of Ws
+            store_w();
+            __syncthreads();
+            if (step + 1 < steps) load_w(step + 1);
+            const uint32_t* arow = &As[(wm * 64 + tap * a.dil + (lane & 15)) * ROW3 + 4 * (lane >> 4)];
+            const uint32_t* wrow = &Ws[(wn * (BN / 2) + (lane & 15)) * ROW3 + 4 * (lane >> 4)];
+            uint4 xa[3][4], wa[3][CT];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) xa[pl][p] = *reinterpret_cast<const uint4*>(arow + p * 16 * ROW3 + pl * 16);
+#pragma unroll
+                for (int c = 0; c < CT; ++c) wa[pl][c] = *reinterpret_cast<const uint4*>(wrow + c * 16 * ROW3 + pl * 16);
+            }
+            // (weight plane, activation plane) pairs, smallest product first
+            constexpr int PW[6] = {2, 0, 1, 1, 0, 0};
+            constexpr int PX[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c) acc[p][c] = mfma_bf16(wa[PW[q]][c], xa[PX[q]][p], acc[p][c]);
+        }
+    }
+
+    float* ob = a.out + (size_t)b * a.out_bstride;
+    const float* rb = a.res ? a.res + (size_t)b * a.res_bstride : nullptr;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int t = t0 + wm * 64 + p * 16 + (lane & 15);
+        if (t >= T) continue;
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int n = n0 + wn * (BN / 2) + c * 16 + 4 * (lane >> 4);
+            if (n >= a.N) continue;
+            float v[4] = {acc[p][c][0], acc[p][c][1], acc[p][c][2], acc[p][c][3]};
+            if (a.bias) {
+                const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
+                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+            }
+            if (a.act == 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+            } else if (a.act != 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = act_other(v[j], a.act);
+            }
+            if (a.scale) {
+                const float4 sv = *reinterpret_cast<const float4*>(a.scale + n);
+                v[0] *= sv.x; v[1] *= sv.y; v[2] *= sv.z; v[3] *= sv.w;
+            }
+            if (rb) {
+                const float4 rv = *reinterpret_cast<const float4*>(rb + (size_t)t * a.ldr + n);
+                v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+            }
+            *reinterpret_cast<float4*>(ob + (size_t)t * a.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
 }  // namespace
 
 void launch_conv_gemm(const ConvGemmArgs& a, hipStream_t st) {
@@ -244,14 +443,26 @@ void launch_conv_gemm(const ConvGemmArgs& a, hipStream_t st) {
     else if (a.N % 96 == 0) BN = 96;
     else if (a.N > 128 && (a.N % 64) != 0) BN = 128;
     dim3 grid((a.N + BN - 1) / BN, mt, a.B), block(256);
-    const size_t smem = size_t(BM + (a.K - 1) * a.dil + 2 * BN) * LDS_LD * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {  // 160 KiB of LDS per CU on gfx950; the default static cap is 64 KiB
         Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<96>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_split_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_split_kernel<96>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_split_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         attr_set = true;
     }
+    if (a.w3) {
+        const size_t smem3 = size_t(BM + (a.K - 1) * a.dil + BN) * ROW3 * sizeof(uint32_t);
+        switch (BN) {
+            case 128: hipLaunchKernelGGL(conv_gemm_split_kernel<128>, grid, block, smem3, st, a); break;
+            case 96: hipLaunchKernelGGL(conv_gemm_split_kernel<96>, grid, block, smem3, st, a); break;
+            default: hipLaunchKernelGGL(conv_gemm_split_kernel<64>, grid, block, smem3, st, a); break;
+        }
+        return;
+    }
+    const size_t smem = size_t(BM + (a.K - 1) * a.dil + 2 * BN) * LDS_LD * sizeof(float);
     switch (BN) {
         case 128: hipLaunchKernelGGL(conv_gemm_kernel<128>, grid, block, smem, st, a); break;
         case 96: hipLaunchKernelGGL(conv_gemm_kernel<96>, grid, block, smem, st, a); break;

@@ -297,6 +297,7 @@ struct Builder {
     size_t off = 0;
     uint8_t* staging = nullptr;   // device staging for raw matrices before tiling
     size_t max_staging = 0;       // bytes, collected in the dry pass
+    bool split3 = false;          // codec decoder: convs also get the three-plane bf16 copy of their weights
 
     template <class T>
     T* alloc(size_t n) {
@@ -517,6 +518,45 @@ const HostTensor* maybe(const TMap& t, const std::string& k) {
     return it == t.end() ? nullptr : &it->second;
 }
 
+// x = hi + mid + lo exactly, each a bf16 (truncation keeps the next 8 significand bits each time: 3 x 8 = 24).
+// The device side splits activations the same way (codec_conv.hip).
+inline void split_bf16x3(float x, uint16_t& hi, uint16_t& mid, uint16_t& lo) {
+    uint32_t u;
+    std::memcpy(&u, &x, 4);
+    const uint32_t h = u & 0xffff0000u;
+    float hf;
+    std::memcpy(&hf, &h, 4);
+    const float r1 = x - hf;
+    std::memcpy(&u, &r1, 4);
+    const uint32_t m = u & 0xffff0000u;
+    float mf;
+    std::memcpy(&mf, &m, 4);
+    const float r2 = r1 - mf;
+    std::memcpy(&u, &r2, 4);
+    hi = uint16_t(h >> 16);
+    mid = uint16_t(m >> 16);
+    lo = uint16_t(u >> 16);
+}
+
+// w [N][K][Cin] fp32 -> [K][chunks of 32 input channels][N][3 planes][32] bf16 (zero beyond Cin): one (tap, chunk)
+// step of conv_gemm_split_kernel reads BN * 192 contiguous bytes
+void attach_split(Builder& b, ConvW& c, const std::vector<float>& w) {
+    if (!b.split3) return;
+    const int chunks = (c.Cin + 31) / 32;
+    const size_t n = size_t(c.K) * chunks * c.N * 96;
+    std::vector<uint16_t> p;
+    if (!b.dry && b.fill && !w.empty()) {
+        p.assign(n, 0);
+        for (int nn = 0; nn < c.N; ++nn)
+            for (int tap = 0; tap < c.K; ++tap)
+                for (int ci = 0; ci < c.Cin; ++ci) {
+                    uint16_t* d = &p[((size_t(tap) * chunks + ci / 32) * c.N + nn) * 96 + (ci % 32)];
+                    split_bf16x3(w[(size_t(nn) * c.K + tap) * c.Cin + ci], d[0], d[32], d[64]);
+                }
+    }
+    c.w3 = b.put<uint16_t>(p.empty() ? nullptr : p.data(), n);
+}
+
 ConvW put_conv(Builder& b, const TMap& t, const std::string& name, int dil = 1) {
     const HostTensor& w = need(t, name + ".weight");
     ConvW c;
@@ -531,6 +571,7 @@ ConvW put_conv(Builder& b, const TMap& t, const std::string& name, int dil = 1) 
     }
     c.dil = dil;
     c.w = b.put_f32(w);
+    attach_split(b, c, w.data);
     if (const HostTensor* bias = maybe(t, name + ".bias")) c.bias = b.put_f32(*bias);
     return c;
 }
@@ -557,6 +598,7 @@ ConvW put_linear_concat(Builder& b, const TMap& t, const std::vector<std::string
     c.K = 1;
     c.Cin = K;
     c.w = b.put_f32(cat);
+    attach_split(b, c, cat.data);
     return c;
 }
 
@@ -587,6 +629,7 @@ ConvW put_tconv(Builder& b, const TMap& t, const std::string& name, int stride) 
     c.Cin = Cin;
     c.dil = 1;
     c.w = b.put_f32(p);
+    attach_split(b, c, p.data);
     if (const HostTensor* bias = maybe(t, name + ".bias")) {
         HostTensor bb;
         bb.shape = {int64_t(stride) * Cout};
@@ -648,6 +691,7 @@ void build_codec(Builder& b, const TMap& t, const CodecDecoderConfig& dc, CodecW
         c.rvq_out.K = 1;
         c.rvq_out.Cin = 2 * in;
         c.rvq_out.w = b.put_f32(f);
+        attach_split(b, c.rvq_out, f.data);
     }
     c.pre_conv = put_conv(b, t, "decoder.pre_conv.conv");
     const std::string pt = "decoder.pre_transformer";
@@ -981,7 +1025,9 @@ void build_all(Builder& b, Model& m, const SafetensorsDir& main, const TMap* cod
     build_stack(b, mt, "talker.code_predictor.model", m.cp, CH, cp_inter, cp.num_attention_heads, cp.num_key_value_heads,
                 cp.head_dim, cp.rms_norm_eps, cp.rope_theta, 64);
     if (codec_t) {
+        b.split3 = true;
         build_codec(b, *codec_t, cfg.codec, m.codec);
+        b.split3 = false;
         m.has_codec = true;
         if (cfg.has_codec_encoder) {  // SpeechTokenizer.swift:808-812
             build_codec_encoder(b, *codec_t, cfg.codec_enc, m.codec_enc);

@@ -25,11 +25,21 @@ if not os.path.exists(os.path.join(d, ".complete")):
     synth.save_safetensors(os.path.join(d, "speech_tokenizer", "model.safetensors"),
                            synth.codec_tensors(p["speech_tokenizer"]["decoder_config"], g))
     open(os.path.join(d, ".complete"), "w").write("ok")
-m = Qwen3TTSModel.from_pretrained(d, max_batch=1, max_frames=8, max_prompt=64)
 rng = np.random.default_rng(0)
 codes = rng.integers(1, 2048, size=(B, F, 16)).astype(np.int32)
-for i in range(reps):
-    t0 = time.time()
-    m.codec_decode(codes)
-    print(f"codec_decode B={B} F={F}: wall {1e3 * (time.time() - t0):.1f} ms, device {m.last_timing().codec_ms:.1f} ms", flush=True)
-m.close()
+pcm = {}
+modes = ("0", "1") if os.environ.get("Q3TTS_CODEC_COMPARE") else (os.environ.get("Q3TTS_CODEC_FP32", "0"),)
+for mode in modes:   # "1": fp32 matrix-core path, "0": bf16x3 (default)
+    os.environ["Q3TTS_CODEC_FP32"] = mode
+    m = Qwen3TTSModel.from_pretrained(d, max_batch=1, max_frames=8, max_prompt=64)
+    for i in range(reps):
+        t0 = time.time()
+        out = m.codec_decode(codes)
+        print(f"codec_decode fp32_mfma={mode} B={B} F={F}: wall {1e3 * (time.time() - t0):.1f} ms, "
+              f"device {m.last_timing().codec_ms:.1f} ms", flush=True)
+    pcm[mode] = np.asarray(out[0] if isinstance(out, (tuple, list)) else out)
+    m.close()
+if len(pcm) == 2:
+    a, b = pcm["0"], pcm["1"]
+    print(f"bf16x3 vs fp32 MFMA: max |diff| {np.abs(a - b).max():.3e}, rms diff {np.sqrt(np.mean((a - b) ** 2)):.3e}, "
+          f"rms signal {np.sqrt(np.mean(b ** 2)):.3e}, clipped {np.mean(np.abs(b) >= 1.0):.3f}", flush=True)
