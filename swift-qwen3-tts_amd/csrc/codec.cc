@@ -88,17 +88,18 @@ int CodecRunner::decode(const int32_t* codes_dev, int code_stride_frames, const 
         const int nb = std::min(rows_per_chunk, B - r0);
         const int32_t* fr = lens_dev_ + r0;
         const int32_t* codes = codes_dev + size_t(r0) * code_stride_frames * 16;
+        // `post`: also (or, with out == nullptr, only) write SnakeBeta_post(result) to out2 for the next conv
         auto conv = [&](const ConvW& cw, const float* x, int Tmax, int ppf, float* out, const SnakeW* sn, const float* res,
-                        int act, int out_mul = 1) {
+                        int act, const SnakeW* post = nullptr, float* out2 = nullptr) {
             ConvGemmArgs a{};
             a.x = x; a.ldx = cw.Cin; a.x_bstride = int64_t(Tmax) * cw.Cin;
             a.w = cw.w; a.w3 = fp32_mfma_ ? nullptr : cw.w3; a.bias = cw.bias; a.scale = cw.scale;
             a.res = res; a.ldr = cw.N; a.res_bstride = int64_t(Tmax) * cw.N;
             a.out = out; a.ldo = cw.N; a.out_bstride = int64_t(Tmax) * cw.N;
             a.snake_ea = sn ? sn->ea : nullptr; a.snake_ib = sn ? sn->ib : nullptr;
+            if (post) { a.out2 = out2; a.post_ea = post->ea; a.post_ib = post->ib; a.post_C = post->C; }
             a.frames = fr; a.ppf = ppf; a.Tmax = Tmax; a.B = nb;
             a.Cin = cw.Cin; a.N = cw.N; a.K = cw.K; a.dil = cw.dil; a.act = act;
-            (void)out_mul;
             launch_conv_gemm(a, st_);
         };
         int T = Fmax, ppf = 1;
@@ -144,24 +145,28 @@ int CodecRunner::decode(const int32_t* codes_dev, int code_stride_frames, const 
             cur = (cur + 1) & 3;
             capture(("upsample" + std::to_string(i)).c_str(), bufs[cur], T, C, nb);
         }
-        // 6. MainDecoder (:681-690)
+        // 6. MainDecoder (:681-690). Every SnakeBeta sits in front of a conv; it is evaluated in the epilogue of the
+        // conv that PRODUCES the tensor (one sinf per element) and the activated copy is what the next conv stages.
+        const size_t nblk = w.blocks.size();
         {
-            float* y = bufs[(cur + 1) & 3];
-            conv(w.init_conv, bufs[cur], T, ppf, y, nullptr, nullptr, 0);
-            cur = (cur + 1) & 3;
+            float *y = bufs[(cur + 1) & 3], *ys = bufs[(cur + 2) & 3];
+            conv(w.init_conv, bufs[cur], T, ppf, y, nullptr, nullptr, 0, nblk ? &w.blocks[0].snake : nullptr, ys);
+            cur = (cur + 1) & 3;  // bufs[cur] = init_conv output, bufs[cur + 1] = snake_0 of it
             capture("init_conv", bufs[cur], T, w.init_conv.N, nb);
         }
-        for (size_t i = 0; i < w.blocks.size(); ++i) {
+        for (size_t i = 0; i < nblk; ++i) {
             const auto& Bk = w.blocks[i];
-            float *h = bufs[cur], *y = bufs[(cur + 1) & 3], *t1 = bufs[(cur + 2) & 3];
-            conv(Bk.tconv, h, T, ppf, y, &Bk.snake, nullptr, 0);  // snake -> transposed conv (:474-475)
+            // in: bufs[cur + 1] = snake_i(previous stage). y (raw residual stream), ya = act1(y) / next snake(y), t1 = act2(conv1)
+            float *hs = bufs[(cur + 1) & 3], *y = bufs[(cur + 2) & 3], *ya = bufs[(cur + 3) & 3], *t1 = bufs[cur];
+            conv(Bk.tconv, hs, T, ppf, y, nullptr, nullptr, 0, &Bk.res[0].act1, ya);  // snake -> transposed conv (:474-475)
             T *= Bk.stride;
             ppf *= Bk.stride;
-            for (int j = 0; j < 3; ++j) {  // DecoderResidualUnit (:430-437)
-                conv(Bk.res[j].conv1, y, T, ppf, t1, &Bk.res[j].act1, nullptr, 0);
-                conv(Bk.res[j].conv2, t1, T, ppf, y, &Bk.res[j].act2, y, 0);
+            for (int j = 0; j < 3; ++j) {  // DecoderResidualUnit (:430-437): y += conv2(act2(conv1(act1(y))))
+                conv(Bk.res[j].conv1, ya, T, ppf, nullptr, nullptr, nullptr, 0, &Bk.res[j].act2, t1);
+                const SnakeW* next = j < 2 ? &Bk.res[j + 1].act1 : (i + 1 < nblk ? &w.blocks[i + 1].snake : nullptr);
+                conv(Bk.res[j].conv2, t1, T, ppf, y, nullptr, y, 0, next, ya);
             }
-            cur = (cur + 1) & 3;
+            cur = (cur + 2) & 3;  // bufs[cur] = y, bufs[cur + 1] = next block's snake of it
             capture(("block" + std::to_string(i)).c_str(), bufs[cur], T, Bk.Cout, nb);
         }
         // 7. outSnake -> outConv -> clip (:687-688, :781)

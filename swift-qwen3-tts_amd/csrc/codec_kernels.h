@@ -20,9 +20,13 @@ struct ConvGemmArgs {
     const float* res;    // residual or nullptr
     int ldr;
     int64_t res_bstride;
-    float* out;
+    float* out;          // may be nullptr when only out2 is wanted
     int ldo;
     int64_t out_bstride;
+    float* out2;         // optional second output, same geometry as out: SnakeBeta(post_ea, post_ib) of the result, for
+    const float* post_ea;  // the conv that consumes it (its own snake_ea then stays nullptr). Parameters are indexed by
+    const float* post_ib;  // n % post_C (a transposed conv's N is stride * channels)
+    int post_C;
     const float* snake_ea;  // SnakeBeta prologue on x (exp(alpha), 1/(exp(beta)+1e-9)) or nullptr
     const float* snake_ib;
     const int32_t* frames;  // [B]

@@ -44,6 +44,68 @@ __device__ __forceinline__ float act_other(float v, int act) {
     }
 }
 
+// Four consecutive output channels n..n+3 of position t: + bias, activation, scale, + residual -> out; and, when the
+// consumer of this tensor is a conv behind a SnakeBeta (DecoderResidualUnit act1/act2, DecoderBlock snake:
+// SpeechTokenizer.swift:430-437, 474-475), the activated copy -> out2, so that each element goes through sinf once
+// here instead of once per output-channel tile (and halo overlap) in the consumer's staging loop.
+__device__ __forceinline__ void epilogue4(const ConvGemmArgs& a, int b, int t, int n, f32x4& accv) {
+    float v[4] = {accv[0], accv[1], accv[2], accv[3]};
+    if (a.bias) {
+        const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
+        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+    }
+    if (a.act == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+    } else if (a.act != 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = act_other(v[j], a.act);
+    }
+    if (a.scale) {
+        const float4 sv = *reinterpret_cast<const float4*>(a.scale + n);
+        v[0] *= sv.x; v[1] *= sv.y; v[2] *= sv.z; v[3] *= sv.w;
+    }
+    if (a.res) {
+        const float4 rv = *reinterpret_cast<const float4*>(a.res + (size_t)b * a.res_bstride + (size_t)t * a.ldr + n);
+        v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+    }
+    if (a.out) *reinterpret_cast<float4*>(a.out + (size_t)b * a.out_bstride + (size_t)t * a.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+    accv = f32x4{v[0], v[1], v[2], v[3]};  // kept for snake_pass
+}
+
+// Second output: SnakeBeta of the finished tile. The accumulators are parked in LDS (each lane its own slots, so no
+// barrier beyond the one that retires the main loop's tiles) and walked by a ROLLED loop: one inlined sinf body per
+// 16-position slice instead of one per accumulator register (64 copies demote the accumulators to scratch).
+template <int CT>
+__device__ __forceinline__ void snake_pass(const ConvGemmArgs& a, float* smem_base, int b, int t0, int n0w, int T, int wave, int lane,
+                                           f32x4 (&acc)[4][CT], int wm) {
+    float4* stash = reinterpret_cast<float4*>(smem_base) + wave * (CT * 64);
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) stash[c * 64 + lane] = make_float4(acc[p][c][0], acc[p][c][1], acc[p][c][2], acc[p][c][3]);
+        const int t = t0 + wm * 64 + p * 16 + (lane & 15);
+        if (t >= T) continue;
+        float* dst = a.out2 + (size_t)b * a.out_bstride + (size_t)t * a.ldo;
+#pragma unroll 1
+        for (int c = 0; c < CT; ++c) {
+            const int n = n0w + c * 16 + 4 * (lane >> 4);
+            if (n >= a.N) break;
+            float4 v = stash[c * 64 + lane];
+            const int ch = n % a.post_C;  // transposed convs: n = phase * Cout + channel
+            const float4 ea = *reinterpret_cast<const float4*>(a.post_ea + ch);
+            const float4 ib = *reinterpret_cast<const float4*>(a.post_ib + ch);
+            float s;
+            s = sinf(v.x * ea.x); v.x = v.x + ib.x * (s * s);
+            s = sinf(v.y * ea.y); v.y = v.y + ib.y * (s * s);
+            s = sinf(v.z * ea.z); v.z = v.z + ib.z * (s * s);
+            s = sinf(v.w * ea.w); v.w = v.w + ib.w * (s * s);
+            *reinterpret_cast<float4*>(dst + n) = v;
+        }
+    }
+}
+
 template <int BN>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
     constexpr int CT = BN / 32;  // 16-channel tiles per wave (wave tile = 64 positions x BN/2 channels)
@@ -195,8 +257,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
     }
 
     // epilogue: lane holds channels n..n+3 (rows of D) of position t (column of D)
-    float* ob = a.out + (size_t)b * a.out_bstride;
-    const float* rb = a.res ? a.res + (size_t)b * a.res_bstride : nullptr;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int t = t0 + wm * 64 + p * 16 + (lane & 15);
@@ -205,29 +265,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
         for (int c = 0; c < CT; ++c) {
             const int n = n0 + wn * (BN / 2) + c * 16 + 4 * (lane >> 4);
             if (n >= a.N) continue;
-            float v[4] = {acc[p][c][0], acc[p][c][1], acc[p][c][2], acc[p][c][3]};
-            if (a.bias) {
-                const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
-                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-            }
-            if (a.act == 1) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
-            } else if (a.act != 0) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = act_other(v[j], a.act);
-            }
-            if (a.scale) {
-                const float4 sv = *reinterpret_cast<const float4*>(a.scale + n);
-                v[0] *= sv.x; v[1] *= sv.y; v[2] *= sv.z; v[3] *= sv.w;
-            }
-            if (rb) {
-                const float4 rv = *reinterpret_cast<const float4*>(rb + (size_t)t * a.ldr + n);
-                v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-            }
-            *reinterpret_cast<float4*>(ob + (size_t)t * a.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+            epilogue4(a, b, t, n, acc[p][c]);
         }
     }
+    if (a.out2) snake_pass<CT>(a, smem, b, t0, n0 + wn * (BN / 2), T, wave, lane, acc, wm);
 }
 
 // ---- bf16x3 variant ---------------------------------------------------------------------------------
@@ -394,8 +435,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvGemmArgs a)
         }
     }
 
-    float* ob = a.out + (size_t)b * a.out_bstride;
-    const float* rb = a.res ? a.res + (size_t)b * a.res_bstride : nullptr;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int t = t0 + wm * 64 + p * 16 + (lane & 15);
@@ -404,29 +443,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvGemmArgs a)
         for (int c = 0; c < CT; ++c) {
             const int n = n0 + wn * (BN / 2) + c * 16 + 4 * (lane >> 4);
             if (n >= a.N) continue;
-            float v[4] = {acc[p][c][0], acc[p][c][1], acc[p][c][2], acc[p][c][3]};
-            if (a.bias) {
-                const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
-                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-            }
-            if (a.act == 1) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
-            } else if (a.act != 0) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = act_other(v[j], a.act);
-            }
-            if (a.scale) {
-                const float4 sv = *reinterpret_cast<const float4*>(a.scale + n);
-                v[0] *= sv.x; v[1] *= sv.y; v[2] *= sv.z; v[3] *= sv.w;
-            }
-            if (rb) {
-                const float4 rv = *reinterpret_cast<const float4*>(rb + (size_t)t * a.ldr + n);
-                v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-            }
-            *reinterpret_cast<float4*>(ob + (size_t)t * a.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+            epilogue4(a, b, t, n, acc[p][c]);
         }
     }
+    if (a.out2) snake_pass<CT>(a, reinterpret_cast<float*>(smem3), b, t0, n0 + wn * (BN / 2), T, wave, lane, acc, wm);
 }
 
 }  // namespace

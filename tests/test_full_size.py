@@ -81,9 +81,7 @@ def test_full_size_codec_both_contraction_paths_match_the_oracle(full_codec_dir,
     """The codec decoder contracts on bf16 matrix cores with every fp32 operand split exactly into three bf16 planes
     (six products per block, csrc/kernels/codec_conv.hip); Q3TTS_CODEC_FP32=1 selects the plain fp32 matrix-core
     kernel. Both must sit at fp32 rounding noise from the oracle's fmaf chains at the real layer widths, stage by stage."""
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
-    import oracle as O
+    from oracle import oracle as O
     from qwen3tts import Qwen3TTSModel
     om = O.OracleModel(full_codec_dir)
     codes = np.random.default_rng(3).integers(1, 2048, size=(3, 16)).astype(np.int32)
