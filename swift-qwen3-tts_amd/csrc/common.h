@@ -82,14 +82,58 @@ __device__ __forceinline__ uint32_t pack_bf(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane reductions on the VALU (DPP row operations + gfx950's v_permlane{16,32}_swap) instead of ds_bpermute: the
+// LDS crossbar costs a full LDS round trip per butterfly step, and the decode kernels are chains of such steps. Every
+// function pairs exactly the lanes the xor butterfly it replaces paired (i with i ^ o), so results are bit-identical
+// to the __shfl_xor forms (checked on the GPU by tools/dpp_reduce.hip).
+template <int CTRL, int BANK = 0xF>
+__device__ __forceinline__ float dpp_mov(float old, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xF, BANK, false));
+}
+struct XorPartner {  // v's value in lane i ^ o for o = 32, 16, 8, 4, 2, 1 (in that order)
+    static __device__ __forceinline__ void swap32(float v, float& a, float& b) {
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+        a = __int_as_float(r[0]); b = __int_as_float(r[1]);  // {lo, lo}, {hi, hi}: a op b = v[i] op v[i ^ 32] for a commutative op
+    }
+    static __device__ __forceinline__ void swap16(float v, float& a, float& b) {
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);
+        a = __int_as_float(r[0]); b = __int_as_float(r[1]);
+    }
+    static __device__ __forceinline__ float x8(float v) { return dpp_mov<0x128>(v, v); }  // row_ror:8
+    static __device__ __forceinline__ float x4(float v) {                                   // row_shl:4 | row_shr:4 by bank
+        const float t = dpp_mov<0x104, 0x5>(v, v);
+        return dpp_mov<0x114, 0xA>(t, v);
+    }
+    static __device__ __forceinline__ float x2(float v) { return dpp_mov<0x4E>(v, v); }   // quad_perm [2,3,0,1]
+    static __device__ __forceinline__ float x1(float v) { return dpp_mov<0xB1>(v, v); }   // quad_perm [1,0,3,2]
+};
+__device__ __forceinline__ float wave_sum(float v) {  // butterfly o = 32, 16, ..., 1; every lane gets the sum
+    float a, b;
+    XorPartner::swap32(v, a, b); v = a + b;
+    XorPartner::swap16(v, a, b); v = a + b;
+    v += XorPartner::x8(v);
+    v += XorPartner::x4(v);
+    v += XorPartner::x2(v);
+    v += XorPartner::x1(v);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    float a, b;
+    XorPartner::swap32(v, a, b); v = fmaxf(a, b);
+    XorPartner::swap16(v, a, b); v = fmaxf(a, b);
+    v = fmaxf(v, XorPartner::x8(v));
+    v = fmaxf(v, XorPartner::x4(v));
+    v = fmaxf(v, XorPartner::x2(v));
+    v = fmaxf(v, XorPartner::x1(v));
+    return v;
+}
+// sum over a 16-lane DPP row, butterfly o = 1, 2, 4, 8 (the attention kernels' per-position dot products). After the
+// first two steps every quad is uniform, so the mirrors pair the same VALUES as xor 4 and xor 8 would.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += XorPartner::x1(v);
+    v += XorPartner::x2(v);
+    v += dpp_mov<0x141>(v, v);  // row_half_mirror
+    v += dpp_mov<0x140>(v, v);  // row_mirror
     return v;
 }
 

@@ -152,10 +152,7 @@ __global__ __launch_bounds__(NTH) void attn_decode_kernel(AttnArgs a) {
             float d = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) d += q[h][j] * kf[j];
-            d += __shfl_xor(d, 1, 64);
-            d += __shfl_xor(d, 2, 64);
-            d += __shfl_xor(d, 4, 64);
-            d += __shfl_xor(d, 8, 64);
+            d = row16_sum(d);
             const float sc = d * a.scale;
             const float mn = fmaxf(m[h], sc);
             const float alpha = __expf(m[h] - mn);  // exp(-inf) = 0 on the first position
@@ -320,10 +317,7 @@ __global__ __launch_bounds__(NTH) void attn_chunk_kernel(AttnArgs a) {
                 float d = 0.f;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) d += q[h][j] * kf[j];
-                d += __shfl_xor(d, 1, 64);
-                d += __shfl_xor(d, 2, 64);
-                d += __shfl_xor(d, 4, 64);
-                d += __shfl_xor(d, 8, 64);
+                d = row16_sum(d);
                 const float sc = d * a.scale;
                 const float mn = fmaxf(m[h], sc);
                 const float alpha = __expf(m[h] - mn);

@@ -298,7 +298,9 @@ __device__ __forceinline__ f32x4 mfma_bf16(const uint4& a, const uint4& b, f32x4
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, c, 0, 0, 0);
 }
 
-template <int BN>
+// PRO: input prologues compiled in (pre-add, ELU, SnakeBeta, reflect/shift windows). The decoder's convs need none of them
+// since SnakeBeta moved to the producers' epilogues, and their staging loop is then a bare load + split.
+template <int BN, bool PRO>
 __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvGemmArgs a) {
     constexpr int CT = BN / 32;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem3[];
@@ -355,29 +357,34 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvGemmArgs a)
         for (int i = 0; i < AV; ++i) {
             const int item = i * 256 + tid;
             const int r = item >> 3, c4 = (item & 7) * 4;
-            int t = t0 - halo + a.shift + r;
-            if (a.reflect) t = t < 0 ? -t : (t >= T ? 2 * (T - 1) - t : t);
+            int t = t0 - halo + r;
+            if constexpr (PRO) {
+                t += a.shift;
+                if (a.reflect) t = t < 0 ? -t : (t >= T ? 2 * (T - 1) - t : t);
+            }
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < rows && t >= 0 && t < T && c0 + c4 < a.Cin) {
                 v = *reinterpret_cast<const float4*>(xb + (size_t)t * a.ldx + c0 + c4);
-                if (x2b) {
-                    const float4 u = *reinterpret_cast<const float4*>(x2b + (size_t)t * a.ldx2 + c0 + c4);
-                    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-                }
-                if (a.pre_act == 1) {
-                    v.x = v.x > 0.f ? v.x : expf(v.x) - 1.0f;
-                    v.y = v.y > 0.f ? v.y : expf(v.y) - 1.0f;
-                    v.z = v.z > 0.f ? v.z : expf(v.z) - 1.0f;
-                    v.w = v.w > 0.f ? v.w : expf(v.w) - 1.0f;
-                }
-                if (a.snake_ea) {
-                    const float4 ea = *reinterpret_cast<const float4*>(a.snake_ea + c0 + c4);
-                    const float4 ib = *reinterpret_cast<const float4*>(a.snake_ib + c0 + c4);
-                    float s;
-                    s = sinf(v.x * ea.x); v.x = v.x + ib.x * (s * s);
-                    s = sinf(v.y * ea.y); v.y = v.y + ib.y * (s * s);
-                    s = sinf(v.z * ea.z); v.z = v.z + ib.z * (s * s);
-                    s = sinf(v.w * ea.w); v.w = v.w + ib.w * (s * s);
+                if constexpr (PRO) {
+                    if (x2b) {
+                        const float4 u = *reinterpret_cast<const float4*>(x2b + (size_t)t * a.ldx2 + c0 + c4);
+                        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                    }
+                    if (a.pre_act == 1) {
+                        v.x = v.x > 0.f ? v.x : expf(v.x) - 1.0f;
+                        v.y = v.y > 0.f ? v.y : expf(v.y) - 1.0f;
+                        v.z = v.z > 0.f ? v.z : expf(v.z) - 1.0f;
+                        v.w = v.w > 0.f ? v.w : expf(v.w) - 1.0f;
+                    }
+                    if (a.snake_ea) {
+                        const float4 ea = *reinterpret_cast<const float4*>(a.snake_ea + c0 + c4);
+                        const float4 ib = *reinterpret_cast<const float4*>(a.snake_ib + c0 + c4);
+                        float s;
+                        s = sinf(v.x * ea.x); v.x = v.x + ib.x * (s * s);
+                        s = sinf(v.y * ea.y); v.y = v.y + ib.y * (s * s);
+                        s = sinf(v.z * ea.z); v.z = v.z + ib.z * (s * s);
+                        s = sinf(v.w * ea.w); v.w = v.w + ib.w * (s * s);
+                    }
                 }
             }
             areg[i] = v;
@@ -468,17 +475,21 @@ void launch_conv_gemm(const ConvGemmArgs& a, hipStream_t st) {
         Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<96>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_split_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_split_kernel<96>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_split_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        void (*split_kernels[6])(ConvGemmArgs) = {&conv_gemm_split_kernel<128, true>, &conv_gemm_split_kernel<128, false>,
+                                                   &conv_gemm_split_kernel<96, true>,  &conv_gemm_split_kernel<96, false>,
+                                                   &conv_gemm_split_kernel<64, true>,  &conv_gemm_split_kernel<64, false>};
+        for (auto k : split_kernels)
+            Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         attr_set = true;
     }
     if (a.w3) {
         const size_t smem3 = size_t(BM + (a.K - 1) * a.dil + BN) * ROW3 * sizeof(uint32_t);
+        const bool pro = a.x2 || a.pre_act || a.snake_ea || a.shift || a.reflect;
+        auto go = [&](void (*kern)(ConvGemmArgs)) { hipLaunchKernelGGL(kern, grid, block, smem3, st, a); };
         switch (BN) {
-            case 128: hipLaunchKernelGGL(conv_gemm_split_kernel<128>, grid, block, smem3, st, a); break;
-            case 96: hipLaunchKernelGGL(conv_gemm_split_kernel<96>, grid, block, smem3, st, a); break;
-            default: hipLaunchKernelGGL(conv_gemm_split_kernel<64>, grid, block, smem3, st, a); break;
+            case 128: pro ? go(&conv_gemm_split_kernel<128, true>) : go(&conv_gemm_split_kernel<128, false>); break;
+            case 96: pro ? go(&conv_gemm_split_kernel<96, true>) : go(&conv_gemm_split_kernel<96, false>); break;
+            default: pro ? go(&conv_gemm_split_kernel<64, true>) : go(&conv_gemm_split_kernel<64, false>); break;
         }
         return;
     }

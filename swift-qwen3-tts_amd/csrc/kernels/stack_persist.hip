@@ -419,10 +419,7 @@ __device__ __forceinline__ void attn_unit(const StackPersistArgs& a, const Persi
                 float d = 0.f;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) d += q[h][j] * kf[j];
-                d += __shfl_xor(d, 1, 64);
-                d += __shfl_xor(d, 2, 64);
-                d += __shfl_xor(d, 4, 64);
-                d += __shfl_xor(d, 8, 64);
+                d = row16_sum(d);
                 const float sc = d * a.scale;
                 const float mn = fmaxf(m[h], sc);
                 const float alpha = __expf(m[h] - mn);
