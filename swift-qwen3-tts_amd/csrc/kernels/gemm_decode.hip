@@ -26,6 +26,8 @@
 //     through LDS in fixed wave order -> results do not depend on batch size or launch geometry
 //     (row independence is the batching contract). CH (chunks per wave) is a template
 //     parameter so every weight load of a wave is issued before its first MFMA.
+#include <cstdlib>
+
 #include "../common.h"
 #include "../kernels.h"
 
@@ -89,6 +91,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int tile = blockIdx.x;
+    const int mb0 = blockIdx.y * MB;  // first 16-row block of this workgroup (launch_q splits the rows of narrow layers)
     const int KC = a.K >> 7;  // 128-wide k chunks
 
     f32x4 acc[NT][MB];
@@ -132,8 +135,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
     //     the raw x fragments of the first XG chunks, and (EPI 3) the old hidden-state piece this thread will update.
     // chunks whose x fragments are prefetched: as many as fit next to the weight registers (16 VGPRs per fragment set)
     constexpr int kWRegs = CH * NT * (QUANT ? 5 : 16);
-    constexpr int kRoom = (176 - kWRegs) / (MB * 16);
-    constexpr int XG = (CH == 0) ? 0 : (kRoom < 1 ? 1 : (kRoom > 3 ? (CH < 3 ? CH : 3) : (kRoom < CH ? kRoom : CH)));
+    // (one row block leaves room for every chunk of the widest layer, K = 6144: one round trip for the whole workgroup)
+    constexpr int kRoom = (((MB == 1 && !NORM) ? 200 : 176) - kWRegs) / (MB * 16);
+    constexpr int kCap = (MB == 1 && !NORM) ? 6 : 3;
+    constexpr int XG = (CH == 0) ? 0 : (kRoom < 1 ? 1 : (kRoom > kCap ? (CH < kCap ? CH : kCap) : (kRoom < CH ? kRoom : CH)));
     uint4 xr[XG > 0 ? XG : 1][MB][4];
     uint4 nwr[(NORM && XG > 0) ? XG : 1][4];
     if constexpr (XG > 0) {
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
             }
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
-                const uint4* xp = Xt + ((size_t)(kc * a.xMB + mb) * 4) * 64 + lane;
+                const uint4* xp = Xt + ((size_t)(kc * a.xMB + mb0 + mb) * 4) * 64 + lane;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) xr[c][mb][i] = xp[i * 64];
             }
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
     if constexpr (EPI == 3) {
         if (a.resid && threadIdx.x < 32 * MB) {
             const int o = threadIdx.x, mb = o >> 5, b = (o >> 1) & 15, p = o & 1;
-            hv_pre = *reinterpret_cast<const uint4*>(a.y + act_tiled_offset(16 * mb + b, tile * 16 + 8 * p, a.yMB));
+            hv_pre = *reinterpret_cast<const uint4*>(a.y + act_tiled_offset(16 * (mb0 + mb) + b, tile * 16 + 8 * p, a.yMB));
         }
     }
 
@@ -172,13 +177,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
 #pragma unroll
             for (int u = 0; u < 16; ++u) {  // all partials of this (row, part) in flight before the first add (H <= 2048)
                 const int j = part + 8 * u;
-                tmp[u] = a.ss_in[(size_t)(j < a.ss_count ? j : 0) * a.ss_ld + row];
+                tmp[u] = a.ss_in[(size_t)(j < a.ss_count ? j : 0) * a.ss_ld + 16 * mb0 + row];
             }
             float s = 0.f;
 #pragma unroll
             for (int u = 0; u < 16; ++u)
                 if (part + 8 * u < a.ss_count) s += tmp[u];
-            for (int j = part + 128; j < a.ss_count; j += 8) s += a.ss_in[(size_t)j * a.ss_ld + row];
+            for (int j = part + 128; j < a.ss_count; j += 8) s += a.ss_in[(size_t)j * a.ss_ld + 16 * mb0 + row];
             ssp_s[part][row] = s;
         }
         __syncthreads();
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) xf[i] = xpre[mb][i];
             } else {
-                const uint4* xp = Xt + ((size_t)(kc * a.xMB + mb) * 4) * 64 + lane;
+                const uint4* xp = Xt + ((size_t)(kc * a.xMB + mb0 + mb) * 4) * 64 + lane;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) xf[i] = xp[i * 64];
             }
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
                         }
 #pragma unroll
                         for (int mb = 0; mb < MB; ++mb) {
-                            const uint4* xp = Xt + ((size_t)(kc * a.xMB + mb) * 4) * 64 + lane;
+                            const uint4* xp = Xt + ((size_t)(kc * a.xMB + mb0 + mb) * 4) * 64 + lane;
 #pragma unroll
                             for (int i = 0; i < 4; ++i) xr[c][mb][i] = xp[i * 64];
                         }
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
     // 16-byte stores: thread -> (mb, row b, 8-feature piece p)
     for (int o = threadIdx.x; o < 32 * MB; o += NW * 64) {
         const int mb = o >> 5, b = (o >> 1) & 15, p = o & 1;
-        const int m = 16 * mb + b;
+        const int m = 16 * (mb0 + mb) + b;
         uint4 v = *reinterpret_cast<const uint4*>(&ys[mb][b][8 * p]);
         const int n = tile * 16 + 8 * p;
         if constexpr (EPI == 3) {
@@ -352,11 +357,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
 }
 
 template <int MB, int EPI, bool NORM, bool QUANT>
-void launch_mb(const GemmArgs& a, hipStream_t st) {
+void launch_mb(const GemmArgs& a, int split, hipStream_t st) {
     const int KC = a.K / 128;
     const int nw = KC <= 4 ? 4 : 8;  // no idle waves on short K
     const int ch = (KC + nw - 1) / nw;
-    dim3 grid(a.N / 16);
+    dim3 grid(a.N / 16, split);
 #define Q3_GEMM(NWv, CHv) \
     hipLaunchKernelGGL((gemm_skinny_kernel<MB, EPI, NWv, CHv, NORM, QUANT>), grid, dim3(NWv * 64), 0, st, a)
     if (nw == 4) {
@@ -375,12 +380,23 @@ void launch_mb(const GemmArgs& a, hipStream_t st) {
 
 template <int EPI, bool NORM, bool QUANT>
 void launch_q(const GemmArgs& a, hipStream_t st) {
-    const int MB = (a.Mpad + 15) / 16;
-    switch (MB) {
-        case 1: launch_mb<1, EPI, NORM, QUANT>(a, st); break;
-        case 2: launch_mb<2, EPI, NORM, QUANT>(a, st); break;
-        case 3: launch_mb<3, EPI, NORM, QUANT>(a, st); break;
-        case 4: launch_mb<4, EPI, NORM, QUANT>(a, st); break;
+    const int MBt = (a.Mpad + 15) / 16;
+    // Narrow layers (o_proj, down_proj: N / 16 <= 128 column tiles) leave CUs idle with one workgroup per tile, and a
+    // workgroup that carries two row blocks cannot keep every x fragment of a long K in registers. Their row blocks go
+    // to separate workgroups instead (grid.y); tile x of both lands on the same XCD (128 = 0 mod 8), so the second
+    // read of the weight tile is an L2 hit. Per-row arithmetic does not depend on the grouping: results are unchanged.
+    static const bool no_split = std::getenv("Q3TTS_GEMM_NO_ROW_SPLIT") != nullptr;
+    const int tiles = a.N / 16;
+    int split = 1;
+    if (!no_split) {
+        if (MBt % 4 == 0 && tiles * 4 <= 256) split = 4;
+        else if (MBt % 2 == 0 && tiles * 2 <= 256) split = 2;
+    }
+    switch (MBt / split) {
+        case 1: launch_mb<1, EPI, NORM, QUANT>(a, split, st); break;
+        case 2: launch_mb<2, EPI, NORM, QUANT>(a, split, st); break;
+        case 3: launch_mb<3, EPI, NORM, QUANT>(a, split, st); break;
+        case 4: launch_mb<4, EPI, NORM, QUANT>(a, split, st); break;
         default: throw Error(3, "gemm_skinny: M > 64 is not supported");
     }
 }
