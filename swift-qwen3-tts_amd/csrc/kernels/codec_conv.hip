@@ -23,6 +23,7 @@
 // LDS rows are padded to 40 floats: conflict-free for ds_read_b128 (MI355X_MICROARCH.md LDS table).
 #include "../common.h"
 #include "../codec_kernels.h"
+#include "snake.h"
 
 namespace q3 {
 namespace {
@@ -77,31 +78,40 @@ __device__ __forceinline__ void epilogue4(const ConvGemmArgs& a, int b, int t, i
 // barrier beyond the one that retires the main loop's tiles) and walked by a ROLLED loop: one inlined sinf body per
 // 16-position slice instead of one per accumulator register (64 copies demote the accumulators to scratch).
 template <int CT>
-__device__ __forceinline__ void snake_pass(const ConvGemmArgs& a, float* smem_base, int b, int t0, int n0w, int T, int wave, int lane,
-                                           f32x4 (&acc)[4][CT], int wm) {
+__device__ __forceinline__ void snake_pass(const ConvGemmArgs& a, float* smem_base, int b, int t0, int n0, int wn, int T, int wave,
+                                           int lane, f32x4 (&acc)[4][CT], int wm) {
+    constexpr int BNl = CT * 32;
     float4* stash = reinterpret_cast<float4*>(smem_base) + wave * (CT * 64);
+    float4* par = reinterpret_cast<float4*>(smem_base) + 4 * (CT * 64);  // [BN / 4] exp(alpha), then [BN / 4] 1/(exp(beta)+eps)
     __syncthreads();
+    if (threadIdx.x < BNl / 4) {  // this tile's SnakeBeta parameters, once per workgroup
+        const int n = n0 + 4 * threadIdx.x;
+        if (n < a.N) {
+            const int ch = n % a.post_C;  // transposed convs: n = phase * Cout + channel
+            par[threadIdx.x] = *reinterpret_cast<const float4*>(a.post_ea + ch);
+            par[BNl / 4 + threadIdx.x] = *reinterpret_cast<const float4*>(a.post_ib + ch);
+        }
+    }
+    __syncthreads();
+    const int nl0 = wn * (BNl / 2) + 4 * (lane >> 4);  // this lane's first channel within the tile
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
 #pragma unroll
         for (int c = 0; c < CT; ++c) stash[c * 64 + lane] = make_float4(acc[p][c][0], acc[p][c][1], acc[p][c][2], acc[p][c][3]);
         const int t = t0 + wm * 64 + p * 16 + (lane & 15);
         if (t >= T) continue;
-        float* dst = a.out2 + (size_t)b * a.out_bstride + (size_t)t * a.ldo;
+        float* dst = a.out2 + (size_t)b * a.out_bstride + (size_t)t * a.ldo + n0;
 #pragma unroll 1
         for (int c = 0; c < CT; ++c) {
-            const int n = n0w + c * 16 + 4 * (lane >> 4);
-            if (n >= a.N) break;
+            const int nl = nl0 + c * 16;
+            if (n0 + nl >= a.N) break;
             float4 v = stash[c * 64 + lane];
-            const int ch = n % a.post_C;  // transposed convs: n = phase * Cout + channel
-            const float4 ea = *reinterpret_cast<const float4*>(a.post_ea + ch);
-            const float4 ib = *reinterpret_cast<const float4*>(a.post_ib + ch);
-            float s;
-            s = sinf(v.x * ea.x); v.x = v.x + ib.x * (s * s);
-            s = sinf(v.y * ea.y); v.y = v.y + ib.y * (s * s);
-            s = sinf(v.z * ea.z); v.z = v.z + ib.z * (s * s);
-            s = sinf(v.w * ea.w); v.w = v.w + ib.w * (s * s);
-            *reinterpret_cast<float4*>(dst + n) = v;
+            const float4 ea = par[nl >> 2], ib = par[BNl / 4 + (nl >> 2)];
+            v.x = v.x + ib.x * snake_sin2(v.x * ea.x);
+            v.y = v.y + ib.y * snake_sin2(v.y * ea.y);
+            v.z = v.z + ib.z * snake_sin2(v.z * ea.z);
+            v.w = v.w + ib.w * snake_sin2(v.w * ea.w);
+            *reinterpret_cast<float4*>(dst + nl) = v;
         }
     }
 }
@@ -268,7 +278,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
             epilogue4(a, b, t, n, acc[p][c]);
         }
     }
-    if (a.out2) snake_pass<CT>(a, smem, b, t0, n0 + wn * (BN / 2), T, wave, lane, acc, wm);
+    if (a.out2) snake_pass<CT>(a, smem, b, t0, n0, wn, T, wave, lane, acc, wm);
 }
 
 // ---- bf16x3 variant ---------------------------------------------------------------------------------
@@ -453,7 +463,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvGemmArgs a)
             epilogue4(a, b, t, n, acc[p][c]);
         }
     }
-    if (a.out2) snake_pass<CT>(a, reinterpret_cast<float*>(smem3), b, t0, n0 + wn * (BN / 2), T, wave, lane, acc, wm);
+    if (a.out2) snake_pass<CT>(a, reinterpret_cast<float*>(smem3), b, t0, n0, wn, T, wave, lane, acc, wm);
 }
 
 }  // namespace

@@ -3,6 +3,7 @@
 // depthwise conv + LayerNorm, SwiGLU gating, full attention of the 8-layer pre-transformer and the
 // Snake -> conv(C->1) -> clip tail. All are HBM/L2 bound row kernels over channels-last tensors.
 #include "../common.h"
+#include "snake.h"
 #include "../codec_kernels.h"
 
 namespace q3 {
@@ -162,8 +163,7 @@ __global__ __launch_bounds__(256) void out_conv_kernel(const float* x, int C, co
         float v = 0.f;
         if (t >= 0 && t < T) {
             v = xb[(size_t)t * C + c];
-            const float s = sinf(v * ea[c]);
-            v = v + ib[c] * (s * s);
+            v = v + ib[c] * snake_sin2(v * ea[c]);
         }
         xs[i] = v;
     }
