@@ -80,10 +80,13 @@ __device__ __forceinline__ void dequant_chunk(const uint4& qw, uint32_t sb, uint
 //      3 = hidden-state store, fragment-major, in place: h = bf16((resid ? h : 0) + bf16(acc + bias)),
 //          plus ss_out[tile][m] = sum over the tile's 16 features of h^2
 // NORM: RMSNorm prologue on x (x is then the raw residual stream h)
-template <int MB, int EPI, int NW, int CH, bool NORM, bool QUANT>
+// NP (EPI 2 only): gate/up tile pairs per workgroup. A 6144-wide MLP is 384 pairs: one pair per workgroup runs as a full
+// round of 256 workgroups plus a half-empty one; two pairs per workgroup is one round of 192.
+template <int MB, int EPI, int NW, int CH, bool NORM, bool QUANT, int NP = 1>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
-    constexpr int NT = (EPI == 2) ? 2 : 1;  // weight tiles per workgroup
-    __shared__ float red[NW][NT][MB][4][64];
+    constexpr int NT = (EPI == 2) ? 2 * NP : 1;  // weight tiles per workgroup
+    constexpr int NR = (EPI == 2) ? 2 : 1;       // tiles reduced per pass of the epilogue
+    __shared__ float red[NW][NR][MB][4][64];
     __shared__ __attribute__((aligned(16))) uint16_t ys[MB][16][16];
     __shared__ float rstd_s[NORM ? 16 * MB : 1];
     __shared__ float ssp_s[NORM ? 8 : 1][NORM ? 16 * MB : 1];
@@ -282,29 +285,33 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
         }
     }
 
-    // 4. cross-wave K reduction through LDS, fixed wave order
+    // 4. cross-wave K reduction through LDS, fixed wave order; one tile (EPI 2: one gate/up pair) per pass
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int pr = 0; pr < NT / NR; ++pr) {
+    if (pr > 0) __syncthreads();  // the previous pair's red / ys reads
+#pragma unroll
+    for (int t = 0; t < NR; ++t)
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) red[wave][t][mb][q][lane] = acc[t][mb][q];
+            for (int q = 0; q < 4; ++q) red[wave][t][mb][q][lane] = acc[pr * NR + t][mb][q];
     __syncthreads();
+    const int otile = tile * (NT / NR) + pr;  // 16-column output tile
 
     // 256*MB outputs per tile: thread -> (mb, batch row b, feature f)
     for (int o = threadIdx.x; o < 256 * MB; o += NW * 64) {
         const int mb = o >> 8, rem = o & 255;
         const int b = rem >> 4, f = rem & 15;
         const int src_lane = (f >> 2) * 16 + b, q = f & 3;
-        float v[NT];
+        float v[NR];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
+        for (int t = 0; t < NR; ++t) {
             float sum = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) sum += red[w][t][mb][q][src_lane];
             v[t] = sum;
         }
-        const int n = tile * 16 + f;
+        const int n = otile * 16 + f;
         if constexpr (EPI == 2) {
             const float g = rbf(v[0]), u = rbf(v[1]);
             ys[mb][b][f] = f2bf(rbf(silu_f(g)) * u);
@@ -322,7 +329,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
         const int mb = o >> 5, b = (o >> 1) & 15, p = o & 1;
         const int m = 16 * (mb0 + mb) + b;
         uint4 v = *reinterpret_cast<const uint4*>(&ys[mb][b][8 * p]);
-        const int n = tile * 16 + 8 * p;
+        const int n = otile * 16 + 8 * p;
         if constexpr (EPI == 3) {
             uint16_t* hp = a.y + act_tiled_offset(m, n, a.yMB);
             float ss = 0.f;
@@ -354,6 +361,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
                 *reinterpret_cast<uint4*>(a.y + (size_t)m * a.ldy + n) = v;
         }
     }
+    }
 }
 
 template <int MB, int EPI, bool NORM, bool QUANT>
@@ -361,9 +369,17 @@ void launch_mb(const GemmArgs& a, int split, hipStream_t st) {
     const int KC = a.K / 128;
     const int nw = KC <= 4 ? 4 : 8;  // no idle waves on short K
     const int ch = (KC + nw - 1) / nw;
-    dim3 grid(a.N / 16, split);
+    const int tiles = a.N / 16;
 #define Q3_GEMM(NWv, CHv) \
-    hipLaunchKernelGGL((gemm_skinny_kernel<MB, EPI, NWv, CHv, NORM, QUANT>), grid, dim3(NWv * 64), 0, st, a)
+    hipLaunchKernelGGL((gemm_skinny_kernel<MB, EPI, NWv, CHv, NORM, QUANT>), dim3(tiles, split), dim3(NWv * 64), 0, st, a)
+    if constexpr (EPI == 2 && !NORM && !QUANT && MB <= 2) {
+        // more than one round of workgroups on 256 CUs, and an even pair count: two pairs per workgroup, one round
+        static const bool one_pair = std::getenv("Q3TTS_GEMM_ONE_PAIR") != nullptr;
+        if (!one_pair && nw == 8 && ch == 2 && tiles > 256 && tiles <= 512 && tiles % 2 == 0) {
+            hipLaunchKernelGGL((gemm_skinny_kernel<MB, 2, 8, 2, false, false, 2>), dim3(tiles / 2, split), dim3(512), 0, st, a);
+            return;
+        }
+    }
     if (nw == 4) {
         Q3_GEMM(4, 1);
     } else {
