@@ -89,6 +89,7 @@ Engine::Engine(Model* model, const q3tts_load_opts& opts) : m_(model), opts_(opt
         table(m_->talker, kpool_, vpool_, kv_layer_stride_, &tk_layers_dev_);
         table(m_->cp, cp_kpool_, cp_vpool_, cp_kv_layer_stride_, &cp_layers_dev_);
     }
+    if (m_->has_cp_proj && !persistent_ && !std::getenv("Q3TTS_NO_PROJ_TABLES")) build_cp_proj_tables();
     if (m_->has_codec) codec_ = std::make_unique<CodecRunner>(*m_, st_);
     if (m_->has_codec_encoder || m_->has_speaker_encoder) fe_ = std::make_unique<VoiceFrontEnd>(*m_, st_);
 }
@@ -119,6 +120,40 @@ Engine::~Engine() {
         if (e) (void)hipEventDestroy(e);
     if (fe_uploaded_) (void)hipEventDestroy(fe_uploaded_);
     if (st_) (void)hipStreamDestroy(st_);
+}
+
+// CodePredictor.swift:327-330 projects the embedding of every sampled code (H wide) down to the predictor's width before
+// each of passes 1..14. The projection of a table row does not depend on anything else, so it is taken once per row at
+// load -- by the very GEMM launch the frame step would have made, 64 codes at a time, so the rows (and their per-tile sums
+// of squares for the next norm prologue) are bit-identical to projecting at run time -- and the frame step loses 14 launches.
+void Engine::build_cp_proj_tables() {
+    const TalkerConfig& t = m_->cfg.talker;
+    const int H = t.hidden_size, CH = m_->cp.hidden, MBL = Mp_ / 16, Vc = t.cp.vocab_size, nss = CH / 16;
+    const int ntab = t.num_code_groups - 2;  // embeddings 0..13 feed passes 1..14; the last code feeds nothing
+    if (ntab <= 0) return;
+    if (m_->cp_pe.empty()) {
+        for (int i = 0; i < ntab; ++i) {
+            uint16_t* pe = nullptr;
+            float* pss = nullptr;
+            Q3_HIP(hipMalloc(reinterpret_cast<void**>(&pe), size_t(Vc) * CH * 2));
+            m_->lazy_allocs.push_back(pe);
+            Q3_HIP(hipMalloc(reinterpret_cast<void**>(&pss), size_t(Vc) * nss * 4));
+            m_->lazy_allocs.push_back(pss);
+            for (int c0 = 0; c0 < Vc; c0 += Mp_) {
+                const int rows = std::min(Mp_, Vc - c0);
+                launch_tile_rows(m_->cp_emb[size_t(i)] + size_t(c0) * H, H, cp_x_, MBL, rows, H, st_);
+                GemmArgs p = gemm_args(m_->cp_proj, cp_x_, rows);
+                p.epi = 3; p.y = cp_.h; p.yMB = MBL; p.resid = 0; p.ss_out = cp_.ss_a;
+                launch_gemm_skinny(p, st_);
+                launch_untile_rows(cp_.h, MBL, pe + size_t(c0) * CH, CH, rows, CH, st_);
+                launch_ss_to_table(cp_.ss_a, Mp_, pss + size_t(c0) * nss, nss, rows, st_);
+            }
+            m_->cp_pe.push_back(pe);
+            m_->cp_pss.push_back(pss);
+        }
+        Q3_HIP(hipStreamSynchronize(st_));
+    }
+    cp_tables_ = true;
 }
 
 void Engine::alloc_workspace() {
@@ -321,7 +356,7 @@ void Engine::enqueue_talker_step(int B, bool with_head) {
 // One code-predictor pass (CodePredictor.swift:320-339 without the head). `from_talker`: the input is
 // the talker's final-normed hidden state (step 0, first position); otherwise it is the embedding the
 // previous sampler gathered (fragment-major in cp_x_ when a projection follows, else straight in cp_.h).
-void Engine::enqueue_cp_pass(int B, bool from_talker, int head, int cp_pos) {
+void Engine::enqueue_cp_pass(int B, bool from_talker, int head, int cp_pos, bool projected) {
     const TalkerConfig& t = m_->cfg.talker;
     const int H = t.hidden_size, CH = m_->cp.hidden, MBL = Mp_ / 16;
     int ss_count = 1;
@@ -347,7 +382,9 @@ void Engine::enqueue_cp_pass(int B, bool from_talker, int head, int cp_pos) {
         }
         return;
     }
-    if (m_->has_cp_proj) {  // small_to_mtp_projection (biased), CodePredictor.swift:327-330
+    if (m_->has_cp_proj && projected) {  // the sampler gathered an already projected row and its sums (build_cp_proj_tables)
+        ss_count = CH / 16;
+    } else if (m_->has_cp_proj) {  // small_to_mtp_projection (biased), CodePredictor.swift:327-330
         if (from_talker) talker_norm_into(cp_x2_, nullptr);  // cp_x_ already holds embed(code0) for the second position
         GemmArgs p = gemm_args(m_->cp_proj, from_talker ? cp_x2_ : cp_x_, B);
         p.epi = 3; p.y = cp_.h; p.yMB = MBL; p.resid = 0; p.ss_out = cp_.ss_a;
@@ -425,7 +462,7 @@ void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
     for (int i = 0; i < groups - 1; ++i) {
         const bool second_of_pair = pair && i == 0;  // its stack forward already ran above; rows B..2B-1 hold it
         const int Mh = second_of_pair ? 2 * B : B;
-        if (!second_of_pair) enqueue_cp_pass(B, false, i, i + 1);
+        if (!second_of_pair) enqueue_cp_pass(B, false, i, i + 1, cp_tables_ && i >= 1);
         if (!persistent_) {
             GemmArgs lh = gemm_args(m_->lm_head[size_t(i)], cp_.h, Mh);
             lh.epi = 0; lh.y = cp_.logits; lh.ldy = cp_.ld_logits;
@@ -444,6 +481,10 @@ void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
             sc.emb = m_->cp_emb[size_t(i)]; sc.emb_ld = H; sc.next_x = next_x; sc.next_MB = MBL; sc.next_ss = next_ss;
         }
         sc.H = H; sc.B = B;
+        if (cp_tables_ && i + 1 < groups - 1) {  // projected row + its per-tile sums straight into the next pass's input
+            sc.emb = m_->cp_pe[size_t(i)]; sc.emb_ld = CH; sc.H = CH; sc.next_x = cp_.h;
+            sc.emb_ss = m_->cp_pss[size_t(i)]; sc.nss = CH / 16; sc.next_ss = cp_.ss_a; sc.next_ss_ld = Mp_;
+        }
         sc.logits_dump = (dbg && dbg->cp_logits) ? cl_dump_ : nullptr; sc.dump_ld = (groups - 1) * Vc; sc.dump_off = i * Vc;
         launch_sampler(sc, st_);
     }

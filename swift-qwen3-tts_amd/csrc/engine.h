@@ -99,7 +99,11 @@ class Engine {
         int ld_qkv, ld_act, ld_logits;
     } tk_{}, cp_{};
     uint16_t* cp_x_ = nullptr;   // fragment-major [Mp][H] code-predictor input before the projection
-    uint16_t* cp_x2_ = nullptr;  // staged embedding of code 0 (second position of predictor step 0)
+    uint16_t* cp_x2_ = nullptr;
+    // small_to_mtp_projection applied to every row of the code predictor's embedding tables at load (by the decode GEMM
+    // itself, so rows are bit-identical to projecting at run time); kept in the Model, see Model::cp_pe
+    bool cp_tables_ = false;  // the samplers hand projected rows (Model::cp_pe) straight to the next pass
+    void build_cp_proj_tables();  // staged embedding of code 0 (second position of predictor step 0)
     float* cp_ss2_ = nullptr;
     uint16_t *kpool_ = nullptr, *vpool_ = nullptr, *cp_kpool_ = nullptr, *cp_vpool_ = nullptr;
     size_t kv_layer_stride_ = 0, cp_kv_layer_stride_ = 0;
@@ -166,7 +170,7 @@ class Engine {
                         const int32_t* block_table, int max_pages, const int32_t* kv_len, const uint8_t* active,
                         int ss_count_in, int fixed_len, int chunk, const int32_t* chunk_n_prompt, int chunk_r_base);
     void enqueue_talker_step(int B, bool with_head);
-    void enqueue_cp_pass(int B, bool from_talker, int head, int cp_pos);  // head: lm_head index or -1; cp_pos: tokens already cached
+    void enqueue_cp_pass(int B, bool from_talker, int head, int cp_pos, bool projected = false);  // head: lm_head index or -1; cp_pos: tokens already cached
     void enqueue_frame(int B, const DebugOpts* dbg);
     hipGraphExec_t frame_graph(int B);
     GemmArgs gemm_args(const LinearW& L, const uint16_t* x, int M) const;

@@ -171,12 +171,16 @@ struct SamplerArgs {
     int next_MB;
     int next_row0;           // row b is written at row b + next_row0 of next_x (second position of predictor step 0)
     float* next_ss;          // [B] sum of squares of the gathered row (norm prologue of the consumer) or nullptr
+    const float* emb_ss;     // optional [V][nss]: precomputed per-tile sums of squares of every table row (projected tables);
+    int nss, next_ss_ld;     // copied to next_ss[j * next_ss_ld + row] instead of the single sum
     int H;
     int B;
     uint16_t* logits_dump;   // [B][forced_frames][dump_ld] (tests) or nullptr
     int dump_ld, dump_off;
 };
 void launch_sampler(const SamplerArgs& a, hipStream_t st);
+// dst[r][j] = ss[j * ss_ld + r]: per-tile sums of squares of `rows` GEMM output rows -> table rows
+void launch_ss_to_table(const float* ss, int ss_ld, float* dst, int nss, int rows, hipStream_t st);
 
 // ---- embedding plumbing (lm_misc.hip) ----------------------------------------------------------
 // gather rows of a bf16 table: out[i] = table[ids[i]] (optionally through a token map)

@@ -139,6 +139,11 @@ __global__ void f32_to_bf16_kernel(const float* x, uint16_t* out, int n) {
     if (i < n) out[i] = f2bf(x[i]);
 }
 
+__global__ void ss_to_table_kernel(const float* ss, int ss_ld, float* dst, int nss, int rows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows * nss) dst[i] = ss[(size_t)(i % nss) * ss_ld + i / nss];
+}
+
 __global__ void copy_rows_kernel(const uint16_t* src, int lds, uint16_t* dst, int ldd, int dim) {
     const int r = blockIdx.x;
     const uint4* s = reinterpret_cast<const uint4*>(src + (size_t)r * lds);
@@ -302,6 +307,9 @@ void launch_build_decode_codes(const int32_t* ref, int Tref, const int32_t* gen,
 void launch_f32_to_bf16(const float* x, uint16_t* out, int n, hipStream_t st) {
     if (n <= 0) return;
     hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((n + 255) / 256), dim3(256), 0, st, x, out, n);
+}
+void launch_ss_to_table(const float* ss, int ss_ld, float* dst, int nss, int rows, hipStream_t st) {
+    hipLaunchKernelGGL(ss_to_table_kernel, dim3((rows * nss + 255) / 256), dim3(256), 0, st, ss, ss_ld, dst, nss, rows);
 }
 void launch_copy_rows(const uint16_t* src, int lds, uint16_t* dst, int ldd, int rows, int dim, hipStream_t st) {
     if (rows <= 0) return;

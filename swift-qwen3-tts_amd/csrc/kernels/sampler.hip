@@ -353,7 +353,10 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(SamplerArgs a) {
             for (int j = 0; j < 4; ++j) ss += lo_bf(w[j]) * lo_bf(w[j]) + hi_bf(w[j]) * hi_bf(w[j]);
             *reinterpret_cast<uint4*>(a.next_x + act_tiled_offset(b + a.next_row0, 8 * i, a.next_MB)) = v;
         }
-        if (a.next_ss) {  // sum of squares of the row: first (and only) partial of the consumer's norm prologue
+        if (a.emb_ss) {  // projected table: the per-tile partials the projection GEMM's epilogue would have written
+            for (int j = tid; j < a.nss; j += kThreads)
+                a.next_ss[(size_t)j * a.next_ss_ld + b + a.next_row0] = a.emb_ss[(size_t)used * a.nss + j];
+        } else if (a.next_ss) {  // sum of squares of the row: first (and only) partial of the consumer's norm prologue
             ss = wave_sum(ss);
             __syncthreads();
             if ((tid & 63) == 0) vals[tid >> 6] = ss;

@@ -13,6 +13,7 @@ namespace q3 {
 Model::~Model() {
     if (arena) (void)hipFree(arena);
     for (void* p : side_allocs) (void)hipFree(p);
+    for (void* p : lazy_allocs) (void)hipFree(p);
 }
 
 namespace {

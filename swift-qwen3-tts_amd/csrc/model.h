@@ -172,6 +172,11 @@ struct Model {
     SpeakerEncW speaker;
     int64_t step_weight_bytes = 0;  // distinct weight bytes read by one frame step (roofline)
     std::vector<void*> side_allocs; // pointer tables (absolute addresses; not part of the arena)
+    // small_to_mtp_projection applied to every row of the code predictor's embedding tables: built by the first Engine
+    // with its own decode GEMM (Engine::build_cp_proj_tables), shared by all lanes. [table][Vcp][CH] bf16, [table][Vcp][CH/16]
+    mutable std::vector<const uint16_t*> cp_pe;
+    mutable std::vector<const float*> cp_pss;
+    mutable std::vector<void*> lazy_allocs;
 
     ~Model();
 };

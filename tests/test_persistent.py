@@ -65,3 +65,27 @@ def test_variable_length_and_events(pairs):
     for x, y in zip(ra, rb):
         assert x.status == y.status and (x.codes == y.codes).all()
     assert sorted(ev_a) == sorted(ev_b)
+
+
+def test_projected_embedding_tables_change_nothing(ckpt_dirs, monkeypatch):
+    """The 1.7B-like preset projects every code embedding (small_to_mtp_projection) before the next predictor pass; the
+    engine takes that projection once per table row at load (Engine::build_cp_proj_tables) instead of once per pass.
+    Same GEMM kernel either way, so logits under teacher forcing, sampled codes and PCM must be bit-identical."""
+    from qwen3tts import Qwen3TTSModel
+    d = ckpt_dirs["tiny-b"]   # talker 384 wide, predictor 256: has the projection
+    a = Qwen3TTSModel.from_pretrained(d, max_batch=6, max_frames=64, max_prompt=96)
+    monkeypatch.setenv("Q3TTS_NO_PROJ_TABLES", "1")
+    b = Qwen3TTSModel.from_pretrained(d, max_batch=6, max_frames=64, max_prompt=96)
+    try:
+        reqs = [_req(row=i, n_text=6 + 3 * i) for i in range(5)]
+        kw = dict(temperature=0.9, top_k=40, top_p=0.95, repetition_penalty=1.05, seed=23, force_frames=24)
+        for x, y in zip(a.generate_batch(reqs, **kw), b.generate_batch(reqs, **kw)):
+            assert (x.codes == y.codes).all() and (x.audio == y.audio).all()
+        rng = np.random.default_rng(4)
+        forced = np.concatenate([rng.integers(0, 2048, size=(3, 5, 1)), rng.integers(0, 256, size=(3, 5, 15))], -1).astype(np.int32)
+        ta, ca, sa = a.debug_generate_forced(reqs[:3], forced, temperature=0.0)
+        tb, cb, sb = b.debug_generate_forced(reqs[:3], forced, temperature=0.0)
+        assert (ta == tb).all() and (ca == cb).all() and (sa == sb).all()
+    finally:
+        a.close()
+        b.close()
