@@ -106,7 +106,26 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
     const uint4* Wt = reinterpret_cast<const uint4*>(a.W);
     const uint4* Xt = reinterpret_cast<const uint4*>(a.x);
 
-    // 1. weight loads first: they have the longest latency and depend on nothing
+    // 0. NORM: the producer's per-tile sums of squares are requested before anything else. They gate the whole prologue
+    //    (rstd -> normalised x fragments), and loads return in issue order: with the sums first, the reduction and the
+    //    VALU work on x run while the weight tiles are still arriving instead of after the last of them.
+    constexpr int kSsIter = NORM ? (16 * MB * 8 + NW * 64 - 1) / (NW * 64) : 1;
+    float sst[kSsIter][16];
+    if constexpr (NORM) {
+        const int rows = 16 * MB;
+#pragma unroll
+        for (int it = 0; it < kSsIter; ++it) {
+            const int idx = threadIdx.x + it * NW * 64;
+            const int row = idx % rows, part = idx / rows;  // (row, part): 8 strided partial sums per row
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int j = part + 8 * u;
+                sst[it][u] = (idx < rows * 8) ? a.ss_in[(size_t)(j < a.ss_count ? j : 0) * a.ss_ld + 16 * mb0 + row] : 0.f;
+            }
+        }
+    }
+
+    // 1. weight loads: they depend on nothing
     constexpr int CHR = CH > 0 ? CH : 1;
     constexpr int WL = QUANT ? 1 : 4;  // dwordx4 loads per (chunk, tile): packed int4 needs one
     uint4 wf[CHR][NT][WL];
@@ -125,13 +144,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
             }
         }
     };
-    if constexpr (CH > 0) {
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const int kl = wave + c * NW;
-            load_w(c, kl < KC ? kl : 0);
-        }
-    }
 
     // 1b. every other operand that does not depend on arithmetic is requested now as well, so that the kernel pays
     //     ONE memory round trip instead of a chain of three (sums of squares -> x fragments -> residual tile):
@@ -144,6 +156,19 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
     constexpr int XG = (CH == 0) ? 0 : (kRoom < 1 ? 1 : (kRoom > kCap ? (CH < kCap ? CH : kCap) : (kRoom < CH ? kRoom : CH)));
     uint4 xr[XG > 0 ? XG : 1][MB][4];
     uint4 nwr[(NORM && XG > 0) ? XG : 1][4];
+    // issue order: weights then x, or (NORM) x then weights so that normalising x overlaps the weights' arrival.
+    // Written as a two-trip unrolled loop instead of lambdas: capturing the fragment arrays by reference sends them to scratch.
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+        if ((ph == 0) != NORM) {
+    if constexpr (CH > 0) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int kl = wave + c * NW;
+                load_w(c, kl < KC ? kl : 0);
+            }
+        }
+        } else {
     if constexpr (XG > 0) {
 #pragma unroll
         for (int c = 0; c < XG; ++c) {
@@ -162,6 +187,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
             }
         }
     }
+        }
+    }
     uint4 hv_pre = make_uint4(0, 0, 0, 0);
     if constexpr (EPI == 3) {
         if (a.resid && threadIdx.x < 32 * MB) {
@@ -174,20 +201,18 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
     float rstd[MB];
     if constexpr (NORM) {
         const int rows = 16 * MB;
-        for (int idx = threadIdx.x; idx < rows * 8; idx += NW * 64) {  // (row, part): 8 strided partial sums per row
-            const int row = idx % rows, part = idx / rows;
-            float tmp[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {  // all partials of this (row, part) in flight before the first add (H <= 2048)
-                const int j = part + 8 * u;
-                tmp[u] = a.ss_in[(size_t)(j < a.ss_count ? j : 0) * a.ss_ld + 16 * mb0 + row];
+        for (int it = 0; it < kSsIter; ++it) {
+            const int idx = threadIdx.x + it * NW * 64;
+            if (idx < rows * 8) {
+                const int row = idx % rows, part = idx / rows;
+                float s = 0.f;
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (part + 8 * u < a.ss_count) s += sst[it][u];
+                for (int j = part + 128; j < a.ss_count; j += 8) s += a.ss_in[(size_t)j * a.ss_ld + 16 * mb0 + row];
+                ssp_s[part][row] = s;
             }
-            float s = 0.f;
-#pragma unroll
-            for (int u = 0; u < 16; ++u)
-                if (part + 8 * u < a.ss_count) s += tmp[u];
-            for (int j = part + 128; j < a.ss_count; j += 8) s += a.ss_in[(size_t)j * a.ss_ld + 16 * mb0 + row];
-            ssp_s[part][row] = s;
         }
         __syncthreads();
         if (threadIdx.x < rows) {
