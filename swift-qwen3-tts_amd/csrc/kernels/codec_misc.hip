@@ -148,32 +148,59 @@ __global__ __launch_bounds__(64) void attn_full_f32_kernel(const float* qkv, int
     }
 }
 
-// out[t] = clip(bias + sum_{k,c} snake(x[t-6+k][c]) * w[k][c]); 64 positions per workgroup, 4 lanes each
+// out[t] = clip(bias + sum_{k,c} snake(x[t-6+k][c]) * w[k][c]); 64 positions per workgroup, 4 lanes each.
+// The activated tile (70 rows, stride C + 4 floats so that the 16 positions of a ds_read_b128 lane group spread over
+// the banks) and the 7 x C taps sit in LDS; a lane owns every fourth 4-channel group of its position.
 __global__ __launch_bounds__(256) void out_conv_kernel(const float* x, int C, const float* ea, const float* ib,
                                                        const float* w, const float* bias, const int32_t* frames, int ppf,
                                                        int Tmax, float* pcm) {
-    extern __shared__ __attribute__((aligned(16))) float xs[];  // [(64+6)][C] snake(x)
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [(64+6)][C + 4] snake(x), then [7][C] taps
+    const int ld = C + 4, C4 = C >> 2;
+    float* ws = xs + 70 * ld;
     const int b = blockIdx.y, t0 = blockIdx.x * 64;
     const int T = frames[b] * ppf;
     if (t0 >= T) return;
     const float* xb = x + (size_t)b * Tmax * C;
-    for (int i = threadIdx.x; i < 70 * C; i += 256) {
-        const int r = i / C, c = i % C;
-        const int t = t0 - 6 + r;
-        float v = 0.f;
-        if (t >= 0 && t < T) {
-            v = xb[(size_t)t * C + c];
-            v = v + ib[c] * snake_sin2(v * ea[c]);
+    for (int i = threadIdx.x; i < 7 * C4; i += 256) *reinterpret_cast<float4*>(ws + 4 * i) = *reinterpret_cast<const float4*>(w + 4 * i);
+    {   // (row, 4-channel group) walk without a division per element
+        int r = threadIdx.x / C4, c4 = threadIdx.x % C4;
+        const int dr = 256 / C4, dc = 256 % C4;
+        while (r < 70) {
+            const int t = t0 - 6 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t >= 0 && t < T) {
+                v = *reinterpret_cast<const float4*>(xb + (size_t)t * C + 4 * c4);
+                const float4 e = *reinterpret_cast<const float4*>(ea + 4 * c4), q = *reinterpret_cast<const float4*>(ib + 4 * c4);
+                v.x = v.x + q.x * snake_sin2(v.x * e.x);
+                v.y = v.y + q.y * snake_sin2(v.y * e.y);
+                v.z = v.z + q.z * snake_sin2(v.z * e.z);
+                v.w = v.w + q.w * snake_sin2(v.w * e.w);
+            }
+            *reinterpret_cast<float4*>(xs + r * ld + 4 * c4) = v;
+            r += dr;
+            c4 += dc;
+            if (c4 >= C4) {
+                c4 -= C4;
+                ++r;
+            }
         }
-        xs[i] = v;
     }
     __syncthreads();
     const int p = threadIdx.x >> 2, part = threadIdx.x & 3;
     float acc = 0.f;
-    for (int k = 0; k < 7; ++k)
-        for (int c = part; c < C; c += 4) acc += xs[(p + k) * C + c] * w[k * C + c];
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
+    for (int k = 0; k < 7; ++k) {
+        const float* xr = xs + (p + k) * ld;
+        const float* wr = ws + k * C;
+        for (int g = part; g < C4; g += 4) {
+            const float4 xv = *reinterpret_cast<const float4*>(xr + 4 * g), wv = *reinterpret_cast<const float4*>(wr + 4 * g);
+            acc += xv.x * wv.x;
+            acc += xv.y * wv.y;
+            acc += xv.z * wv.z;
+            acc += xv.w * wv.w;
+        }
+    }
+    acc += XorPartner::x1(acc);
+    acc += XorPartner::x2(acc);
     const int t = t0 + p;
     if (part == 0 && t < T) {
         const float v = acc + bias[0];
@@ -209,8 +236,8 @@ void launch_attn_full_f32(const float* qkv, int heads, const int32_t* frames, in
 }
 void launch_out_conv(const float* x, int C, const float* ea, const float* ib, const float* w, const float* bias,
                      const int32_t* frames, int ppf, int Tmax, int B, float* pcm, hipStream_t st) {
-    const size_t smem = size_t(70) * C * sizeof(float);
-    Q3_CHECK(smem <= 64 * 1024, 3, "out_conv: too many channels");
+    const size_t smem = (size_t(70) * (C + 4) + size_t(7) * C) * sizeof(float);
+    Q3_CHECK(smem <= 64 * 1024 && C % 4 == 0 && C >= 4 && C <= 1024, 3, "out_conv: unsupported channel count");
     hipLaunchKernelGGL(out_conv_kernel, dim3((Tmax + 63) / 64, B), dim3(256), smem, st, x, C, ea, ib, w, bias, frames, ppf,
                        Tmax, pcm);
 }
