@@ -217,7 +217,7 @@ def main():
     value = frames_done / elapsed
     # memory-side bytes per frame step from the PMC passes committed under profiles/ (default workload only)
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01f_frame_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r01g_frame_traffic.json")
     if args.preset == "1.7b" and B == 32 and os.path.exists(tpath):
         traffic = json.load(open(tpath))["traffic_bytes_per_frame_step"]
     step_ms = dec_ms / max(frame_steps, 1)
@@ -239,7 +239,7 @@ def main():
                               "ar_decode": dec_ms / args.steps, "codec_decode": codec_ms / args.steps},
         "roofline": {"bound": "hbm", "kernel": "frame_step (hipGraph: talker step + 16 code-predictor passes + samplers)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_source": "profiles/r01f_frame_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, "
+                     "traffic": traffic, "traffic_source": "profiles/r01g_frame_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, "
                      "Infinity-Cache hits included)" if traffic else None,
                      "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": step_ms},
     }
