@@ -112,14 +112,38 @@ __device__ __forceinline__ Best better(Best a, Best b) {  // larger value, then 
     return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
 }
 
-__device__ Best block_argmax(Best x, Best* scratch) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        Best y;
-        y.v = __shfl_xor(x.v, o, 64);
-        y.i = __shfl_xor(x.i, o, 64);
-        x = better(x, y);
+// lane i ^ o's copy of (v, i) for the butterfly below, on DPP / permlane swaps (common.h XorPartner) instead of ds_bpermute
+template <int O>
+__device__ __forceinline__ Best partner(Best x) {
+    Best y;
+    const float fi = __int_as_float(x.i);
+    if constexpr (O == 32 || O == 16) {
+        float a, b, c, d;
+        if constexpr (O == 32) { XorPartner::swap32(x.v, a, b); XorPartner::swap32(fi, c, d); }
+        else { XorPartner::swap16(x.v, a, b); XorPartner::swap16(fi, c, d); }
+        // a = {lo, lo}, b = {hi, hi}: the partner's value is whichever of the two is not this lane's own copy
+        const bool upper = O == 32 ? ((threadIdx.x & 32) != 0) : ((threadIdx.x & 16) != 0);
+        y.v = upper ? a : b;
+        y.i = __float_as_int(upper ? c : d);
+    } else if constexpr (O == 8) {
+        y.v = XorPartner::x8(x.v); y.i = __float_as_int(XorPartner::x8(fi));
+    } else if constexpr (O == 4) {
+        y.v = XorPartner::x4(x.v); y.i = __float_as_int(XorPartner::x4(fi));
+    } else if constexpr (O == 2) {
+        y.v = XorPartner::x2(x.v); y.i = __float_as_int(XorPartner::x2(fi));
+    } else {
+        y.v = XorPartner::x1(x.v); y.i = __float_as_int(XorPartner::x1(fi));
     }
+    return y;
+}
+
+__device__ Best block_argmax(Best x, Best* scratch) {
+    x = better(x, partner<32>(x));
+    x = better(x, partner<16>(x));
+    x = better(x, partner<8>(x));
+    x = better(x, partner<4>(x));
+    x = better(x, partner<2>(x));
+    x = better(x, partner<1>(x));
     const int wave = threadIdx.x >> 6;
     __syncthreads();
     if ((threadIdx.x & 63) == 0) scratch[wave] = x;
