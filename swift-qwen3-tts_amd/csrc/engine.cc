@@ -89,7 +89,6 @@ Engine::Engine(Model* model, const q3tts_load_opts& opts) : m_(model), opts_(opt
         table(m_->talker, kpool_, vpool_, kv_layer_stride_, &tk_layers_dev_);
         table(m_->cp, cp_kpool_, cp_vpool_, cp_kv_layer_stride_, &cp_layers_dev_);
     }
-    if (m_->has_cp_proj && !persistent_ && !std::getenv("Q3TTS_NO_PROJ_TABLES")) build_cp_proj_tables();
     if (m_->has_codec) codec_ = std::make_unique<CodecRunner>(*m_, st_);
     if (m_->has_codec_encoder || m_->has_speaker_encoder) fe_ = std::make_unique<VoiceFrontEnd>(*m_, st_);
 }
@@ -131,6 +130,7 @@ void Engine::build_cp_proj_tables() {
     const int H = t.hidden_size, CH = m_->cp.hidden, MBL = Mp_ / 16, Vc = t.cp.vocab_size, nss = CH / 16;
     const int ntab = t.num_code_groups - 2;  // embeddings 0..13 feed passes 1..14; the last code feeds nothing
     if (ntab <= 0) return;
+    std::lock_guard<std::mutex> lock(m_->lazy_mutex);  // lanes share the model; the first one to generate builds
     if (m_->cp_pe.empty()) {
         for (int i = 0; i < ntab; ++i) {
             uint16_t* pe = nullptr;
@@ -1025,6 +1025,8 @@ void Engine::generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp
 
     // ---- frame loop ----
     const bool use_graph = opts_.use_graph && !dbg;
+    // the tables are cut from the weights, which may arrive after load (weights_from_broadcast): first use, not load
+    if (!cp_tables_ && m_->has_cp_proj && !persistent_ && !std::getenv("Q3TTS_NO_PROJ_TABLES")) build_cp_proj_tables();
     hipGraphExec_t ge = use_graph ? frame_graph(n) : nullptr;
     std::vector<int32_t> h_nframes((size_t)(n), 0), h_codes;
     std::vector<uint8_t> h_fin((size_t)(n), 0);

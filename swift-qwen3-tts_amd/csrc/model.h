@@ -6,6 +6,7 @@
 // replicas can receive it by one RCCL broadcast (q3tts_model_arena).
 #pragma once
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -177,6 +178,7 @@ struct Model {
     mutable std::vector<const uint16_t*> cp_pe;
     mutable std::vector<const float*> cp_pss;
     mutable std::vector<void*> lazy_allocs;
+    mutable std::mutex lazy_mutex;
 
     ~Model();
 };

@@ -89,3 +89,27 @@ def test_projected_embedding_tables_change_nothing(ckpt_dirs, monkeypatch):
     finally:
         a.close()
         b.close()
+
+
+def test_replica_filled_through_the_arena_generates_the_same(ckpt_dirs):
+    """Multi-GPU load path: a replica allocates its weight arena empty (weights_from_broadcast) and the
+    caller fills it afterwards -- RCCL broadcast in bench.py, a device copy here. Everything the engine derives from
+    the weights (the projected embedding tables) must therefore be cut at first use, not at load."""
+    import ctypes
+    from qwen3tts import Qwen3TTSModel
+    hip = ctypes.CDLL("libamdhip64.so")
+    d = ckpt_dirs["tiny-b"]
+    a = Qwen3TTSModel.from_pretrained(d, max_batch=4, max_frames=48, max_prompt=96)
+    b = Qwen3TTSModel.from_pretrained(d, max_batch=4, max_frames=48, max_prompt=96, weights_from_broadcast=True)
+    try:
+        (pa, na), (pb, nb) = a.arena(), b.arena()
+        assert na == nb and na > 0
+        assert hip.hipMemcpy(ctypes.c_void_p(pb), ctypes.c_void_p(pa), ctypes.c_size_t(na), 3) == 0  # device to device
+        assert hip.hipDeviceSynchronize() == 0
+        reqs = [_req(row=i, n_text=7 + 2 * i) for i in range(3)]
+        kw = dict(temperature=0.9, top_k=40, top_p=1.0, repetition_penalty=1.05, seed=5, force_frames=20)
+        for x, y in zip(a.generate_batch(reqs, **kw), b.generate_batch(reqs, **kw)):
+            assert (x.codes == y.codes).all() and (x.audio == y.audio).all()
+    finally:
+        a.close()
+        b.close()
