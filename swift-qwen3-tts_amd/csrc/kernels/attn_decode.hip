@@ -58,24 +58,6 @@ __global__ __launch_bounds__(NTH) void attn_decode_kernel(AttnArgs a) {
     const int npage = a.identity_pages ? b : bt[len / kPageTokens];
     const size_t nslot = (((size_t)npage * a.n_kv + kvh) * kPageTokens + (len % kPageTokens)) * D;
 
-    // The first cache rows of every lane group are requested before the q/k work: they depend on nothing computed
-    // here, and a code-predictor cache (<= 16 past tokens) is then covered by ONE memory round trip.
-    constexpr int PF = NTH >= 256 ? 8 : 4;
-    const int g = tid >> 4, c = tid & 15;  // lane group g (16 lanes) strides over positions; lane c owns dims 8c..8c+7
-    uint4 kpre[PF], vpre[PF];
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-        const int t = g + u * NG;
-        kpre[u] = make_uint4(0, 0, 0, 0);
-        vpre[u] = make_uint4(0, 0, 0, 0);
-        if (t < len) {
-            const int page = a.identity_pages ? b : bt[t / kPageTokens];
-            const size_t off = (((size_t)page * a.n_kv + kvh) * kPageTokens + (t % kPageTokens)) * D + 8 * c;
-            kpre[u] = *reinterpret_cast<const uint4*>(a.kpool + off);
-            vpre[u] = *reinterpret_cast<const uint4*>(a.vpool + off);
-        }
-    }
-
     // ---- phase 1: q/k norm + rope, v copy; vectors round-robin over the waves. Every vector a wave owns, the norm
     // weights and the RoPE row are loaded before the first store: the compiler cannot move a load above the cache
     // append (it may alias), and a single-wave workgroup would otherwise pay one L2 round trip per vector ----
@@ -94,6 +76,25 @@ __global__ __launch_bounds__(NTH) void attn_decode_kernel(AttnArgs a) {
     }
     const uint16_t qw0 = a.qn_w[lane], qw1 = a.qn_w[lane + 64], kw0 = a.kn_w[lane], kw1 = a.kn_w[lane + 64];
     const uint16_t c0 = cosr[lane], c1 = cosr[lane + 64], s0 = sinr[lane], s1 = sinr[lane + 64];
+    // The first cache rows of every lane group are requested before the q/k ARITHMETIC (they depend on nothing computed
+    // here, and a code-predictor cache of <= 16 past tokens is then covered by one memory round trip) but after the q/k/v
+    // loads above: loads return in issue order, so phase 1 starts on its own operands while the cache rows still arrive.
+    constexpr int PF = NTH >= 256 ? 8 : 4;
+    const int g = tid >> 4, c = tid & 15;  // lane group g (16 lanes) strides over positions; lane c owns dims 8c..8c+7
+    uint4 kpre[PF], vpre[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        const int t = g + u * NG;
+        kpre[u] = make_uint4(0, 0, 0, 0);
+        vpre[u] = make_uint4(0, 0, 0, 0);
+        if (t < len) {
+            const int page = a.identity_pages ? b : bt[t / kPageTokens];
+            const size_t off = (((size_t)page * a.n_kv + kvh) * kPageTokens + (t % kPageTokens)) * D + 8 * c;
+            kpre[u] = *reinterpret_cast<const uint4*>(a.kpool + off);
+            vpre[u] = *reinterpret_cast<const uint4*>(a.vpool + off);
+        }
+    }
+
     auto norm_rope_r = [&](float x0, float x1, uint16_t w0, uint16_t w1, float& o0, float& o1) {
         const float ss = wave_sum(x0 * x0 + x1 * x1);
         const float rstd = 1.0f / sqrtf(ss / (float)D + a.eps);
