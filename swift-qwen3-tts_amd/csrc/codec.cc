@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <utility>
 
 #include "codec_kernels.h"
 
@@ -17,6 +18,8 @@ CodecRunner::CodecRunner(const Model& m, hipStream_t st) : m_(m), st_(st) {
     Q3_CHECK(m.cfg.codec.head_dim == 64, 6, "codec transformer head_dim must be 64");
     const char* e = std::getenv("Q3TTS_CODEC_FP32");
     fp32_mfma_ = e && e[0] == '1';
+    const char* nf = std::getenv("Q3TTS_CODEC_NO_FUSE");
+    no_fuse_ = nf && nf[0] == '1';
 }
 
 CodecRunner::~CodecRunner() {
@@ -158,12 +161,37 @@ int CodecRunner::decode(const int32_t* codes_dev, int code_stride_frames, const 
             const auto& Bk = w.blocks[i];
             // in: bufs[cur + 1] = snake_i(previous stage). y (raw residual stream), ya = act1(y) / next snake(y), t1 = act2(conv1)
             float *hs = bufs[(cur + 1) & 3], *y = bufs[(cur + 2) & 3], *ya = bufs[(cur + 3) & 3], *t1 = bufs[cur];
+            const SnakeW* after = i + 1 < nblk ? &w.blocks[i + 1].snake : nullptr;
+            bool fused = !fp32_mfma_ && !no_fuse_ && resunit_supported(Bk.Cout, Bk.res[0].conv1.K, 9);
+            for (int j = 0; j < 3; ++j)
+                fused = fused && Bk.res[j].conv1.w3 && Bk.res[j].conv2.w3p && Bk.res[j].conv1.N == Bk.Cout && Bk.res[j].conv2.K == 1 &&
+                        resunit_supported(Bk.Cout, Bk.res[j].conv1.K, Bk.res[j].conv1.dil);
+            if (fused) {
+                // narrow blocks: each residual unit is one launch, y ping-pongs between two buffers (codec_conv.hip)
+                conv(Bk.tconv, hs, T, ppf, y, nullptr, nullptr, 0);  // snake (already applied by the producer) -> transposed conv
+                T *= Bk.stride;
+                ppf *= Bk.stride;
+                float *yin = y, *yout = t1;
+                for (int j = 0; j < 3; ++j) {
+                    ResUnitArgs r{};
+                    r.y = yin; r.out = yout;
+                    if (j == 2 && after) { r.out2 = hs; r.post_ea = after->ea; r.post_ib = after->ib; }
+                    r.w1 = Bk.res[j].conv1.w3; r.b1 = Bk.res[j].conv1.bias; r.w2p = Bk.res[j].conv2.w3p; r.b2 = Bk.res[j].conv2.bias;
+                    r.ea1 = Bk.res[j].act1.ea; r.ib1 = Bk.res[j].act1.ib; r.ea2 = Bk.res[j].act2.ea; r.ib2 = Bk.res[j].act2.ib;
+                    r.frames = fr; r.ppf = ppf; r.Tmax = T; r.B = nb; r.C = Bk.Cout; r.K = Bk.res[j].conv1.K; r.dil = Bk.res[j].conv1.dil;
+                    launch_resunit(r, st_);
+                    std::swap(yin, yout);
+                }
+                // three units: the result sits in t1 = bufs[cur], its activated copy (if any) in hs = bufs[cur + 1]
+                capture(("block" + std::to_string(i)).c_str(), bufs[cur], T, Bk.Cout, nb);
+                continue;
+            }
             conv(Bk.tconv, hs, T, ppf, y, nullptr, nullptr, 0, &Bk.res[0].act1, ya);  // snake -> transposed conv (:474-475)
             T *= Bk.stride;
             ppf *= Bk.stride;
             for (int j = 0; j < 3; ++j) {  // DecoderResidualUnit (:430-437): y += conv2(act2(conv1(act1(y))))
                 conv(Bk.res[j].conv1, ya, T, ppf, nullptr, nullptr, nullptr, 0, &Bk.res[j].act2, t1);
-                const SnakeW* next = j < 2 ? &Bk.res[j + 1].act1 : (i + 1 < nblk ? &w.blocks[i + 1].snake : nullptr);
+                const SnakeW* next = j < 2 ? &Bk.res[j + 1].act1 : after;
                 conv(Bk.res[j].conv2, t1, T, ppf, y, nullptr, y, 0, next, ya);
             }
             cur = (cur + 2) & 3;  // bufs[cur] = y, bufs[cur + 1] = next block's snake of it

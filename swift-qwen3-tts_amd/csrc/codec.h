@@ -25,6 +25,7 @@ class CodecRunner {
     const Model& m_;
     hipStream_t st_;
     int up_ = 1920;
+    bool no_fuse_ = false;    // Q3TTS_CODEC_NO_FUSE=1: residual units of the narrow blocks as two launches each
     bool fp32_mfma_ = false;  // Q3TTS_CODEC_FP32=1: contract on the fp32 matrix-core path instead of the bf16x3 one
     uint8_t* buf_ = nullptr;
     size_t buf_bytes_ = 0;

@@ -43,6 +43,29 @@ struct ConvGemmArgs {
 };
 void launch_conv_gemm(const ConvGemmArgs& a, hipStream_t st);
 
+// DecoderResidualUnit (SpeechTokenizer.swift:430-437) in one launch: out = y + conv2(act2(conv1(act1(y)))) with conv1
+// k taps / dilation `dil`, conv2 pointwise, C channels on both (C = 32, 64 or 96). Neither act1(y) nor conv1's
+// output touch HBM: y is read once (+ halo) and the sum written once, to a different buffer than y.
+struct ResUnitArgs {
+    const float* y;       // [B][Tmax][C]
+    float* out;           // [B][Tmax][C], != y
+    float* out2;          // optional: SnakeBeta(post_ea, post_ib) of the result (next block's input) or nullptr
+    const float* post_ea;
+    const float* post_ib;
+    const uint16_t* w1;   // conv1 split planes [K][C/32][C][3][32]
+    const float* b1;      // [C] or nullptr
+    const uint16_t* w2p;  // conv2 split planes, permuted k order [C/32][C][3][32] (model.cc attach_split_perm)
+    const float* b2;
+    const float* ea1;     // act1: exp(alpha), 1/(exp(beta)+1e-9)
+    const float* ib1;
+    const float* ea2;     // act2
+    const float* ib2;
+    const int32_t* frames;
+    int ppf, Tmax, B, C, K, dil;
+};
+bool resunit_supported(int C, int K, int dil);
+void launch_resunit(const ResUnitArgs& a, hipStream_t st);
+
 // Split-RVQ gather (SpeechTokenizer.swift:214-226, 81-96): out[b][f] = [cb_first[c0] | sum_j cb_rest[j][c_{j+1}]]
 void launch_rvq_gather(const int32_t* codes, int code_stride_frames, const float* cb_first,
                        const float* const* cb_rest, int n_rest, int inner, const int32_t* frames, int Fmax, int B,

@@ -466,7 +466,297 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvGemmArgs a)
     if (a.out2) snake_pass<CT>(a, reinterpret_cast<float*>(smem3), b, t0, n0, wn, T, wave, lane, acc, wm);
 }
 
+// ---- fused residual unit -------------------------------------------------------------------------------
+// out = y + conv2(act2(conv1(act1(y)))) (DecoderResidualUnit, SpeechTokenizer.swift:430-437) for the narrow, long blocks
+// (C <= 96 channels at up to 384 k positions per row), which are HBM-bound when every conv is its own launch: six
+// tensor passes per unit (act1 copy in, conv1 out, conv1 out back in, y in, y out, act1 copy out) become two.
+//  * act1 is applied while the raw tile of y (+ causal halo) is staged -- one N tile, so nothing is evaluated twice
+//    except the halo rows;
+//  * each wave owns 32 positions x ALL channels, so conv1's accumulators already hold conv2's whole reduction dimension:
+//    an accumulator pair (tiles 2m, 2m+1) of a lane is exactly one bf16 MFMA B fragment (8 k values of its position)
+//    once conv2's weights are stored with the matching k order (model.cc attach_split_perm) -- act2 and the 3-way
+//    split happen in registers and conv1's output never leaves the wave;
+//  * the residual is the raw y tile again (L2-warm), the sum goes to a second buffer because neighbouring workgroups
+//    still need the old halo rows.
+// LDS: (128 + halo + C) rows x 224 B <= 62 KiB, two workgroups per CU.
+template <int CT2>
+__global__ __launch_bounds__(256, 2) void resunit_split_kernel(ResUnitArgs a) {
+    constexpr int C = 16 * CT2, NCH = CT2 / 2;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem3[];
+    const int halo = (a.K - 1) * a.dil;
+    uint32_t* As = smem3;                        // [(BM + halo)][ROW3]
+    uint32_t* Ws = smem3 + (BM + halo) * ROW3;   // [C][ROW3]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.y * BM;
+    const int T = a.frames[b] * a.ppf;
+    if (t0 >= T) return;
+    const int rows = BM + halo;
+    const size_t boff = (size_t)b * a.Tmax * C;
+    const float* yb = a.y + boff;
+    const int S1 = NCH * a.K;  // conv1 steps; conv2 adds NCH more
+
+    f32x4 acc1[2][CT2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int c = 0; c < CT2; ++c) acc1[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int WV = (C * 12 + 255) / 256;
+    uint4 wreg[WV];
+    auto load_w = [&](int step) {
+        const uint4* src;
+        if (step < S1) {
+            const int chunk = step / a.K, tap = step % a.K;
+            src = reinterpret_cast<const uint4*>(a.w1 + (size_t)(tap * NCH + chunk) * C * 96);
+        } else {
+            src = reinterpret_cast<const uint4*>(a.w2p + (size_t)(step - S1) * C * 96);
+        }
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int item = i * 256 + tid;
+            wreg[i] = item < C * 12 ? src[item] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int item = i * 256 + tid;
+            if (item < C * 12) *reinterpret_cast<uint4*>(&Ws[(item / 12) * ROW3 + (item % 12) * 4]) = wreg[i];
+        }
+    };
+
+    constexpr int AV = ((BM + MAX_HALO) * 8 + 255) / 256;
+    float4 areg[AV];
+    auto load_a = [&](int chunk) {
+        const int c0 = chunk * KC;
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int item = i * 256 + tid;
+            const int r = item >> 3, c4 = (item & 7) * 4;
+            const int t = t0 - halo + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < rows && t >= 0 && t < T) {
+                v = *reinterpret_cast<const float4*>(yb + (size_t)t * C + c0 + c4);
+                const float4 ea = *reinterpret_cast<const float4*>(a.ea1 + c0 + c4);
+                const float4 ib = *reinterpret_cast<const float4*>(a.ib1 + c0 + c4);
+                v.x = v.x + ib.x * snake_sin2(v.x * ea.x);
+                v.y = v.y + ib.y * snake_sin2(v.y * ea.y);
+                v.z = v.z + ib.z * snake_sin2(v.z * ea.z);
+                v.w = v.w + ib.w * snake_sin2(v.w * ea.w);
+            }
+            areg[i] = v;
+        }
+    };
+    auto store_a = [&]() {
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int item = i * 256 + tid;
+            const int r = item >> 3, c4 = (item & 7) * 4;
+            if (r >= rows) continue;
+            uint32_t h[4], m[4], l[4];
+            split3(areg[i].x, h[0], m[0], l[0]);
+            split3(areg[i].y, h[1], m[1], l[1]);
+            split3(areg[i].z, h[2], m[2], l[2]);
+            split3(areg[i].w, h[3], m[3], l[3]);
+            uint32_t* dst = &As[r * ROW3 + (c4 >> 1)];
+            *reinterpret_cast<uint2*>(dst) = make_uint2((h[0] >> 16) | h[1], (h[2] >> 16) | h[3]);
+            *reinterpret_cast<uint2*>(dst + 16) = make_uint2((m[0] >> 16) | m[1], (m[2] >> 16) | m[3]);
+            *reinterpret_cast<uint2*>(dst + 32) = make_uint2((l[0] >> 16) | l[1], (l[2] >> 16) | l[3]);
+        }
+    };
+    constexpr int PW[6] = {2, 0, 1, 1, 0, 0};  // (weight plane, activation plane), smallest product first
+    constexpr int PX[6] = {0, 2, 1, 0, 1, 0};
+    const uint32_t* wrow = &Ws[(lane & 15) * ROW3 + 4 * (lane >> 4)];
+
+    // ---- conv1 ----
+    load_w(0);
+    load_a(0);
+    for (int chunk = 0; chunk < NCH; ++chunk) {
+        __syncthreads();
+        store_a();
+        if (chunk + 1 < NCH) load_a(chunk + 1);
+        for (int tap = 0; tap < a.K; ++tap) {
+            const int step = chunk * a.K + tap;
+            if (tap > 0) __syncthreads();
+            store_w();
+            __syncthreads();
+            load_w(step + 1);  // the step after conv1's last one is conv2's first
+            const uint32_t* arow = &As[(32 * wave + tap * a.dil + (lane & 15)) * ROW3 + 4 * (lane >> 4)];
+            uint4 xa[3][2], wa[3][CT2];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) xa[pl][p] = *reinterpret_cast<const uint4*>(arow + p * 16 * ROW3 + pl * 16);
+#pragma unroll
+                for (int c = 0; c < CT2; ++c) wa[pl][c] = *reinterpret_cast<const uint4*>(wrow + c * 16 * ROW3 + pl * 16);
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int c = 0; c < CT2; ++c) acc1[p][c] = mfma_bf16(wa[PW[q]][c], xa[PX[q]][p], acc1[p][c]);
+        }
+    }
+
+    // ---- + bias1, act2 in registers (lane: channels 16c + 4(lane >> 4) + j of its two position tiles) ----
+    const int q4 = 4 * (lane >> 4);
+    int big = 0;
+#pragma unroll
+    for (int c = 0; c < CT2; ++c) {
+        const float4 bv = a.b1 ? *reinterpret_cast<const float4*>(a.b1 + 16 * c + q4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 ea = *reinterpret_cast<const float4*>(a.ea2 + 16 * c + q4);
+        const float e[4] = {ea.x, ea.y, ea.z, ea.w}, bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc1[p][c][j] += bb[j];
+                big |= !(fabsf(acc1[p][c][j] * e[j]) < 1.0e6f);
+            }
+    }
+    // block-wide vote (also the barrier that retires conv1's tiles): arguments beyond the polynomial's range are possible
+    // only in a diverged model; the whole workgroup then goes through the libm path, one tile at a time via LDS
+    if (__syncthreads_or(big)) {
+        float4* stash = reinterpret_cast<float4*>(As) + wave * (CT2 * 64);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int c = 0; c < CT2; ++c) stash[c * 64 + lane] = make_float4(acc1[p][c][0], acc1[p][c][1], acc1[p][c][2], acc1[p][c][3]);
+#pragma unroll 1
+            for (int c = 0; c < CT2; ++c) {
+                float4 v = stash[c * 64 + lane];
+                const float4 ea = *reinterpret_cast<const float4*>(a.ea2 + 16 * c + q4);
+                const float4 ib = *reinterpret_cast<const float4*>(a.ib2 + 16 * c + q4);
+                v.x = v.x + ib.x * snake_sin2(v.x * ea.x);
+                v.y = v.y + ib.y * snake_sin2(v.y * ea.y);
+                v.z = v.z + ib.z * snake_sin2(v.z * ea.z);
+                v.w = v.w + ib.w * snake_sin2(v.w * ea.w);
+                stash[c * 64 + lane] = v;
+            }
+#pragma unroll
+            for (int c = 0; c < CT2; ++c) {
+                const float4 v = stash[c * 64 + lane];
+                acc1[p][c] = f32x4{v.x, v.y, v.z, v.w};
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CT2; ++c) {
+            const float4 ea = *reinterpret_cast<const float4*>(a.ea2 + 16 * c + q4);
+            const float4 ib = *reinterpret_cast<const float4*>(a.ib2 + 16 * c + q4);
+            const float e[4] = {ea.x, ea.y, ea.z, ea.w}, ii[4] = {ib.x, ib.y, ib.z, ib.w};
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc1[p][c][j] = acc1[p][c][j] + ii[j] * snake_sin2_poly(acc1[p][c][j] * e[j]);
+        }
+    }
+
+    // ---- conv2: the B fragments come out of acc1 ----
+    f32x4 acc2[2][CT2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int c = 0; c < CT2; ++c) acc2[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < NCH; ++m) {
+        if (m > 0) __syncthreads();  // the previous chunk's reads of Ws (chunk 0: the vote above)
+        store_w();
+        __syncthreads();
+        if (m + 1 < NCH) load_w(S1 + m + 1);
+        uint4 xb[3][2], wa[3][CT2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const float v[8] = {acc1[p][2 * m][0], acc1[p][2 * m][1], acc1[p][2 * m][2], acc1[p][2 * m][3],
+                                acc1[p][2 * m + 1][0], acc1[p][2 * m + 1][1], acc1[p][2 * m + 1][2], acc1[p][2 * m + 1][3]};
+            uint32_t h[8], mm[8], l[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) split3(v[j], h[j], mm[j], l[j]);
+            xb[0][p] = make_uint4((h[0] >> 16) | h[1], (h[2] >> 16) | h[3], (h[4] >> 16) | h[5], (h[6] >> 16) | h[7]);
+            xb[1][p] = make_uint4((mm[0] >> 16) | mm[1], (mm[2] >> 16) | mm[3], (mm[4] >> 16) | mm[5], (mm[6] >> 16) | mm[7]);
+            xb[2][p] = make_uint4((l[0] >> 16) | l[1], (l[2] >> 16) | l[3], (l[4] >> 16) | l[5], (l[6] >> 16) | l[7]);
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int c = 0; c < CT2; ++c) wa[pl][c] = *reinterpret_cast<const uint4*>(wrow + c * 16 * ROW3 + pl * 16);
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int c = 0; c < CT2; ++c) acc2[p][c] = mfma_bf16(wa[PW[q]][c], xb[PX[q]][p], acc2[p][c]);
+    }
+
+    // ---- + bias2 + y -> out; optionally the next block's SnakeBeta of the sum -> out2 ----
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int t = t0 + 32 * wave + 16 * p + (lane & 15);
+        if (t >= T) continue;
+#pragma unroll
+        for (int c = 0; c < CT2; ++c) {
+            const int n = 16 * c + q4;
+            const float4 rv = *reinterpret_cast<const float4*>(yb + (size_t)t * C + n);
+            float4 v = make_float4(acc2[p][c][0] + rv.x, acc2[p][c][1] + rv.y, acc2[p][c][2] + rv.z, acc2[p][c][3] + rv.w);
+            if (a.b2) {
+                const float4 bv = *reinterpret_cast<const float4*>(a.b2 + n);
+                v = make_float4((acc2[p][c][0] + bv.x) + rv.x, (acc2[p][c][1] + bv.y) + rv.y, (acc2[p][c][2] + bv.z) + rv.z,
+                                (acc2[p][c][3] + bv.w) + rv.w);
+            }
+            *reinterpret_cast<float4*>(a.out + boff + (size_t)t * C + n) = v;
+            acc2[p][c] = f32x4{v.x, v.y, v.z, v.w};
+        }
+    }
+    if (a.out2) {  // As is free since the vote; every lane uses its own stash slots
+        float4* stash = reinterpret_cast<float4*>(As) + wave * (CT2 * 64);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int c = 0; c < CT2; ++c) stash[c * 64 + lane] = make_float4(acc2[p][c][0], acc2[p][c][1], acc2[p][c][2], acc2[p][c][3]);
+            const int t = t0 + 32 * wave + 16 * p + (lane & 15);
+            if (t >= T) continue;
+#pragma unroll 1
+            for (int c = 0; c < CT2; ++c) {
+                const int n = 16 * c + q4;
+                float4 v = stash[c * 64 + lane];
+                const float4 ea = *reinterpret_cast<const float4*>(a.post_ea + n);
+                const float4 ib = *reinterpret_cast<const float4*>(a.post_ib + n);
+                v.x = v.x + ib.x * snake_sin2(v.x * ea.x);
+                v.y = v.y + ib.y * snake_sin2(v.y * ea.y);
+                v.z = v.z + ib.z * snake_sin2(v.z * ea.z);
+                v.w = v.w + ib.w * snake_sin2(v.w * ea.w);
+                *reinterpret_cast<float4*>(a.out2 + boff + (size_t)t * C + n) = v;
+            }
+        }
+    }
+}
+
 }  // namespace
+
+bool resunit_supported(int C, int K, int dil) { return (C == 32 || C == 64 || C == 96) && K >= 1 && (K - 1) * dil <= MAX_HALO; }
+
+void launch_resunit(const ResUnitArgs& a, hipStream_t st) {
+    Q3_CHECK(resunit_supported(a.C, a.K, a.dil) && a.out != a.y, 3, "resunit: unsupported geometry");
+    const int mt = (a.Tmax + BM - 1) / BM;
+    if (mt <= 0 || a.B <= 0) return;
+    static bool attr_set = false;
+    if (!attr_set) {
+        void (*ks[3])(ResUnitArgs) = {&resunit_split_kernel<2>, &resunit_split_kernel<4>, &resunit_split_kernel<6>};
+        for (auto k : ks)
+            Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        attr_set = true;
+    }
+    dim3 grid(1, mt, a.B), block(256);
+    const size_t smem = size_t(BM + (a.K - 1) * a.dil + a.C) * ROW3 * sizeof(uint32_t);
+    switch (a.C) {
+        case 32: hipLaunchKernelGGL(resunit_split_kernel<2>, grid, block, smem, st, a); break;
+        case 64: hipLaunchKernelGGL(resunit_split_kernel<4>, grid, block, smem, st, a); break;
+        default: hipLaunchKernelGGL(resunit_split_kernel<6>, grid, block, smem, st, a); break;
+    }
+}
 
 void launch_conv_gemm(const ConvGemmArgs& a, hipStream_t st) {
     Q3_CHECK((a.K - 1) * a.dil <= MAX_HALO, 3, "conv_gemm: receptive field too large");

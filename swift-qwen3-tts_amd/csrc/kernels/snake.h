@@ -9,11 +9,8 @@
 
 namespace q3 {
 
-__device__ __forceinline__ float snake_sin2(float u) {
-    if (__builtin_expect(!(fabsf(u) < 1.0e6f), 0)) {
-        const float s = sinf(u);
-        return s * s;
-    }
+// the polynomial path alone (callers vote on !(|u| < 1e6) and take snake_sin2 for the whole tile when it fires)
+__device__ __forceinline__ float snake_sin2_poly(float u) {
     const float k = __builtin_rintf(u * 0.636619772367581343f);
     float r = __builtin_fmaf(k, -1.57079637050628662109375f, u);
     r = __builtin_fmaf(k, 4.37113900018624283e-8f, r);
@@ -23,6 +20,14 @@ __device__ __forceinline__ float snake_sin2(float u) {
     const float s = __builtin_fmaf(r * r2, p, r);
     const float s2 = s * s;
     return (static_cast<int>(k) & 1) ? 1.0f - s2 : s2;
+}
+
+__device__ __forceinline__ float snake_sin2(float u) {
+    if (__builtin_expect(!(fabsf(u) < 1.0e6f), 0)) {
+        const float s = sinf(u);
+        return s * s;
+    }
+    return snake_sin2_poly(u);
 }
 
 }  // namespace q3

@@ -558,6 +558,27 @@ void attach_split(Builder& b, ConvW& c, const std::vector<float>& w) {
     c.w3 = b.put<uint16_t>(p.empty() ? nullptr : p.data(), n);
 }
 
+// conv2 of a residual unit for the fused kernel: k slot s = 8q + 4e + j of chunk m holds input channel 32m + 16e + 4q + j,
+// i.e. what lane group q of an MFMA accumulator pair (tiles 2m, 2m+1) carries in registers j of tile e
+void attach_split_perm(Builder& b, ConvW& c, const std::vector<float>& w) {
+    if (!b.split3 || c.K != 1 || c.Cin % 32 != 0) return;
+    const int chunks = c.Cin / 32;
+    const size_t n = size_t(chunks) * c.N * 96;
+    std::vector<uint16_t> p;
+    if (!b.dry && b.fill && !w.empty()) {
+        p.assign(n, 0);
+        for (int nn = 0; nn < c.N; ++nn)
+            for (int m = 0; m < chunks; ++m)
+                for (int s = 0; s < 32; ++s) {
+                    const int q = s >> 3, e = (s >> 2) & 1, j = s & 3;
+                    const int ci = 32 * m + 16 * e + 4 * q + j;
+                    uint16_t* d = &p[(size_t(m) * c.N + nn) * 96 + s];
+                    split_bf16x3(w[size_t(nn) * c.Cin + ci], d[0], d[32], d[64]);
+                }
+    }
+    c.w3p = b.put<uint16_t>(p.empty() ? nullptr : p.data(), n);
+}
+
 ConvW put_conv(Builder& b, const TMap& t, const std::string& name, int dil = 1) {
     const HostTensor& w = need(t, name + ".weight");
     ConvW c;
@@ -744,6 +765,7 @@ void build_codec(Builder& b, const TMap& t, const CodecDecoderConfig& dc, CodecW
             B.res[j].conv1 = put_conv(b, t, rp + ".conv1.conv", dils[j]);
             B.res[j].act2 = put_snake(b, t, rp + ".act2");
             B.res[j].conv2 = put_conv(b, t, rp + ".conv2.conv");
+            attach_split_perm(b, B.res[j].conv2, need(t, rp + ".conv2.conv.weight").data);
         }
     }
     c.out_snake = put_snake(b, t, "decoder.decoder.outSnake");
