@@ -104,3 +104,29 @@ def test_full_size_codec_both_contraction_paths_match_the_oracle(full_codec_dir,
     print("worst stage error / stage scale: bf16x3 %.2e, fp32 MFMA %.2e" % (worst["0"], worst["1"]))
     # measured: 4.3e-5 for both at block3 (the SnakeBeta chain amplifies fp32 rounding noise of ANY summation order)
     assert worst["0"] <= 1.5 * worst["1"] + 1e-6         # the split path is no noisier than the fp32 matrix cores
+
+
+def test_full_size_codec_ragged_rows_match_the_oracle(full_codec_dir):
+    """Two rows of different length through the real-width decoder (fused residual units in the 96-channel block, hoisted
+    SnakeBeta elsewhere): each row must equal the oracle's decode of that row alone, and nothing may leak past a row's end."""
+    from oracle import oracle as O
+    from qwen3tts import Qwen3TTSModel
+    om = O.OracleModel(full_codec_dir)
+    rng = np.random.default_rng(9)
+    F = [3, 2]
+    codes = np.zeros((2, 3, 16), np.int32)
+    for b, f in enumerate(F):
+        codes[b, :f] = rng.integers(1, 2048, size=(f, 16))
+    m = Qwen3TTSModel.from_pretrained(full_codec_dir, max_batch=2, max_frames=8, max_prompt=64)
+    try:
+        pcm, lens = m.codec_decode(codes, n_frames=F)
+        for b, f in enumerate(F):
+            ref, valid = om.codec_decode(codes[b, :f])
+            assert lens[b] == valid == f * 1920
+            # random-init weights drive the output into the clip; compare where the oracle is inside (-1, 1)
+            inside = np.abs(ref) < 0.999
+            assert inside.mean() > 0.05
+            assert np.abs(pcm[b, :f * 1920] - ref)[inside].max() <= 2e-3
+            assert (pcm[b, f * 1920:] == 0).all()
+    finally:
+        m.close()
