@@ -156,40 +156,56 @@ __device__ Best block_argmax(Best x, Best* scratch) {
 __global__ __launch_bounds__(kThreads) void sampler_kernel(SamplerArgs a) {
     __shared__ float vals[kMaxV];
     __shared__ uint32_t sortbuf[kMaxV];
-    __shared__ uint32_t hist[256];
+    __shared__ uint32_t hist[2][256];
     __shared__ Best scratch[kThreads / 64];
-    __shared__ uint32_t wcount[kThreads / 64];
-    __shared__ int sel[4];
+    __shared__ uint32_t wcount[kElems][kThreads / 64];
+    __shared__ int sel[2][2];
 
     const int b = blockIdx.x, tid = threadIdx.x;
+    // Every operand is requested before the first branch: the row's logits and repetition flags do not depend on the
+    // flags that decide whether the row is still live, and a finished row wastes a few loads instead of every live row
+    // paying a second memory round trip.
+    const int V = a.V;
+    const uint16_t* lrow = a.logits + (size_t)b * a.ldl;
+    uint16_t raw[kElems];
+    uint8_t was_seen[kElems];
+    const bool want_seen = a.is_talker && a.seen;
+#pragma unroll
+    for (int k = 0; k < kElems; ++k) {
+        const int i = k * kThreads + tid;
+        raw[k] = i < V ? lrow[i] : (uint16_t)0;
+        was_seen[k] = (want_seen && i < V) ? a.seen[(size_t)b * V + i] : (uint8_t)0;
+    }
     const SamplingParams sp = *a.sp;
     const bool row_done = a.finished[b] != 0;
     const int frame = a.n_frames[b];
     const bool gate = a.advance_gate ? (a.advance_gate[b] != 0) : true;
+    if (tid < 256) {  // both radix levels' histograms, zeroed under the loads
+        hist[0][tid] = 0;
+        hist[1][tid] = 0;
+    }
     if (row_done) {
         if (tid == 0 && a.advance && gate && !a.advance_gate) a.kv_len[b] += 1;  // predictor rows keep in step
         return;
     }
-    const int V = a.V;
-    const uint16_t* lrow = a.logits + (size_t)b * a.ldl;
     if (a.logits_dump && frame < a.forced_frames)
         for (int i = tid; i < V; i += kThreads)
             a.logits_dump[((size_t)b * a.forced_frames + frame) * a.dump_ld + a.dump_off + i] = lrow[i];
 
     // ---- 1+2: suppress, repetition penalty ----
     const float pen = rbf(sp.rep_penalty);
-    const bool use_pen = a.is_talker && a.seen && sp.rep_penalty != 1.0f;
+    const bool use_pen = want_seen && sp.rep_penalty != 1.0f;
     float l[kElems];
 #pragma unroll
     for (int k = 0; k < kElems; ++k) {
         const int i = k * kThreads + tid;
         float v = -INFINITY;
         if (i < V) {
-            v = bf2f(lrow[i]);
+            v = bf2f(raw[k]);
             if (a.is_talker) {
                 if (i >= a.suppress_lo && i < a.suppress_hi && i != a.eos_id) v = -INFINITY;
                 if (sp.mask_eos && i == a.eos_id) v = -INFINITY;
-                if (use_pen && a.seen[(size_t)b * V + i]) v = (v < 0.f) ? rbf(v * pen) : rbf(v / pen);
+                if (use_pen && was_seen[k]) v = (v < 0.f) ? rbf(v * pen) : rbf(v / pen);
             }
         }
         l[k] = v;
@@ -217,18 +233,17 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(SamplerArgs a) {
             for (int k = 0; k < kElems; ++k) key[k] = key16(l[k]);
             int need = sp.top_k;
             uint32_t prefix = 0;  // selected high byte
-            for (int level = 0; level < 2; ++level) {
-                if (tid < 256) hist[tid] = 0;
-                __syncthreads();
+            for (int level = 0; level < 2; ++level) {  // hist[level] was zeroed at the top; two barriers per level
 #pragma unroll
                 for (int k = 0; k < kElems; ++k) {
                     const int i = k * kThreads + tid;
                     if (i < V && (level == 0 || (key[k] >> 8) == prefix))
-                        atomicAdd(&hist[level == 0 ? (key[k] >> 8) : (key[k] & 0xff)], 1u);
+                        atomicAdd(&hist[level][level == 0 ? (key[k] >> 8) : (key[k] & 0xff)], 1u);
                 }
                 __syncthreads();
                 if (tid < 64) {  // one wave: lane l owns bins 4l..4l+3; inclusive suffix sums by shuffles
-                    const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+                    const uint32_t* hl = hist[level];
+                    const uint32_t h0 = hl[4 * tid], h1 = hl[4 * tid + 1], h2 = hl[4 * tid + 2], h3 = hl[4 * tid + 3];
                     const int own = (int)(h0 + h1 + h2 + h3);
                     int suf = own;  // sum over lanes >= tid
 #pragma unroll
@@ -247,40 +262,46 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(SamplerArgs a) {
                             if (cum + hh[bin & 3] >= need) break;
                             cum += hh[bin & 3];
                         }
-                        sel[0] = bin;
-                        sel[1] = need - cum;
+                        sel[level][0] = bin;
+                        sel[level][1] = need - cum;
                     }
                     if (none && tid == 0) {
-                        sel[0] = 0;
-                        sel[1] = need - (suf - (int)h0);
+                        sel[level][0] = 0;
+                        sel[level][1] = need - (suf - (int)h0);
                     }
                 }
                 __syncthreads();
-                if (level == 0) prefix = (uint32_t)sel[0];
-                else prefix = (prefix << 8) | (uint32_t)sel[0];
-                need = sel[1];
-                __syncthreads();
+                if (level == 0) prefix = (uint32_t)sel[0][0];
+                else prefix = (prefix << 8) | (uint32_t)sel[1][0];
+                need = sel[level][1];
             }
             const uint32_t kt = prefix;  // threshold key; `need` equal-key elements survive
-            int base = 0;
-#pragma unroll
-            for (int k = 0; k < kElems; ++k) {
-                const int i = k * kThreads + tid;
-                const bool eq = (i < V) && key[k] == kt;
-                const unsigned long long bal = __ballot(eq);
+            // rank of every threshold-key element in index order: per-wave counts of all kElems slices, one barrier
+            unsigned long long bal[kElems];
+            {
                 const int lane = tid & 63, wave = tid >> 6;
-                const int below = __popcll(bal & ((1ull << lane) - 1ull));
-                if (lane == 0) wcount[wave] = (uint32_t)__popcll(bal);
-                __syncthreads();
-                int woff = 0, total = 0;
-                for (int w = 0; w < kThreads / 64; ++w) {
-                    if (w < wave) woff += (int)wcount[w];
-                    total += (int)wcount[w];
+#pragma unroll
+                for (int k = 0; k < kElems; ++k) {
+                    const int i = k * kThreads + tid;
+                    bal[k] = __ballot((i < V) && key[k] == kt);
+                    if (lane == 0) wcount[k][wave] = (uint32_t)__popcll(bal[k]);
                 }
-                const int rank = base + woff + below;
-                if (i < V && (key[k] < kt || (eq && rank >= need))) l[k] = -INFINITY;
-                base += total;
                 __syncthreads();
+                int base = 0;
+#pragma unroll
+                for (int k = 0; k < kElems; ++k) {
+                    const int i = k * kThreads + tid;
+                    const bool eq = (i < V) && key[k] == kt;
+                    const int below = __popcll(bal[k] & ((1ull << lane) - 1ull));
+                    int woff = 0, total = 0;
+                    for (int w = 0; w < kThreads / 64; ++w) {
+                        if (w < wave) woff += (int)wcount[k][w];
+                        total += (int)wcount[k][w];
+                    }
+                    const int rank = base + woff + below;
+                    if (i < V && (key[k] < kt || (eq && rank >= need))) l[k] = -INFINITY;
+                    base += total;
+                }
             }
 #pragma unroll
             for (int k = 0; k < kElems; ++k) vals[k * kThreads + tid] = l[k];
