@@ -156,6 +156,8 @@ __device__ Best block_argmax(Best x, Best* scratch) {
 __global__ __launch_bounds__(kThreads) void sampler_kernel(SamplerArgs a) {
     __shared__ float vals[kMaxV];
     __shared__ uint32_t sortbuf[kMaxV];
+    __shared__ float sval[kMaxV];   // surviving logits, compacted (indices in sortbuf)
+    __shared__ int n_surv;
     __shared__ uint32_t hist[2][256];
     __shared__ Best scratch[kThreads / 64];
     __shared__ uint32_t wcount[kElems][kThreads / 64];
@@ -184,6 +186,7 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(SamplerArgs a) {
         hist[0][tid] = 0;
         hist[1][tid] = 0;
     }
+    if (tid == 0) n_surv = 0;
     if (row_done) {
         if (tid == 0 && a.advance && gate && !a.advance_gate) a.kv_len[b] += 1;  // predictor rows keep in step
         return;
@@ -352,18 +355,27 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(SamplerArgs a) {
         // ---- 8: categorical(logits * (1/T)) ----
         const float invt = rbf(1.0f / sp.temperature);
         const uint32_t draw = (uint32_t)frame * 16u + (uint32_t)a.cb;
-        Best x{-INFINITY, 0x7fffffff};
-        bool any = false;
+        // The survivors (top_k of them, scattered over the 16 waves) are compacted first: Philox + two logarithms per element
+        // is ~250 instructions, and a wave executes them once per slice in which ANY of its lanes holds a survivor --
+        // nearly every (wave, slice) pair for 50 survivors. Compacted, one wave does it once. The noise is keyed by the
+        // element index, and the arg-max breaks ties by lower index, so the order of evaluation does not matter.
 #pragma unroll
         for (int k = 0; k < kElems; ++k) {
             const int i = k * kThreads + tid;
             if (i < V && l[k] != -INFINITY) {
-                const float v = rbf(l[k] * invt) + gumbel_noise(sp.seed, sp.row0 + (uint32_t)b, draw, (uint32_t)i);
-                if (!any || v > x.v) x = Best{v, i};  // ascending i within a thread: first maximum kept
-                any = true;
+                const int slot = atomicAdd(&n_surv, 1);
+                sortbuf[slot] = (uint32_t)i;
+                sval[slot] = l[k];
             }
         }
-        if (!any) x = Best{-INFINITY, 0x7fffffff};
+        __syncthreads();
+        const int ns = n_surv;
+        Best x{-INFINITY, 0x7fffffff};
+        for (int q = tid; q < ns; q += kThreads) {
+            const int i = (int)sortbuf[q];
+            const float v = rbf(sval[q] * invt) + gumbel_noise(sp.seed, sp.row0 + (uint32_t)b, draw, (uint32_t)i);
+            x = better(x, Best{v, i});
+        }
         Best r = block_argmax(x, scratch);
         tok = (r.i == 0x7fffffff) ? 0 : r.i;
     }
