@@ -42,7 +42,9 @@ Engine::Engine(Model* model, const q3tts_load_opts& opts) : m_(model), opts_(opt
     for (auto& e : ev_fe_) Q3_HIP(hipEventCreate(&e));
     Q3_HIP(hipEventCreateWithFlags(&fe_uploaded_, hipEventDisableTiming));
     Bm_ = opts.max_batch;
-    Mp_ = 64;  // activation rows: up to 64 (batch rows x positions per launch), whatever the batch
+    // activation rows per launch (batch rows x positions), whatever the batch: 128 lets 64 rows run the code predictor's
+    // two-position step 0 as one pass and doubles the prefill chunk; the GEMMs take them as row blocks of <= 64 (grid.y)
+    Mp_ = std::getenv("Q3TTS_ROWS_64") ? 64 : 128;
     Pcap_ = opts.max_prompt;
     Tcap_ = opts.max_prompt;
     Fcap_ = opts.max_frames;
@@ -994,7 +996,7 @@ void Engine::generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp
     pl.prompt = prompt_; pl.n_prompt = n_prompt_; pl.Pmax = Pcap_; pl.H = H; pl.B = n; pl.h = tk_.h; pl.hMB = Mp_ / 16;
     pl.ss_out = tk_.ss_a; pl.active = active_;
     // prompt_ rows are laid out with stride Pcap_; right alignment is relative to the longest prompt.
-    // Positions 0 .. Pmax-2 go through the decode kernels C at a time (C * n <= 64 activation rows: the GEMMs stream
+    // Positions 0 .. Pmax-2 go through the decode kernels C at a time (C * n <= Mp_ activation rows: the GEMMs stream
     // the weights once per chunk instead of once per position); rows whose prompt is shorter start inside a chunk.
     {
         const int P1 = Pmax - 1;  // positions before the one the first frame step consumes

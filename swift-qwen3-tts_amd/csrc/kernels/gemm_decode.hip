@@ -433,12 +433,14 @@ void launch_q(const GemmArgs& a, hipStream_t st) {
         if (MBt % 4 == 0 && tiles * 4 <= 256) split = 4;
         else if (MBt % 2 == 0 && tiles * 2 <= 256) split = 2;
     }
+    // more than 64 rows (prefill chunks, the predictor's two-position step at batch 64): row blocks of at most 4 per workgroup
+    while (MBt / split > 4 || MBt % split != 0) ++split;
     switch (MBt / split) {
         case 1: launch_mb<1, EPI, NORM, QUANT>(a, split, st); break;
         case 2: launch_mb<2, EPI, NORM, QUANT>(a, split, st); break;
         case 3: launch_mb<3, EPI, NORM, QUANT>(a, split, st); break;
         case 4: launch_mb<4, EPI, NORM, QUANT>(a, split, st); break;
-        default: throw Error(3, "gemm_skinny: M > 64 is not supported");
+        default: throw Error(3, "gemm_skinny: more than 4 row blocks per workgroup");
     }
 }
 
@@ -452,7 +454,7 @@ void launch_epi(const GemmArgs& a, hipStream_t st) {
 
 void launch_gemm_skinny(const GemmArgs& a, hipStream_t st) {
     Q3_CHECK(a.K % 128 == 0 && a.N % 16 == 0, 3, "gemm_skinny: K must be a multiple of 128 and N of 16");
-    Q3_CHECK(a.Mpad % 16 == 0 && a.M <= a.Mpad && a.Mpad <= 64, 3, "gemm_skinny: bad M padding");
+    Q3_CHECK(a.Mpad % 16 == 0 && a.M <= a.Mpad && a.Mpad <= 128, 3, "gemm_skinny: bad M padding");
     Q3_CHECK(a.xMB * 16 >= a.Mpad, 3, "gemm_skinny: x allocation has fewer row blocks than the batch");
     const bool norm = a.norm_w != nullptr;
     if (norm) Q3_CHECK(a.ss_in && a.ss_count >= 1 && a.ss_ld >= a.Mpad, 3, "gemm_skinny: norm prologue needs sums of squares");
