@@ -42,9 +42,10 @@ Engine::Engine(Model* model, const q3tts_load_opts& opts) : m_(model), opts_(opt
     for (auto& e : ev_fe_) Q3_HIP(hipEventCreate(&e));
     Q3_HIP(hipEventCreateWithFlags(&fe_uploaded_, hipEventDisableTiming));
     Bm_ = opts.max_batch;
-    // activation rows per launch (batch rows x positions), whatever the batch: 128 lets 64 rows run the code predictor's
-    // two-position step 0 as one pass and doubles the prefill chunk; the GEMMs take them as row blocks of <= 64 (grid.y)
-    Mp_ = std::getenv("Q3TTS_ROWS_64") ? 64 : 128;
+    // activation rows per launch (batch rows x positions), whatever the batch: 64 rows can run the code predictor's
+    // two-position step 0 as one pass, and a prefill chunk is 8 positions up to batch 32; the GEMMs take them as row
+    // blocks of <= 64 (grid.y)
+    Mp_ = std::getenv("Q3TTS_ROWS_64") ? 64 : 256;
     Pcap_ = opts.max_prompt;
     Tcap_ = opts.max_prompt;
     Fcap_ = opts.max_frames;
