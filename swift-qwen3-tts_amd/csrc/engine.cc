@@ -126,7 +126,7 @@ Engine::~Engine() {
 
 // CodePredictor.swift:327-330 projects the embedding of every sampled code (H wide) down to the predictor's width before
 // each of passes 1..14. The projection of a table row does not depend on anything else, so it is taken once per row at
-// load -- by the very GEMM launch the frame step would have made, 64 codes at a time, so the rows (and their per-tile sums
+// load -- by the very GEMM kernel the frame step would have launched, Mp_ codes at a time, so the rows (and their per-tile sums
 // of squares for the next norm prologue) are bit-identical to projecting at run time -- and the frame step loses 14 launches.
 void Engine::build_cp_proj_tables() {
     const TalkerConfig& t = m_->cfg.talker;
