@@ -433,7 +433,12 @@ void launch_q(const GemmArgs& a, hipStream_t st) {
         if (MBt % 4 == 0 && tiles * 4 <= 256) split = 4;
         else if (MBt % 2 == 0 && tiles * 2 <= 256) split = 2;
     }
-    // more than 64 rows (prefill chunks, the predictor's two-position step at batch 64): row blocks of at most 4 per workgroup
+    // More than 64 rows (prefill chunks, the predictor's two-position step): at most 4 row blocks per workgroup -- 2 with
+    // the norm prologue, whose VALU work on the x fragments (critical path, per workgroup) grows with the row blocks.
+    if (!no_split) {
+        const int cap = NORM ? 2 : 4;
+        while (MBt / split > cap || MBt % split != 0) ++split;
+    }
     while (MBt / split > 4 || MBt % split != 0) ++split;
     switch (MBt / split) {
         case 1: launch_mb<1, EPI, NORM, QUANT>(a, split, st); break;
