@@ -548,8 +548,7 @@ __global__ __launch_bounds__(NW * 64) void stack_persist_kernel(StackPersistArgs
         // ---- P2: attention ----
         for (int u = blockIdx.x; u < a.n_kv * a.M; u += G) {
             const int kvh = u % a.n_kv, b = u / a.n_kv;
-            if (a.max_pages == 1) attn_unit<kRepPersist, 64>(a, L, kvh, b, sm);
-            else attn_unit<kRepPersist, 256>(a, L, kvh, b, sm);
+            attn_unit<kRepPersist, 256>(a, L, kvh, b, sm);  // same lane-group count as attn_decode.hip for every cache length
         }
         GemmDesc o = base_desc();
         o.W = L.o; o.x = xao; o.N = a.H; o.K = a.QD; o.y = xh; o.resid = 1; o.ss_out = sb;
