@@ -266,11 +266,11 @@ void Engine::enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, 
     const int H = s.hidden, MBL = Mp_ / 16, tiles = H / 16;
     const int M = B * (chunk > 1 ? chunk : 1);  // GEMM rows: chunk element p of batch row b is row p * B + b
     Q3_CHECK(M <= Mp_, 7, "internal error: chunk does not fit the activation buffers");
-    // The RMSNorm prologue re-normalises all of x in every workgroup: VALU work that grows with K and with the number
-    // of workgroups. Measured against a separate row-norm launch (4.8 us): +1 us at K = 1024; at K = 2048 +2.7 us in the
-    // qkv GEMM (256 workgroups) but +6.5 us in the gate/up GEMM (384 workgroups, two rounds on 256 CUs). So a 2048-wide
-    // stack norms in the qkv prologue and keeps a row-norm kernel in front of gate/up.
-    const bool prologue_qkv = H <= 2048, prologue_mlp = H <= 1024;
+    // The RMSNorm prologue re-normalises all of x in every workgroup: VALU work on the critical path that grows with K and
+    // with the row blocks per workgroup (0.8-1.3 us). Against a separate row-norm launch (4.5 us) it wins at both widths
+    // since the norm-prologue kernels request x before the weight tiles, take at most two row blocks per workgroup and
+    // the 6144-wide gate/up runs as one round of workgroups (gemm_decode.hip); wider stacks keep the row-norm kernel.
+    const bool prologue_qkv = H <= 2048, prologue_mlp = H <= 2048;
     auto norm_into_xn = [&](const uint16_t* nw) {
         NormRowsArgs n{};
         n.h = w.h; n.hMB = MBL; n.w = nw; n.eps = s.eps; n.out = w.xn; n.outMB = MBL; n.M = M; n.H = H;

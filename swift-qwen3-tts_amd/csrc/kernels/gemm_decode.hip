@@ -397,11 +397,11 @@ void launch_mb(const GemmArgs& a, int split, hipStream_t st) {
     const int tiles = a.N / 16;
 #define Q3_GEMM(NWv, CHv) \
     hipLaunchKernelGGL((gemm_skinny_kernel<MB, EPI, NWv, CHv, NORM, QUANT>), dim3(tiles, split), dim3(NWv * 64), 0, st, a)
-    if constexpr (EPI == 2 && !NORM && !QUANT && MB <= 2) {
+    if constexpr (EPI == 2 && !QUANT && MB <= 2) {
         // more than one round of workgroups on 256 CUs, and an even pair count: two pairs per workgroup, one round
         static const bool one_pair = std::getenv("Q3TTS_GEMM_ONE_PAIR") != nullptr;
         if (!one_pair && nw == 8 && ch == 2 && tiles > 256 && tiles <= 512 && tiles % 2 == 0) {
-            hipLaunchKernelGGL((gemm_skinny_kernel<MB, 2, 8, 2, false, false, 2>), dim3(tiles / 2, split), dim3(512), 0, st, a);
+            hipLaunchKernelGGL((gemm_skinny_kernel<MB, 2, 8, 2, NORM, false, 2>), dim3(tiles / 2, split), dim3(512), 0, st, a);
             return;
         }
     }
