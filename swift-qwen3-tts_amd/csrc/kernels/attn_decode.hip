@@ -392,22 +392,37 @@ void launch_attn_decode(const AttnArgs& a, hipStream_t st) {
     const int rep = a.n_heads / a.n_kv;
     Q3_CHECK(rep * a.n_kv == a.n_heads && rep >= 1 && rep <= kMaxRep, 3, "attn_decode: unsupported GQA ratio");
     dim3 grid(a.n_kv, a.B);
-    // 256 threads for short caches too (the code predictor never holds more than 17 tokens): the four vectors of phase 1
-    // go to four waves and every cached position to its own lane group. One wave per workgroup -- free barriers, nothing
-    // waits on other waves -- looked right on paper and measured 4 % slower on the whole frame step.
+    // Short caches (the code predictor never holds more than 17 tokens; max_pages == 1): 256 threads -- phase 1's four
+    // vectors on four waves, every cached position on its own lane group. One wave per workgroup (free barriers, nothing
+    // waits on other waves) looked right on paper and measured 4 % slower on the whole frame step. Long caches: 512
+    // threads, 32 lane groups walk the positions (1.3 % on the frame step over 256; LDS allows it up to two query heads per
+    // kv head). The chunk kernel and the persistent kernel use the same counts, so all of them round identically.
+    const bool wide = a.max_pages > 1 && rep <= 2;
     if (a.chunk > 1) {
         Q3_CHECK(a.chunk <= 8, 3, "attn_decode: at most 8 positions per launch");
         switch (rep) {
-            case 1: hipLaunchKernelGGL((attn_chunk_kernel<1, 256, 8>), grid, dim3(256), 0, st, a); break;
-            case 2: hipLaunchKernelGGL((attn_chunk_kernel<2, 256, 8>), grid, dim3(256), 0, st, a); break;
+            case 1:
+                if (wide) hipLaunchKernelGGL((attn_chunk_kernel<1, 512, 8>), grid, dim3(512), 0, st, a);
+                else hipLaunchKernelGGL((attn_chunk_kernel<1, 256, 8>), grid, dim3(256), 0, st, a);
+                break;
+            case 2:
+                if (wide) hipLaunchKernelGGL((attn_chunk_kernel<2, 512, 8>), grid, dim3(512), 0, st, a);
+                else hipLaunchKernelGGL((attn_chunk_kernel<2, 256, 8>), grid, dim3(256), 0, st, a);
+                break;
             case 3: hipLaunchKernelGGL((attn_chunk_kernel<3, 256, 8>), grid, dim3(256), 0, st, a); break;
             case 4: hipLaunchKernelGGL((attn_chunk_kernel<4, 256, 8>), grid, dim3(256), 0, st, a); break;
         }
         return;
     }
     switch (rep) {
-        case 1: hipLaunchKernelGGL((attn_decode_kernel<1, 256>), grid, dim3(256), 0, st, a); break;
-        case 2: hipLaunchKernelGGL((attn_decode_kernel<2, 256>), grid, dim3(256), 0, st, a); break;
+        case 1:
+            if (wide) hipLaunchKernelGGL((attn_decode_kernel<1, 512>), grid, dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((attn_decode_kernel<1, 256>), grid, dim3(256), 0, st, a);
+            break;
+        case 2:
+            if (wide) hipLaunchKernelGGL((attn_decode_kernel<2, 512>), grid, dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((attn_decode_kernel<2, 256>), grid, dim3(256), 0, st, a);
+            break;
         case 3: hipLaunchKernelGGL((attn_decode_kernel<3, 256>), grid, dim3(256), 0, st, a); break;
         case 4: hipLaunchKernelGGL((attn_decode_kernel<4, 256>), grid, dim3(256), 0, st, a); break;
     }

@@ -125,9 +125,9 @@ struct Smem {  // one workgroup's LDS, reused by every phase
             __attribute__((aligned(16))) float q_s[kMaxRepPersist][D];
             float k_s[D];
             float v_s[D];
-            float m_s[16][kMaxRepPersist];
-            float l_s[16][kMaxRepPersist];
-            float acc_s[16][kMaxRepPersist][D];
+            float m_s[32][kMaxRepPersist];
+            float l_s[32][kMaxRepPersist];
+            float acc_s[32][kMaxRepPersist][D];
         } a;
     };
     int ok;
@@ -548,7 +548,9 @@ __global__ __launch_bounds__(NW * 64) void stack_persist_kernel(StackPersistArgs
         // ---- P2: attention ----
         for (int u = blockIdx.x; u < a.n_kv * a.M; u += G) {
             const int kvh = u % a.n_kv, b = u / a.n_kv;
-            attn_unit<kRepPersist, 256>(a, L, kvh, b, sm);  // same lane-group count as attn_decode.hip for every cache length
+            // the lane-group counts of attn_decode.hip: 16 for the code predictor's one-page cache, 32 for long caches
+            if (a.max_pages == 1) attn_unit<kRepPersist, 256>(a, L, kvh, b, sm);
+            else attn_unit<kRepPersist, 512>(a, L, kvh, b, sm);
         }
         GemmDesc o = base_desc();
         o.W = L.o; o.x = xao; o.N = a.H; o.K = a.QD; o.y = xh; o.resid = 1; o.ss_out = sb;
