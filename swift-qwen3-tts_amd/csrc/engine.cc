@@ -79,6 +79,16 @@ Engine::Engine(Model* model, const q3tts_load_opts& opts) : m_(model), opts_(opt
         if (const char* g = std::getenv("Q3TTS_PERSIST_GRID")) persist_grid_ = std::max(8, std::min(std::atoi(g), prop.multiProcessorCount));
     }
     alloc_workspace();
+    // Off by default: measured 2 % SLOWER on the frame step than the two launches; kept as the
+    // starting point for finer-grained producer/consumer launches
+    if (!persistent_ && std::getenv("Q3TTS_FUSED_ATTN")) {
+        const TalkerConfig& tc = m_->cfg.talker;
+        fuse_nodes_cap_ = tc.cp.num_hidden_layers * tc.num_code_groups;
+        Q3_HIP(hipMalloc(reinterpret_cast<void**>(&fuse_flags_), size_t(fuse_nodes_cap_) * 512 * 4));
+        Q3_HIP(hipMalloc(reinterpret_cast<void**>(&fuse_err_), 4));
+        Q3_HIP(hipMemset(fuse_err_, 0, 4));
+        fuse_ = true;
+    }
     if (persistent_) {
         auto table = [&](const StackW& s, uint16_t* kp, uint16_t* vp, size_t stride, PersistLayer** out) {
             std::vector<PersistLayer> v(s.layers.size());
@@ -108,6 +118,8 @@ Engine::~Engine() {
     }
     for (void* p : {(void*)ref_audio_dev_, (void*)ref_codes_dev_, (void*)extra_, (void*)spk_f32_, (void*)dec_codes_})
         if (p) (void)hipFree(p);
+    if (fuse_flags_) (void)hipFree(fuse_flags_);
+    if (fuse_err_) (void)hipFree(fuse_err_);
     if (ws_) (void)hipFree(ws_);
     if (uc_ws_) (void)hipFree(uc_ws_);
     if (tk_layers_dev_) (void)hipFree(tk_layers_dev_);
@@ -284,7 +296,6 @@ void Engine::enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, 
         if (prologue_qkv) {
             q.norm_w = L.ln1; q.ss_in = w.ss_a; q.ss_count = (l == 0) ? ss_count_in : tiles; q.norm_dim = H; q.norm_eps = s.eps;
         }
-        launch_gemm_skinny(q, st_);
         AttnArgs at{};
         at.qkv = w.qkv; at.ld = w.ld_qkv; at.qn_w = L.qn; at.kn_w = L.kn; at.eps = s.eps;
         at.rope_cos = s.rope_cos; at.rope_sin = s.rope_sin;
@@ -294,7 +305,13 @@ void Engine::enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, 
         at.fixed_len = fixed_len; at.identity_pages = fixed_len >= 0 ? 1 : 0;
         at.chunk = chunk; at.chunk_n_prompt = chunk_n_prompt; at.chunk_r_base = chunk_r_base;
         at.scale = powf(float(kHeadDim), -0.5f);  // Talker.swift:179
-        launch_attn_decode(at, st_);
+        if (fuse_ && fuse_node_ >= 0 && fuse_node_ < fuse_nodes_cap_ && q.N / 16 <= 512 && qkv_attn_fused_supported(q, at)) {
+            launch_qkv_attn_fused(q, at, fuse_flags_ + size_t(fuse_node_) * 512, fuse_err_, st_);
+            ++fuse_node_;
+        } else {
+            launch_gemm_skinny(q, st_);
+            launch_attn_decode(at, st_);
+        }
         GemmArgs o = gemm_args(L.o, w.ao, M);
         o.epi = 3; o.y = w.h; o.yMB = MBL; o.resid = 1; o.ss_out = w.ss_b;
         launch_gemm_skinny(o, st_);
@@ -338,6 +355,14 @@ void Engine::enqueue_stack_persist(const StackW& s, const PersistLayer* layers_d
 }
 
 void Engine::check_persist_error() {
+    if (fuse_) {
+        int ferr = 0;
+        Q3_HIP(hipMemcpy(&ferr, fuse_err_, 4, hipMemcpyDeviceToHost));
+        if (ferr) {
+            Q3_HIP(hipMemset(fuse_err_, 0, 4));
+            throw Error(7, "fused qkv + attention: " + std::to_string(ferr) + " attention units timed out waiting for their projection tiles");
+        }
+    }
     if (!persistent_) return;
     int err = 0;
     Q3_HIP(hipMemcpy(&err, sync_err_, 4, hipMemcpyDeviceToHost));
@@ -401,6 +426,12 @@ void Engine::enqueue_cp_pass(int B, bool from_talker, int head, int cp_pos, bool
 }
 
 void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
+    struct FuseScope {  // fused launches are numbered within a frame; outside enqueue_frame nothing fuses
+        int& n;
+        explicit FuseScope(int& r) : n(r) { n = 0; }
+        ~FuseScope() { n = -1; }
+    } fuse_scope(fuse_node_);
+    if (fuse_) Q3_HIP(hipMemsetAsync(fuse_flags_, 0, size_t(fuse_nodes_cap_) * 512 * 4, st_));
     const TalkerConfig& t = m_->cfg.talker;
     const int H = t.hidden_size, V = t.vocab_size, Vc = t.cp.vocab_size, CH = t.cp.hidden_size;
     const int groups = t.num_code_groups, MBL = Mp_ / 16;

@@ -102,6 +102,12 @@ class Engine {
     uint16_t* cp_x2_ = nullptr;
     // small_to_mtp_projection applied to every row of the code predictor's embedding tables at load (by the decode GEMM
     // itself, so rows are bit-identical to projecting at run time); kept in the Model, see Model::cp_pe
+    // fused qkv + attention launches of the code predictor (fused_qkv_attn.hip): one flag array per launch of a frame,
+    // zeroed by a memset at the head of the frame; fuse_node_ counts the launches while a frame is being enqueued
+    unsigned* fuse_flags_ = nullptr;
+    int* fuse_err_ = nullptr;
+    int fuse_nodes_cap_ = 0, fuse_node_ = -1;  // -1: not inside enqueue_frame (prefill, tables): no fusing
+    bool fuse_ = false;
     bool cp_tables_ = false;  // the samplers hand projected rows (Model::cp_pe) straight to the next pass
     void build_cp_proj_tables();  // staged embedding of code 0 (second position of predictor step 0)
     float* cp_ss2_ = nullptr;

@@ -133,6 +133,11 @@ struct AttnArgs {
 };
 void launch_attn_decode(const AttnArgs& a, hipStream_t st);
 
+// qkv projection (norm prologue) + one-position attention of a short-cache stack in one launch (fused_qkv_attn.hip).
+// flags: one word per 16-column tile of the projection, zero before the launch; err[0] counts consumer timeouts.
+bool qkv_attn_fused_supported(const GemmArgs& g, const AttnArgs& at);
+void launch_qkv_attn_fused(const GemmArgs& g, const AttnArgs& at, unsigned* flags, int* err, hipStream_t st);
+
 // ---- sampler (sampler.hip) ---------------------------------------------------------------------
 struct SamplingParams {  // lives in device memory so the captured graph does not depend on it
     float temperature;

@@ -19,222 +19,11 @@
 namespace q3 {
 namespace {
 
-constexpr int D = kHeadDim;
-constexpr int kMaxRep = 4;
-
-// RMSNorm over 128 dims + RoPE for one head vector held as 2 elements per lane (i = lane, lane+64).
-// Rounding points follow the oracle: n = bf16(x*rstd); y = bf16(n*w); rope = bf16(bf16(y*cos) + bf16(rot*sin)).
-__device__ __forceinline__ void norm_rope(float x0, float x1, const uint16_t* w, float eps, const uint16_t* cosr,
-                                          const uint16_t* sinr, int lane, float& o0, float& o1) {
-    float ss = wave_sum(x0 * x0 + x1 * x1);
-    float rstd = 1.0f / sqrtf(ss / (float)D + eps);
-    float y0 = rbf(rbf(x0 * rstd) * bf2f(w[lane]));
-    float y1 = rbf(rbf(x1 * rstd) * bf2f(w[lane + 64]));
-    // rotate_half: first half pairs with -x2, second half with x1 (Talker.swift:125-130)
-    o0 = rbf(rbf(y0 * bf2f(cosr[lane])) + rbf(-y1 * bf2f(sinr[lane])));
-    o1 = rbf(rbf(y1 * bf2f(cosr[lane + 64])) + rbf(y0 * bf2f(sinr[lane + 64])));
-}
+#include "attn_body.inc"
 
 template <int REP, int NTH>
 __global__ __launch_bounds__(NTH) void attn_decode_kernel(AttnArgs a) {
-    constexpr int NG = NTH / 16;  // 16-lane groups striding over cache positions
-    constexpr int NWV = NTH / 64;
-    __shared__ __attribute__((aligned(16))) float q_s[REP][D];
-    __shared__ float k_s[D];
-    __shared__ float v_s[D];
-    __shared__ float m_s[NG][REP];
-    __shared__ float l_s[NG][REP];
-    __shared__ float acc_s[NG][REP][D];
-
-    const int kvh = blockIdx.x, b = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int len = a.fixed_len >= 0 ? a.fixed_len : a.kv_len[b];  // position of the new token
-    const bool append = a.active ? (a.active[b] != 0) : true;
-    const uint16_t* row = a.qkv + (size_t)b * a.ld;
-    const uint16_t* cosr = a.rope_cos + (size_t)len * D;
-    const uint16_t* sinr = a.rope_sin + (size_t)len * D;
-    const int qdim = a.n_heads * D, kdim = a.n_kv * D;
-
-    // new-token page slot
-    const int32_t* bt = a.block_table + (size_t)b * a.max_pages;
-    const int npage = a.identity_pages ? b : bt[len / kPageTokens];
-    const size_t nslot = (((size_t)npage * a.n_kv + kvh) * kPageTokens + (len % kPageTokens)) * D;
-
-    // ---- phase 1: q/k norm + rope, v copy; vectors round-robin over the waves. Every vector a wave owns, the norm
-    // weights and the RoPE row are loaded before the first store: the compiler cannot move a load above the cache
-    // append (it may alias), and a single-wave workgroup would otherwise pay one L2 round trip per vector ----
-    constexpr int VPW = (REP + 2 + NWV - 1) / NWV;  // vectors per wave
-    uint16_t raw0[VPW], raw1[VPW];
-#pragma unroll
-    for (int u = 0; u < VPW; ++u) {
-        const int j = wave + u * NWV;
-        raw0[u] = 0;
-        raw1[u] = 0;
-        if (j < REP + 2) {
-            const uint16_t* vp = row + (j < REP ? (size_t)(kvh * REP + j) * D : (j == REP ? qdim + (size_t)kvh * D : qdim + kdim + (size_t)kvh * D));
-            raw0[u] = vp[lane];
-            raw1[u] = vp[lane + 64];
-        }
-    }
-    const uint16_t qw0 = a.qn_w[lane], qw1 = a.qn_w[lane + 64], kw0 = a.kn_w[lane], kw1 = a.kn_w[lane + 64];
-    const uint16_t c0 = cosr[lane], c1 = cosr[lane + 64], s0 = sinr[lane], s1 = sinr[lane + 64];
-    // The first cache rows of every lane group are requested before the q/k ARITHMETIC (they depend on nothing computed
-    // here, and a code-predictor cache of <= 16 past tokens is then covered by one memory round trip) but after the q/k/v
-    // loads above: loads return in issue order, so phase 1 starts on its own operands while the cache rows still arrive.
-    constexpr int PF = NTH >= 256 ? 8 : 4;
-    const int g = tid >> 4, c = tid & 15;  // lane group g (16 lanes) strides over positions; lane c owns dims 8c..8c+7
-    uint4 kpre[PF], vpre[PF];
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-        const int t = g + u * NG;
-        kpre[u] = make_uint4(0, 0, 0, 0);
-        vpre[u] = make_uint4(0, 0, 0, 0);
-        if (t < len) {
-            const int page = a.identity_pages ? b : bt[t / kPageTokens];
-            const size_t off = (((size_t)page * a.n_kv + kvh) * kPageTokens + (t % kPageTokens)) * D + 8 * c;
-            kpre[u] = *reinterpret_cast<const uint4*>(a.kpool + off);
-            vpre[u] = *reinterpret_cast<const uint4*>(a.vpool + off);
-        }
-    }
-
-    auto norm_rope_r = [&](float x0, float x1, uint16_t w0, uint16_t w1, float& o0, float& o1) {
-        const float ss = wave_sum(x0 * x0 + x1 * x1);
-        const float rstd = 1.0f / sqrtf(ss / (float)D + a.eps);
-        const float y0 = rbf(rbf(x0 * rstd) * bf2f(w0));
-        const float y1 = rbf(rbf(x1 * rstd) * bf2f(w1));
-        o0 = rbf(rbf(y0 * bf2f(c0)) + rbf(-y1 * bf2f(s0)));
-        o1 = rbf(rbf(y1 * bf2f(c1)) + rbf(y0 * bf2f(s1)));
-    };
-#pragma unroll
-    for (int u = 0; u < VPW; ++u) {
-        const int j = wave + u * NWV;
-        if (j >= REP + 2) continue;
-        if (j < REP) {
-            float o0, o1;
-            norm_rope_r(bf2f(raw0[u]), bf2f(raw1[u]), qw0, qw1, o0, o1);
-            q_s[j][lane] = o0;
-            q_s[j][lane + 64] = o1;
-        } else if (j == REP) {
-            float o0, o1;
-            norm_rope_r(bf2f(raw0[u]), bf2f(raw1[u]), kw0, kw1, o0, o1);
-            k_s[lane] = o0;
-            k_s[lane + 64] = o1;
-            if (append) {
-                a.kpool[nslot + lane] = f2bf(o0);
-                a.kpool[nslot + lane + 64] = f2bf(o1);
-            }
-        } else {
-            v_s[lane] = bf2f(raw0[u]);
-            v_s[lane + 64] = bf2f(raw1[u]);
-            if (append) {
-                a.vpool[nslot + lane] = raw0[u];
-                a.vpool[nslot + lane + 64] = raw1[u];
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- phase 2: online-softmax attention; lane group g (16 lanes) strides over positions ----
-    float q[REP][8];
-#pragma unroll
-    for (int h = 0; h < REP; ++h)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) q[h][j] = q_s[h][8 * c + j];
-    float m[REP], l[REP], acc[REP][8];
-#pragma unroll
-    for (int h = 0; h < REP; ++h) {
-        m[h] = -INFINITY;
-        l[h] = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[h][j] = 0.f;
-    }
-
-    auto step = [&](const float (&kf)[8], const float (&vf)[8]) {
-#pragma unroll
-        for (int h = 0; h < REP; ++h) {
-            float d = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) d += q[h][j] * kf[j];
-            d = row16_sum(d);
-            const float sc = d * a.scale;
-            const float mn = fmaxf(m[h], sc);
-            const float alpha = __expf(m[h] - mn);  // exp(-inf) = 0 on the first position
-            const float p = __expf(sc - mn);
-            l[h] = l[h] * alpha + p;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[h][j] = acc[h][j] * alpha + p * vf[j];
-            m[h] = mn;
-        }
-    };
-
-    auto step_raw = [&](const uint4& kr, const uint4& vr) {
-        float kf[8] = {lo_bf(kr.x), hi_bf(kr.x), lo_bf(kr.y), hi_bf(kr.y), lo_bf(kr.z), hi_bf(kr.z), lo_bf(kr.w), hi_bf(kr.w)};
-        float vf[8] = {lo_bf(vr.x), hi_bf(vr.x), lo_bf(vr.y), hi_bf(vr.y), lo_bf(vr.z), hi_bf(vr.z), lo_bf(vr.w), hi_bf(vr.w)};
-        step(kf, vf);
-    };
-#pragma unroll
-    for (int u = 0; u < PF; ++u)
-        if (g + u * NG < len) step_raw(kpre[u], vpre[u]);
-    for (int t0 = g + PF * NG; t0 < len; t0 += PF * NG) {  // later rows, PF at a time (loads first, then the updates)
-        uint4 kr[PF], vr[PF];
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int t = t0 + u * NG;
-            kr[u] = make_uint4(0, 0, 0, 0);
-            vr[u] = make_uint4(0, 0, 0, 0);
-            if (t < len) {
-                const int page = a.identity_pages ? b : bt[t / kPageTokens];
-                const size_t off = (((size_t)page * a.n_kv + kvh) * kPageTokens + (t % kPageTokens)) * D + 8 * c;
-                kr[u] = *reinterpret_cast<const uint4*>(a.kpool + off);
-                vr[u] = *reinterpret_cast<const uint4*>(a.vpool + off);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < PF; ++u)
-            if (t0 + u * NG < len) step_raw(kr[u], vr[u]);
-    }
-    if (g == (len % NG)) {  // the new token (kept in LDS: it may not be in the cache when !append)
-        float kf[8], vf[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            kf[j] = k_s[8 * c + j];
-            vf[j] = v_s[8 * c + j];
-        }
-        step(kf, vf);
-    }
-
-#pragma unroll
-    for (int h = 0; h < REP; ++h) {
-        if (c == 0) {
-            m_s[g][h] = m[h];
-            l_s[g][h] = l[h];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc_s[g][h][8 * c + j] = acc[h][j];
-    }
-    __syncthreads();
-
-    // ---- merge the 16 groups: thread -> (head, dim); results staged in LDS for 16-byte stores ----
-    uint16_t* out_s = reinterpret_cast<uint16_t*>(&q_s[0][0]);  // q_s is dead: every wave passed the barrier above
-    for (int o = tid; o < REP * D; o += NTH) {
-        const int h = o / D, d = o % D;
-        float M = -INFINITY;
-#pragma unroll
-        for (int gg = 0; gg < NG; ++gg) M = fmaxf(M, m_s[gg][h]);
-        float num = 0.f, den = 0.f;
-#pragma unroll
-        for (int gg = 0; gg < NG; ++gg) {
-            const float w = (m_s[gg][h] == -INFINITY) ? 0.f : __expf(m_s[gg][h] - M);
-            num += acc_s[gg][h][d] * w;
-            den += l_s[gg][h] * w;
-        }
-        out_s[o] = f2bf(num / den);
-    }
-    __syncthreads();
-    for (int p = tid; p < REP * D / 8; p += NTH) {  // fragment-major store (x operand of o_proj)
-        const int col = (kvh * REP) * D + 8 * p;
-        *reinterpret_cast<uint4*>(a.out + act_tiled_offset(b, col, a.outMB)) = *reinterpret_cast<const uint4*>(out_s + 8 * p);
-    }
+    attn_decode_body<REP, NTH, false>(a, blockIdx.x, blockIdx.y, nullptr, nullptr);
 }
 
 // Several consecutive positions of every row in one launch (chunked prompt prefill; the code predictor's step 0,

@@ -35,358 +35,11 @@ namespace q3 {
 
 namespace {
 
-__device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, f32x4 c) {
-    bf16x8 av, bv;
-    __builtin_memcpy(&av, &a, 16);
-    __builtin_memcpy(&bv, &b, 16);
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, c, 0, 0, 0);
-}
+#include "gemm_body.inc"
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
-
-// bf16( bf16(h * rstd) * w ) on 8 packed elements
-__device__ __forceinline__ uint4 norm8(const uint4& hx, const uint4& wx, float rstd) {
-    const uint32_t hw[4] = {hx.x, hx.y, hx.z, hx.w}, ww[4] = {wx.x, wx.y, wx.z, wx.w};
-    uint32_t o[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float n0 = rbf(lo_bf(hw[j]) * rstd), n1 = rbf(hi_bf(hw[j]) * rstd);
-        o[j] = pack_bf(n0 * lo_bf(ww[j]), n1 * hi_bf(ww[j]));
-    }
-    return make_uint4(o[0], o[1], o[2], o[3]);
-}
-
-// MLX affine int4, group 64 (QuantizedLinear installed by quantize(model:...) at Qwen3.swift:1412-1425):
-// w = bf16(q * scale + bias). One dwordx4 per lane holds the 32 nibbles of its four A fragments of a chunk
-// (8 consecutive k per uint32, little-endian nibbles), so an int4 weight tile is 1 KiB instead of 4 KiB.
-__device__ __forceinline__ void dequant_chunk(const uint4& qw, uint32_t sb, uint4 (&out)[4]) {
-    const float sc = lo_bf(sb), bi = hi_bf(sb);
-    const uint32_t w[4] = {qw.x, qw.y, qw.z, qw.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        uint32_t o[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float q0 = (float)((w[i] >> (8 * j)) & 15u), q1 = (float)((w[i] >> (8 * j + 4)) & 15u);
-            // mul and add rounded separately like the oracle (no fma contraction)
-            o[j] = pack_bf(__fadd_rn(__fmul_rn(q0, sc), bi), __fadd_rn(__fmul_rn(q1, sc), bi));
-        }
-        out[i] = make_uint4(o[0], o[1], o[2], o[3]);
-    }
-}
-
-// EPI: 0 = bf16 store (+bias, +optional silu), row-major or fragment-major
-//      2 = gate/up tile pair -> bf16(bf16(silu(g)) * u), fragment-major
-//      3 = hidden-state store, fragment-major, in place: h = bf16((resid ? h : 0) + bf16(acc + bias)),
-//          plus ss_out[tile][m] = sum over the tile's 16 features of h^2
-// NORM: RMSNorm prologue on x (x is then the raw residual stream h)
-// NP (EPI 2 only): gate/up tile pairs per workgroup. A 6144-wide MLP is 384 pairs: one pair per workgroup runs as a full
-// round of 256 workgroups plus a half-empty one; two pairs per workgroup is one round of 192.
 template <int MB, int EPI, int NW, int CH, bool NORM, bool QUANT, int NP = 1>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
-    constexpr int NT = (EPI == 2) ? 2 * NP : 1;  // weight tiles per workgroup
-    constexpr int NR = (EPI == 2) ? 2 : 1;       // tiles reduced per pass of the epilogue
-    __shared__ float red[NW][NR][MB][4][64];
-    __shared__ __attribute__((aligned(16))) uint16_t ys[MB][16][16];
-    __shared__ float rstd_s[NORM ? 16 * MB : 1];
-    __shared__ float ssp_s[NORM ? 8 : 1][NORM ? 16 * MB : 1];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int tile = blockIdx.x;
-    const int mb0 = blockIdx.y * MB;  // first 16-row block of this workgroup (launch_q splits the rows of narrow layers)
-    const int KC = a.K >> 7;  // 128-wide k chunks
-
-    f32x4 acc[NT][MB];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) acc[t][mb] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const uint4* Wt = reinterpret_cast<const uint4*>(a.W);
-    const uint4* Xt = reinterpret_cast<const uint4*>(a.x);
-
-    // 0. NORM: the producer's per-tile sums of squares are requested before anything else. They gate the whole prologue
-    //    (rstd -> normalised x fragments), and loads return in issue order: with the sums first, the reduction and the
-    //    VALU work on x run while the weight tiles are still arriving instead of after the last of them.
-    constexpr int kSsIter = NORM ? (16 * MB * 8 + NW * 64 - 1) / (NW * 64) : 1;
-    float sst[kSsIter][16];
-    if constexpr (NORM) {
-        const int rows = 16 * MB;
-#pragma unroll
-        for (int it = 0; it < kSsIter; ++it) {
-            const int idx = threadIdx.x + it * NW * 64;
-            const int row = idx % rows, part = idx / rows;  // (row, part): 8 strided partial sums per row
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int j = part + 8 * u;
-                sst[it][u] = (idx < rows * 8) ? a.ss_in[(size_t)(j < a.ss_count ? j : 0) * a.ss_ld + 16 * mb0 + row] : 0.f;
-            }
-        }
-    }
-
-    // 1. weight loads: they depend on nothing
-    constexpr int CHR = CH > 0 ? CH : 1;
-    constexpr int WL = QUANT ? 1 : 4;  // dwordx4 loads per (chunk, tile): packed int4 needs one
-    uint4 wf[CHR][NT][WL];
-    uint32_t wsb[CHR][NT];
-    auto load_w = [&](int c, int kc) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const size_t blk = (size_t)(tile * NT + t) * KC + kc;
-            if constexpr (QUANT) {
-                wf[c][t][0] = Wt[blk * 64 + lane];
-                wsb[c][t] = a.Wsb[blk * 64 + lane];
-            } else {
-                const uint4* wp = Wt + blk * 256 + lane;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) wf[c][t][i] = wp[i * 64];
-            }
-        }
-    };
-
-    // 1b. every other operand that does not depend on arithmetic is requested now as well, so that the kernel pays
-    //     ONE memory round trip instead of a chain of three (sums of squares -> x fragments -> residual tile):
-    //     the raw x fragments of the first XG chunks, and (EPI 3) the old hidden-state piece this thread will update.
-    // chunks whose x fragments are prefetched: as many as fit next to the weight registers (16 VGPRs per fragment set)
-    constexpr int kWRegs = CH * NT * (QUANT ? 5 : 16);
-    // (one row block leaves room for every chunk of the widest layer, K = 6144: one round trip for the whole workgroup)
-    constexpr int kRoom = (((MB == 1 && !NORM) ? 200 : 176) - kWRegs) / (MB * 16);
-    constexpr int kCap = (MB == 1 && !NORM) ? 6 : 3;
-    constexpr int XG = (CH == 0) ? 0 : (kRoom < 1 ? 1 : (kRoom > kCap ? (CH < kCap ? CH : kCap) : (kRoom < CH ? kRoom : CH)));
-    uint4 xr[XG > 0 ? XG : 1][MB][4];
-    uint4 nwr[(NORM && XG > 0) ? XG : 1][4];
-    // issue order: weights then x, or (NORM) x then weights so that normalising x overlaps the weights' arrival.
-    // Written as a two-trip unrolled loop instead of lambdas: capturing the fragment arrays by reference sends them to scratch.
-#pragma unroll
-    for (int ph = 0; ph < 2; ++ph) {
-        if ((ph == 0) != NORM) {
-    if constexpr (CH > 0) {
-#pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                const int kl = wave + c * NW;
-                load_w(c, kl < KC ? kl : 0);
-            }
-        }
-        } else {
-    if constexpr (XG > 0) {
-#pragma unroll
-        for (int c = 0; c < XG; ++c) {
-            const int kl = wave + c * NW;
-            const int kc = kl < KC ? kl : 0;
-            if constexpr (NORM) {
-                const uint4* np = reinterpret_cast<const uint4*>(a.norm_w + kc * 128 + 32 * (lane >> 4));
-#pragma unroll
-                for (int i = 0; i < 4; ++i) nwr[c][i] = np[i];
-            }
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                const uint4* xp = Xt + ((size_t)(kc * a.xMB + mb0 + mb) * 4) * 64 + lane;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) xr[c][mb][i] = xp[i * 64];
-            }
-        }
-    }
-        }
-    }
-    uint4 hv_pre = make_uint4(0, 0, 0, 0);
-    if constexpr (EPI == 3) {
-        if (a.resid && threadIdx.x < 32 * MB) {
-            const int o = threadIdx.x, mb = o >> 5, b = (o >> 1) & 15, p = o & 1;
-            hv_pre = *reinterpret_cast<const uint4*>(a.y + act_tiled_offset(16 * (mb0 + mb) + b, tile * 16 + 8 * p, a.yMB));
-        }
-    }
-
-    // 2. NORM: rstd per row from the producer's per-tile sums of squares, summed in tile order
-    float rstd[MB];
-    if constexpr (NORM) {
-        const int rows = 16 * MB;
-#pragma unroll
-        for (int it = 0; it < kSsIter; ++it) {
-            const int idx = threadIdx.x + it * NW * 64;
-            if (idx < rows * 8) {
-                const int row = idx % rows, part = idx / rows;
-                float s = 0.f;
-#pragma unroll
-                for (int u = 0; u < 16; ++u)
-                    if (part + 8 * u < a.ss_count) s += sst[it][u];
-                for (int j = part + 128; j < a.ss_count; j += 8) s += a.ss_in[(size_t)j * a.ss_ld + 16 * mb0 + row];
-                ssp_s[part][row] = s;
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < rows) {
-            float s = 0.f;
-#pragma unroll
-            for (int p = 0; p < 8; ++p) s += ssp_s[p][threadIdx.x];
-            rstd_s[threadIdx.x] = 1.0f / sqrtf(s / (float)a.norm_dim + a.norm_eps);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) rstd[mb] = rstd_s[16 * mb + (lane & 15)];
-    }
-
-    // 3. x fragments (+ norm) and MFMAs
-    auto chunk = [&](int kc, int c, const uint4 (*xpre)[4], const uint4* nwpre) {
-        uint4 w[NT][4];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if constexpr (QUANT) {
-                dequant_chunk(wf[c][t][0], wsb[c][t], w[t]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) w[t][i] = wf[c][t][i];
-            }
-        }
-        uint4 nw[4];
-        if constexpr (NORM) {
-            if (nwpre) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) nw[i] = nwpre[i];
-            } else {
-                const uint4* np = reinterpret_cast<const uint4*>(a.norm_w + kc * 128 + 32 * (lane >> 4));
-#pragma unroll
-                for (int i = 0; i < 4; ++i) nw[i] = np[i];
-            }
-        }
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            uint4 xf[4];
-            if (xpre) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) xf[i] = xpre[mb][i];
-            } else {
-                const uint4* xp = Xt + ((size_t)(kc * a.xMB + mb0 + mb) * 4) * 64 + lane;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) xf[i] = xp[i * 64];
-            }
-            if constexpr (NORM) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) xf[i] = norm8(xf[i], nw[i], rstd[mb]);
-            }
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[t][mb] = mfma16(w[t][i], xf[i], acc[t][mb]);
-        }
-    };
-    if constexpr (CH > 0) {
-        // chunks in groups of XG: the first group's fragments are already in flight; each later group is requested as a
-        // whole (one round trip per group) into the same registers
-#pragma unroll
-        for (int g0 = 0; g0 < CH; g0 += XG) {
-            if (g0 > 0) {
-#pragma unroll
-                for (int c = 0; c < XG; ++c) {
-                    if (g0 + c < CH) {
-                        const int kl = wave + (g0 + c) * NW;
-                        const int kc = kl < KC ? kl : 0;
-                        if constexpr (NORM) {
-                            const uint4* np = reinterpret_cast<const uint4*>(a.norm_w + kc * 128 + 32 * (lane >> 4));
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) nwr[c][i] = np[i];
-                        }
-#pragma unroll
-                        for (int mb = 0; mb < MB; ++mb) {
-                            const uint4* xp = Xt + ((size_t)(kc * a.xMB + mb0 + mb) * 4) * 64 + lane;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) xr[c][mb][i] = xp[i * 64];
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < XG; ++c) {
-                if (g0 + c < CH) {
-                    const int kl = wave + (g0 + c) * NW;
-                    if (kl < KC) chunk(kl, g0 + c, xr[c], NORM ? nwr[c] : nullptr);  // wave-uniform
-                }
-            }
-        }
-    } else {
-        for (int kl = wave; kl < KC; kl += NW) {
-            load_w(0, kl);
-            chunk(kl, 0, nullptr, nullptr);
-        }
-    }
-
-    // 4. cross-wave K reduction through LDS, fixed wave order; one tile (EPI 2: one gate/up pair) per pass
-#pragma unroll
-    for (int pr = 0; pr < NT / NR; ++pr) {
-    if (pr > 0) __syncthreads();  // the previous pair's red / ys reads
-#pragma unroll
-    for (int t = 0; t < NR; ++t)
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) red[wave][t][mb][q][lane] = acc[pr * NR + t][mb][q];
-    __syncthreads();
-    const int otile = tile * (NT / NR) + pr;  // 16-column output tile
-
-    // 256*MB outputs per tile: thread -> (mb, batch row b, feature f)
-    for (int o = threadIdx.x; o < 256 * MB; o += NW * 64) {
-        const int mb = o >> 8, rem = o & 255;
-        const int b = rem >> 4, f = rem & 15;
-        const int src_lane = (f >> 2) * 16 + b, q = f & 3;
-        float v[NR];
-#pragma unroll
-        for (int t = 0; t < NR; ++t) {
-            float sum = 0.f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) sum += red[w][t][mb][q][src_lane];
-            v[t] = sum;
-        }
-        const int n = otile * 16 + f;
-        if constexpr (EPI == 2) {
-            const float g = rbf(v[0]), u = rbf(v[1]);
-            ys[mb][b][f] = f2bf(rbf(silu_f(g)) * u);
-        } else {
-            float y = v[0];
-            if (a.bias) y += bf2f(a.bias[n]);
-            uint16_t yb = f2bf(y);
-            if (EPI == 0 && a.act_silu) yb = f2bf(silu_f(bf2f(yb)));
-            ys[mb][b][f] = yb;
-        }
-    }
-    __syncthreads();
-    // 16-byte stores: thread -> (mb, row b, 8-feature piece p)
-    for (int o = threadIdx.x; o < 32 * MB; o += NW * 64) {
-        const int mb = o >> 5, b = (o >> 1) & 15, p = o & 1;
-        const int m = 16 * (mb0 + mb) + b;
-        uint4 v = *reinterpret_cast<const uint4*>(&ys[mb][b][8 * p]);
-        const int n = otile * 16 + 8 * p;
-        if constexpr (EPI == 3) {
-            uint16_t* hp = a.y + act_tiled_offset(m, n, a.yMB);
-            float ss = 0.f;
-            const uint32_t yw[4] = {v.x, v.y, v.z, v.w};
-            uint32_t ow[4];
-            const uint4 hv = hv_pre;  // o == threadIdx.x here (32 * MB <= 128 threads, one trip)
-            const uint32_t hw[4] = {hv.x, hv.y, hv.z, hv.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float h0 = lo_bf(yw[j]), h1 = hi_bf(yw[j]);
-                if (a.resid) {
-                    h0 = rbf(lo_bf(hw[j]) + h0);
-                    h1 = rbf(hi_bf(hw[j]) + h1);
-                }
-                ss += h0 * h0;
-                ss += h1 * h1;
-                ow[j] = pack_bf(h0, h1);
-            }
-            const float other = __shfl_xor(ss, 1, 64);  // the tile's second 8-feature piece of this row
-            if (m < a.M) {
-                *reinterpret_cast<uint4*>(hp) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-                if (p == 0 && a.ss_out) a.ss_out[(size_t)tile * a.ss_ld + m] = ss + other;
-            }
-        } else {
-            if (m >= a.M) continue;
-            if (EPI == 2 || a.y_tiled)
-                *reinterpret_cast<uint4*>(a.y + act_tiled_offset(m, n, a.yMB)) = v;
-            else
-                *reinterpret_cast<uint4*>(a.y + (size_t)m * a.ldy + n) = v;
-        }
-    }
-    }
+    gemm_skinny_body<MB, EPI, NW, CH, NORM, QUANT, NP, false>(a, blockIdx.x, blockIdx.y * MB, nullptr);
 }
 
 template <int MB, int EPI, bool NORM, bool QUANT>
