@@ -51,9 +51,6 @@ typedef struct {
                                        q3tts_model_arena before the first generate */
     int32_t n_streams;  /* lanes the batch is split over (own HIP stream + hipGraph + host thread each);
                            0 = default (1). Results do not depend on it (rows are independent) */
-    int32_t persistent; /* 1: each decoder-stack forward of the AR loop is ONE persistent kernel (phases separated by a
-                           device-wide flag barrier, next phase's weights prefetched across it) instead of one launch
-                           per op; 0: launch per op; -1: engine default. Same arithmetic either way */
 } q3tts_load_opts;
 
 void q3tts_default_load_opts(q3tts_load_opts* o);

@@ -45,7 +45,6 @@ void q3tts_default_load_opts(q3tts_load_opts* o) {
     o->use_graph = 1;
     o->weights_from_broadcast = 0;
     o->n_streams = 0;
-    o->persistent = -1;
 }
 
 void q3tts_default_sampling(q3tts_sampling* s) {  // Qwen3.swift:1296-1299

@@ -53,55 +53,7 @@ Engine::Engine(Model* model, const q3tts_load_opts& opts) : m_(model), opts_(opt
     n_pages_ = Bm_ * max_pages_;
     for (auto& kv : m_->cfg.talker.spk_id) speakers.push_back(kv.first);
     std::sort(speakers.begin(), speakers.end());
-    {   // persistent stack kernel: bf16 weights, uniform layer widths, an instantiated width combination
-        const TalkerConfig& t = m_->cfg.talker;
-        auto uniform = [](const StackW& s) {
-            for (auto& L : s.layers)
-                if (L.inter_p != s.layers[0].inter_p) return false;
-            return !s.layers.empty();
-        };
-        const bool ok = !m_->cfg.has_quantization && uniform(m_->talker) && uniform(m_->cp) &&
-                        stack_persist_supported(t.hidden_size, t.num_attention_heads * kHeadDim, m_->talker.layers[0].inter_p, 0,
-                                                t.num_attention_heads, t.num_key_value_heads) &&
-                        stack_persist_supported(t.cp.hidden_size, t.cp.num_attention_heads * kHeadDim, m_->cp.layers[0].inter_p,
-                                                m_->has_cp_proj ? t.hidden_size : 0, t.cp.num_attention_heads,
-                                                t.cp.num_key_value_heads) &&
-                        t.hidden_size <= 2048 && t.cp.hidden_size <= 2048;
-        const char* env = std::getenv("Q3TTS_PERSISTENT");
-        int want = opts.persistent;
-        if (want < 0 && env) want = std::atoi(env);
-        if (want < 0) want = 0;  // engine default
-        Q3_CHECK(want == 0 || ok || opts.persistent < 0, 3, "Invalid input: the persistent kernel does not support this model configuration");
-        persistent_ = want != 0 && ok;
-        hipDeviceProp_t prop{};
-        Q3_HIP(hipGetDeviceProperties(&prop, m_->device));
-        persist_grid_ = std::min(256, prop.multiProcessorCount);
-        if (const char* g = std::getenv("Q3TTS_PERSIST_GRID")) persist_grid_ = std::max(8, std::min(std::atoi(g), prop.multiProcessorCount));
-    }
     alloc_workspace();
-    // Off by default: measured 2 % SLOWER on the frame step than the two launches; kept as the
-    // starting point for finer-grained producer/consumer launches
-    if (!persistent_ && std::getenv("Q3TTS_FUSED_ATTN")) {
-        const TalkerConfig& tc = m_->cfg.talker;
-        fuse_nodes_cap_ = tc.cp.num_hidden_layers * tc.num_code_groups;
-        Q3_HIP(hipMalloc(reinterpret_cast<void**>(&fuse_flags_), size_t(fuse_nodes_cap_) * 512 * 4));
-        Q3_HIP(hipMalloc(reinterpret_cast<void**>(&fuse_err_), 4));
-        Q3_HIP(hipMemset(fuse_err_, 0, 4));
-        fuse_ = true;
-    }
-    if (persistent_) {
-        auto table = [&](const StackW& s, uint16_t* kp, uint16_t* vp, size_t stride, PersistLayer** out) {
-            std::vector<PersistLayer> v(s.layers.size());
-            for (size_t l = 0; l < s.layers.size(); ++l) {
-                const LayerW& L = s.layers[l];
-                v[l] = PersistLayer{L.qkv.w, L.o.w, L.gateup.w, L.down.w, L.ln1, L.ln2, L.qn, L.kn, kp + l * stride, vp + l * stride, L.inter_p};
-            }
-            Q3_HIP(hipMalloc(reinterpret_cast<void**>(out), v.size() * sizeof(PersistLayer)));
-            Q3_HIP(hipMemcpy(*out, v.data(), v.size() * sizeof(PersistLayer), hipMemcpyHostToDevice));
-        };
-        table(m_->talker, kpool_, vpool_, kv_layer_stride_, &tk_layers_dev_);
-        table(m_->cp, cp_kpool_, cp_vpool_, cp_kv_layer_stride_, &cp_layers_dev_);
-    }
     if (m_->has_codec) codec_ = std::make_unique<CodecRunner>(*m_, st_);
     if (m_->has_codec_encoder || m_->has_speaker_encoder) fe_ = std::make_unique<VoiceFrontEnd>(*m_, st_);
 }
@@ -118,12 +70,7 @@ Engine::~Engine() {
     }
     for (void* p : {(void*)ref_audio_dev_, (void*)ref_codes_dev_, (void*)extra_, (void*)spk_f32_, (void*)dec_codes_})
         if (p) (void)hipFree(p);
-    if (fuse_flags_) (void)hipFree(fuse_flags_);
-    if (fuse_err_) (void)hipFree(fuse_err_);
     if (ws_) (void)hipFree(ws_);
-    if (uc_ws_) (void)hipFree(uc_ws_);
-    if (tk_layers_dev_) (void)hipFree(tk_layers_dev_);
-    if (cp_layers_dev_) (void)hipFree(cp_layers_dev_);
     for (void* p : {(void*)forced_dev_, (void*)sampled_dev_, (void*)tl_dump_, (void*)cl_dump_})
         if (p) (void)hipFree(p);
     for (auto& e : ev_)
@@ -182,9 +129,7 @@ void Engine::alloc_workspace() {
     proj_cap_ = Bm_ * (2 * Pcap_ + 8);  // text + instruct or reference-text ids + the three tts tokens per row
     for (int pass = 0; pass < 2; ++pass) {
         Bump b{pass ? ws_ : nullptr};
-        // persistent path: everything one workgroup writes and another reads inside a launch lives in uncached memory
-        Bump uc{pass ? uc_ws_ : nullptr};
-        Bump& x = persistent_ ? uc : b;
+        Bump& x = b;
         auto stream = [&](Stream& s, int hid, int q, int k, int inter_p, int vocab) {
             s.ld_qkv = q + 2 * k;
             s.ld_act = inter_p;
@@ -203,11 +148,6 @@ void Engine::alloc_workspace() {
         cp_x_ = x.take<uint16_t>(size_t(Mp_) * H);
         cp_x2_ = x.take<uint16_t>(size_t(Mp_) * H);
         cp_ss2_ = x.take<float>(size_t(Mp_));
-        if (persistent_) {
-            sync_flags_ = uc.take<unsigned>(512);
-            sync_epoch_ = uc.take<unsigned>(64);
-            sync_err_ = uc.take<int>(64);
-        }
         kpool_ = b.take<uint16_t>(kv_layer_stride_ * L);
         vpool_ = b.take<uint16_t>(kv_layer_stride_ * L);
         cp_kpool_ = b.take<uint16_t>(cp_kv_layer_stride_ * CL);
@@ -240,11 +180,6 @@ void Engine::alloc_workspace() {
             ws_bytes_ = align_up(b.off, 256);
             Q3_HIP(hipMalloc(reinterpret_cast<void**>(&ws_), ws_bytes_));
             Q3_HIP(hipMemset(ws_, 0, ws_bytes_));
-            if (persistent_) {
-                uc_ws_bytes_ = align_up(uc.off, 256);
-                Q3_HIP(hipExtMallocWithFlags(reinterpret_cast<void**>(&uc_ws_), uc_ws_bytes_, hipDeviceMallocUncached));
-                Q3_HIP(hipMemset(uc_ws_, 0, uc_ws_bytes_));
-            }
         }
     }
     std::vector<int32_t> cbt((size_t)(Bm_));  // code-predictor cache: one private page per row
@@ -305,13 +240,8 @@ void Engine::enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, 
         at.fixed_len = fixed_len; at.identity_pages = fixed_len >= 0 ? 1 : 0;
         at.chunk = chunk; at.chunk_n_prompt = chunk_n_prompt; at.chunk_r_base = chunk_r_base;
         at.scale = powf(float(kHeadDim), -0.5f);  // Talker.swift:179
-        if (fuse_ && fuse_node_ >= 0 && fuse_node_ < fuse_nodes_cap_ && q.N / 16 <= 512 && qkv_attn_fused_supported(q, at)) {
-            launch_qkv_attn_fused(q, at, fuse_flags_ + size_t(fuse_node_) * 512, fuse_err_, st_);
-            ++fuse_node_;
-        } else {
-            launch_gemm_skinny(q, st_);
-            launch_attn_decode(at, st_);
-        }
+        launch_gemm_skinny(q, st_);
+        launch_attn_decode(at, st_);
         GemmArgs o = gemm_args(L.o, w.ao, M);
         o.epi = 3; o.y = w.h; o.yMB = MBL; o.resid = 1; o.ss_out = w.ss_b;
         launch_gemm_skinny(o, st_);
@@ -328,56 +258,8 @@ void Engine::enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, 
     }
 }
 
-void Engine::enqueue_stack_persist(const StackW& s, const PersistLayer* layers_dev, Stream& w, int B, const int32_t* block_table,
-                                   int max_pages, const int32_t* kv_len, const uint8_t* active, int ss_count_in,
-                                   const LinearW* proj, const uint16_t* proj_x, const uint16_t* proj_norm_w,
-                                   const float* proj_ss_in, int proj_ss_count, int proj_norm_dim, float proj_norm_eps,
-                                   const LinearW* head, const uint16_t* head_norm_w) {
-    StackPersistArgs a{};
-    a.layers = layers_dev;
-    a.n_layers = int(s.layers.size());
-    a.H = s.hidden; a.QD = s.n_heads * kHeadDim; a.KD = s.n_kv * kHeadDim; a.I_p = s.layers[0].inter_p;
-    a.n_heads = s.n_heads; a.n_kv = s.n_kv; a.eps = s.eps; a.scale = powf(float(kHeadDim), -0.5f);
-    a.h = w.h; a.qkv = w.qkv; a.ao = w.ao; a.act = w.act; a.ss_a = w.ss_a; a.ss_b = w.ss_b;
-    a.MBL = Mp_ / 16; a.ss_ld = Mp_; a.ld_qkv = w.ld_qkv; a.M = B; a.ss_count_in = ss_count_in;
-    if (proj) {
-        a.proj_W = proj->w; a.proj_bias = proj->bias; a.proj_x = proj_x; a.proj_K = proj->Kp;
-        a.proj_norm_w = proj_norm_w; a.proj_ss_in = proj_ss_in; a.proj_ss_count = proj_ss_count;
-        a.proj_norm_dim = proj_norm_dim; a.proj_norm_eps = proj_norm_eps;
-    }
-    if (head) {
-        a.head_W = head->w; a.head_norm_w = head_norm_w; a.logits = w.logits; a.ld_logits = w.ld_logits; a.head_N = head->Np;
-    }
-    a.rope_cos = s.rope_cos; a.rope_sin = s.rope_sin; a.block_table = block_table; a.max_pages = max_pages;
-    a.kv_len = kv_len; a.active = active;
-    a.flags = sync_flags_; a.epoch = sync_epoch_; a.err = sync_err_;
-    launch_stack_persist(a, persist_grid_, st_);
-}
-
-void Engine::check_persist_error() {
-    if (fuse_) {
-        int ferr = 0;
-        Q3_HIP(hipMemcpy(&ferr, fuse_err_, 4, hipMemcpyDeviceToHost));
-        if (ferr) {
-            Q3_HIP(hipMemset(fuse_err_, 0, 4));
-            throw Error(7, "fused qkv + attention: " + std::to_string(ferr) + " attention units timed out waiting for their projection tiles");
-        }
-    }
-    if (!persistent_) return;
-    int err = 0;
-    Q3_HIP(hipMemcpy(&err, sync_err_, 4, hipMemcpyDeviceToHost));
-    if (err) {
-        Q3_HIP(hipMemset(sync_err_, 0, 4));
-        throw Error(7, "persistent kernel: a device-wide barrier timed out (" + std::to_string(err) + " workgroups)");
-    }
-}
-
 void Engine::enqueue_talker_step(int B, bool with_head) {
-    if (persistent_) {  // layers (+ final norm + codec_head, Talker.swift:573, 644) in one launch
-        enqueue_stack_persist(m_->talker, tk_layers_dev_, tk_, B, block_table_, max_pages_, kv_len_, active_, 1, nullptr, nullptr,
-                              nullptr, nullptr, 0, 0, 0.f, with_head ? &m_->codec_head : nullptr, m_->talker.final_norm);
-        return;
-    }
+    (void)with_head;
     enqueue_layers(m_->talker, tk_, B, kpool_, vpool_, kv_layer_stride_, block_table_, max_pages_, kv_len_, active_, 1, -1, 1, nullptr, 0);
 }
 
@@ -389,27 +271,13 @@ void Engine::enqueue_cp_pass(int B, bool from_talker, int head, int cp_pos, bool
     const int H = t.hidden_size, CH = m_->cp.hidden, MBL = Mp_ / 16;
     int ss_count = 1;
     // The talker's final norm (Talker.swift:573) is always a row kernel, so that every way of scheduling step 0 (two
-    // passes, one two-position pass, the persistent kernel) rounds it identically.
+    // passes, one two-position pass) rounds it identically.
     auto talker_norm_into = [&](uint16_t* dst, float* ss_out) {
         NormRowsArgs n{};
         n.h = tk_.h; n.hMB = MBL; n.w = m_->talker.final_norm; n.eps = m_->talker.eps;
         n.out = dst; n.outMB = MBL; n.ss_out = ss_out; n.M = B; n.H = H;
         launch_norm_rows(n, st_);
     };
-    if (persistent_) {  // [projection +] layers [+ final norm + lm_head] in one launch
-        const LinearW* hd = head >= 0 ? &m_->lm_head[size_t(head)] : nullptr;
-        if (m_->has_cp_proj) {
-            // cp_x_ already holds embed(code0) for the second position: the normed hidden state goes to cp_x2_
-            if (from_talker) talker_norm_into(cp_x2_, nullptr);
-            enqueue_stack_persist(m_->cp, cp_layers_dev_, cp_, B, cp_block_table_, 1, cp_len_, nullptr, 1, &m_->cp_proj,
-                                  from_talker ? cp_x2_ : cp_x_, nullptr, nullptr, 0, 0, 0.f, hd, m_->cp.final_norm);
-        } else {
-            if (from_talker) talker_norm_into(cp_.h, cp_.ss_a);
-            enqueue_stack_persist(m_->cp, cp_layers_dev_, cp_, B, cp_block_table_, 1, cp_len_, nullptr, 1, nullptr, nullptr, nullptr,
-                                  nullptr, 0, 0, 0.f, hd, m_->cp.final_norm);
-        }
-        return;
-    }
     if (m_->has_cp_proj && projected) {  // the sampler gathered an already projected row and its sums (build_cp_proj_tables)
         ss_count = CH / 16;
     } else if (m_->has_cp_proj) {  // small_to_mtp_projection (biased), CodePredictor.swift:327-330
@@ -426,17 +294,11 @@ void Engine::enqueue_cp_pass(int B, bool from_talker, int head, int cp_pos, bool
 }
 
 void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
-    struct FuseScope {  // fused launches are numbered within a frame; outside enqueue_frame nothing fuses
-        int& n;
-        explicit FuseScope(int& r) : n(r) { n = 0; }
-        ~FuseScope() { n = -1; }
-    } fuse_scope(fuse_node_);
-    if (fuse_) Q3_HIP(hipMemsetAsync(fuse_flags_, 0, size_t(fuse_nodes_cap_) * 512 * 4, st_));
     const TalkerConfig& t = m_->cfg.talker;
     const int H = t.hidden_size, V = t.vocab_size, Vc = t.cp.vocab_size, CH = t.cp.hidden_size;
     const int groups = t.num_code_groups, MBL = Mp_ / 16;
     enqueue_talker_step(B, true);
-    if (!persistent_) {   // final norm (prologue) + codec_head (Talker.swift:573, 644)
+    {   // final norm (prologue) + codec_head (Talker.swift:573, 644)
         GemmArgs hd = gemm_args(m_->codec_head, tk_.h, B);
         hd.epi = 0; hd.y = tk_.logits; hd.ldy = tk_.ld_logits;
         hd.norm_w = m_->talker.final_norm; hd.ss_in = tk_.ss_a; hd.ss_count = H / 16; hd.norm_dim = H; hd.norm_eps = m_->talker.eps;
@@ -447,8 +309,8 @@ void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
     float* next_ss = m_->has_cp_proj ? nullptr : cp_.ss_a;
     // Predictor step 0 takes two positions, [talker hidden, embed(code0)] (Qwen3.swift:884-887). When 2 * B rows fit the
     // activation buffers they go through the stack together (rows 0..B-1 and B..2B-1, chunk attention), which saves a
-    // whole pass of launches per frame; otherwise (and on the persistent path) they are two passes.
-    const bool pair = !persistent_ && 2 * B <= Mp_;
+    // whole pass of launches per frame; otherwise they are two passes.
+    const bool pair = 2 * B <= Mp_;
     SamplerArgs sa{};
     sa.logits = tk_.logits; sa.ldl = tk_.ld_logits; sa.V = V; sa.sp = sp_dev_; sa.is_talker = 1;
     sa.suppress_lo = V - 1024; sa.suppress_hi = V; sa.eos_id = t.codec_eos_token_id;  // Qwen3.swift:829-835
@@ -497,7 +359,7 @@ void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
         const bool second_of_pair = pair && i == 0;  // its stack forward already ran above; rows B..2B-1 hold it
         const int Mh = second_of_pair ? 2 * B : B;
         if (!second_of_pair) enqueue_cp_pass(B, false, i, i + 1, cp_tables_ && i >= 1);
-        if (!persistent_) {
+        {
             GemmArgs lh = gemm_args(m_->lm_head[size_t(i)], cp_.h, Mh);
             lh.epi = 0; lh.y = cp_.logits; lh.ldy = cp_.ld_logits;
             lh.norm_w = m_->cp.final_norm; lh.ss_in = cp_.ss_a; lh.ss_count = CH / 16; lh.norm_dim = CH; lh.norm_eps = m_->cp.eps;
@@ -995,11 +857,6 @@ void Engine::generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp
     for (int32_t* p : {kv_len_, cp_len_, n_frames_, trailing_idx_}) Q3_HIP(hipMemsetAsync(p, 0, size_t(n) * 4, st_));
     Q3_HIP(hipMemsetAsync(active_, 0, size_t(n), st_));
     Q3_HIP(hipMemsetAsync(finished_, 0, size_t(n), st_));
-    if (persistent_) {  // barrier sequence restarts with every call (the stream is idle here)
-        Q3_HIP(hipMemsetAsync(sync_flags_, 0, 512 * sizeof(unsigned), st_));
-        Q3_HIP(hipMemsetAsync(sync_epoch_, 0, sizeof(unsigned), st_));
-        Q3_HIP(hipMemsetAsync(sync_err_, 0, sizeof(int), st_));
-    }
     Q3_HIP(hipMemsetAsync(seen_, 0, size_t(n) * V, st_));
     Q3_HIP(hipMemsetAsync(codes_, 0, size_t(n) * Fcap_ * 16 * 4, st_));
     SamplingParams sph{sp.temperature, sp.top_k, sp.top_p, sp.repetition_penalty, sp.seed, row_offset, sp.force_frames > 0 ? 1 : 0};
@@ -1033,7 +890,6 @@ void Engine::generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp
     {
         const int P1 = Pmax - 1;  // positions before the one the first frame step consumes
         int C = std::max(1, std::min(8, Mp_ / n));
-        if (persistent_) C = 1;   // the persistent stack kernel takes one position per launch
         const int S = (P1 + C - 1) / C;
         for (int s = 0; s < S; ++s) {
             // element p of row b in chunk s is prompt position r = s*C - S*C + (n_prompt[b] - 1) + p
@@ -1060,7 +916,7 @@ void Engine::generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp
     // ---- frame loop ----
     const bool use_graph = opts_.use_graph && !dbg;
     // the tables are cut from the weights, which may arrive after load (weights_from_broadcast): first use, not load
-    if (!cp_tables_ && m_->has_cp_proj && !persistent_ && !std::getenv("Q3TTS_NO_PROJ_TABLES")) build_cp_proj_tables();
+    if (!cp_tables_ && m_->has_cp_proj && !std::getenv("Q3TTS_NO_PROJ_TABLES")) build_cp_proj_tables();
     hipGraphExec_t ge = use_graph ? frame_graph(n) : nullptr;
     std::vector<int32_t> h_nframes((size_t)(n), 0), h_codes;
     std::vector<uint8_t> h_fin((size_t)(n), 0);
@@ -1116,7 +972,6 @@ void Engine::generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp
     Q3_HIP(hipEventRecord(ev_[2], st_));
     Q3_HIP(hipMemcpyAsync(h_nframes.data(), n_frames_, size_t(n) * 4, hipMemcpyDeviceToHost, st_));
     Q3_HIP(hipStreamSynchronize(st_));
-    check_persist_error();
     if (dbg) {
         const size_t nf = size_t(n) * dbg->frames;
         if (dbg->sampled) Q3_HIP(hipMemcpy(dbg->sampled, sampled_dev_, nf * 16 * 4, hipMemcpyDeviceToHost));

@@ -102,12 +102,6 @@ class Engine {
     uint16_t* cp_x2_ = nullptr;
     // small_to_mtp_projection applied to every row of the code predictor's embedding tables at load (by the decode GEMM
     // itself, so rows are bit-identical to projecting at run time); kept in the Model, see Model::cp_pe
-    // fused qkv + attention launches of the code predictor (fused_qkv_attn.hip): one flag array per launch of a frame,
-    // zeroed by a memset at the head of the frame; fuse_node_ counts the launches while a frame is being enqueued
-    unsigned* fuse_flags_ = nullptr;
-    int* fuse_err_ = nullptr;
-    int fuse_nodes_cap_ = 0, fuse_node_ = -1;  // -1: not inside enqueue_frame (prefill, tables): no fusing
-    bool fuse_ = false;
     bool cp_tables_ = false;  // the samplers hand projected rows (Model::cp_pe) straight to the next pass
     void build_cp_proj_tables();  // staged embedding of code 0 (second position of predictor step 0)
     float* cp_ss2_ = nullptr;
@@ -153,20 +147,6 @@ class Engine {
     const float* upload_audio(const float* audio, int64_t n);
     void prepare_clone_rows(std::vector<ResolvedRequest>& reqs);
 
-    // persistent stack-forward path (kernels/stack_persist.hip)
-    bool persistent_ = false;
-    int persist_grid_ = 256;
-    uint8_t* uc_ws_ = nullptr;          // uncached device memory: activations exchanged between workgroups + barrier state
-    size_t uc_ws_bytes_ = 0;
-    PersistLayer *tk_layers_dev_ = nullptr, *cp_layers_dev_ = nullptr;
-    unsigned *sync_flags_ = nullptr, *sync_epoch_ = nullptr;
-    int* sync_err_ = nullptr;
-    void enqueue_stack_persist(const StackW& s, const PersistLayer* layers_dev, Stream& w, int B, const int32_t* block_table,
-                               int max_pages, const int32_t* kv_len, const uint8_t* active, int ss_count_in,
-                               const LinearW* proj, const uint16_t* proj_x, const uint16_t* proj_norm_w, const float* proj_ss_in,
-                               int proj_ss_count, int proj_norm_dim, float proj_norm_eps, const LinearW* head,
-                               const uint16_t* head_norm_w);
-    void check_persist_error();
     void alloc_workspace();
     ResolvedRequest resolve(const q3tts_request& r, const q3tts_sampling& sp) const;
     // builds prompt_/trailing_/tts_pad_ for rows [0,n); fills host-side lengths

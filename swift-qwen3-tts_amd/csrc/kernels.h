@@ -35,58 +35,6 @@ struct GemmArgs {
 };
 void launch_gemm_skinny(const GemmArgs& a, hipStream_t st);
 
-// ---- persistent decoder-stack forward (stack_persist.hip) ------------------------------------------
-constexpr int kRepPersist = 2;     // query heads per kv head handled by the persistent kernel (every shipped config)
-constexpr int kMaxRepPersist = 2;
-struct PersistLayer {  // device-resident, one per layer
-    const uint16_t *qkv, *o, *gateup, *down;  // tiled bf16 weights
-    const uint16_t *ln1, *ln2, *qn, *kn;
-    uint16_t *kpool, *vpool;                  // this layer's KV pool
-    int inter_p;                              // padded intermediate size
-};
-struct StackPersistArgs {
-    const PersistLayer* layers;
-    int n_layers;
-    int H, QD, KD, I_p, n_heads, n_kv;  // hidden, n_heads*128, n_kv*128, padded intermediate (uniform over layers)
-    float eps, scale;
-    // activations exchanged between workgroups: UNCACHED device memory (hipDeviceMallocUncached)
-    uint16_t* h;     // fragment-major residual stream [MBL*16][H]
-    uint16_t* qkv;   // row-major [M][ld_qkv]
-    uint16_t* ao;    // fragment-major [.][QD]
-    uint16_t* act;   // fragment-major [.][I_p]
-    float* ss_a;     // [H/16][ss_ld] per-tile sums of squares entering a layer
-    float* ss_b;     // after o_proj
-    int MBL, ss_ld, ld_qkv, M;
-    int ss_count_in;  // partials of ss_a that describe the rows entering layer 0 (1 when a row kernel produced them)
-    // optional input projection: h <- bf16(proj_W . [RMSNorm](proj_x) + bias)   (small_to_mtp_projection)
-    const uint16_t* proj_W;
-    const uint16_t* proj_bias;
-    const uint16_t* proj_x;
-    int proj_K;
-    const uint16_t* proj_norm_w;  // nullptr: no norm on the projection input
-    const float* proj_ss_in;
-    int proj_ss_count, proj_norm_dim;
-    float proj_norm_eps;
-    // optional head: logits = RMSNorm(h; head_norm_w) . head_W^T, row-major [M][ld_logits]
-    const uint16_t* head_W;
-    const uint16_t* head_norm_w;
-    uint16_t* logits;
-    int ld_logits, head_N;
-    // attention
-    const uint16_t* rope_cos;
-    const uint16_t* rope_sin;
-    const int32_t* block_table;
-    int max_pages;
-    const int32_t* kv_len;
-    const uint8_t* active;
-    // grid barrier state (uncached): flags[grid], epoch[1], err[1]
-    unsigned* flags;
-    unsigned* epoch;
-    int* err;
-};
-bool stack_persist_supported(int H, int QD, int I_p, int proj_K, int n_heads, int n_kv);
-void launch_stack_persist(const StackPersistArgs& a, int grid, hipStream_t st);
-
 // ---- RMSNorm of whole rows (lm_misc.hip): only where a normalised vector must be materialised --
 // (the code predictor's first input when there is no small_to_mtp_projection). In the layers the
 // norm lives in the consumer GEMM's prologue.
@@ -132,11 +80,6 @@ struct AttnArgs {
     int chunk_r_base;
 };
 void launch_attn_decode(const AttnArgs& a, hipStream_t st);
-
-// qkv projection (norm prologue) + one-position attention of a short-cache stack in one launch (fused_qkv_attn.hip).
-// flags: one word per 16-column tile of the projection, zero before the launch; err[0] counts consumer timeouts.
-bool qkv_attn_fused_supported(const GemmArgs& g, const AttnArgs& at);
-void launch_qkv_attn_fused(const GemmArgs& g, const AttnArgs& at, unsigned* flags, int* err, hipStream_t st);
 
 // ---- sampler (sampler.hip) ---------------------------------------------------------------------
 struct SamplingParams {  // lives in device memory so the captured graph does not depend on it

@@ -23,7 +23,7 @@ namespace {
 
 template <int REP, int NTH>
 __global__ __launch_bounds__(NTH) void attn_decode_kernel(AttnArgs a) {
-    attn_decode_body<REP, NTH, false>(a, blockIdx.x, blockIdx.y, nullptr, nullptr);
+    attn_decode_body<REP, NTH>(a, blockIdx.x, blockIdx.y);
 }
 
 // Several consecutive positions of every row in one launch (chunked prompt prefill; the code predictor's step 0,
@@ -185,7 +185,7 @@ void launch_attn_decode(const AttnArgs& a, hipStream_t st) {
     // vectors on four waves, every cached position on its own lane group. One wave per workgroup (free barriers, nothing
     // waits on other waves) looked right on paper and measured 4 % slower on the whole frame step. Long caches: 512
     // threads, 32 lane groups walk the positions (1.3 % on the frame step over 256; LDS allows it up to two query heads per
-    // kv head). The chunk kernel and the persistent kernel use the same counts, so all of them round identically.
+    // kv head). The chunk kernel uses the same counts, so both round identically.
     const bool wide = a.max_pages > 1 && rep <= 2;
     if (a.chunk > 1) {
         Q3_CHECK(a.chunk <= 8, 3, "attn_decode: at most 8 positions per launch");

@@ -39,7 +39,7 @@ namespace {
 
 template <int MB, int EPI, int NW, int CH, bool NORM, bool QUANT, int NP = 1>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
-    gemm_skinny_body<MB, EPI, NW, CH, NORM, QUANT, NP, false>(a, blockIdx.x, blockIdx.y * MB, nullptr);
+    gemm_skinny_body<MB, EPI, NW, CH, NORM, QUANT, NP>(a, blockIdx.x, blockIdx.y * MB);
 }
 
 template <int MB, int EPI, bool NORM, bool QUANT>

@@ -18,7 +18,7 @@ u8p = C.POINTER(C.c_uint8)
 class LoadOpts(C.Structure):
     _fields_ = [("device", C.c_int32), ("max_batch", C.c_int32), ("max_frames", C.c_int32),
                 ("max_prompt", C.c_int32), ("use_graph", C.c_int32), ("weights_from_broadcast", C.c_int32),
-                ("n_streams", C.c_int32), ("persistent", C.c_int32)]
+                ("n_streams", C.c_int32)]
 
 
 class ModelInfo(C.Structure):

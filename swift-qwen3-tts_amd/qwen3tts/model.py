@@ -81,8 +81,7 @@ class Qwen3TTSModel:
     @classmethod
     def from_pretrained(cls, model_path: str, device: int = 0, max_batch: int = 1, max_frames: int = 2048,
                         max_prompt: int = 512, use_graph: bool = True,
-                        weights_from_broadcast: bool = False, n_streams: int = 0,
-                        persistent: int = -1) -> "Qwen3TTSModel":
+                        weights_from_broadcast: bool = False, n_streams: int = 0) -> "Qwen3TTSModel":
         lib = L.lib()
         o = L.LoadOpts()
         lib.q3tts_default_load_opts(C.byref(o))
@@ -90,7 +89,6 @@ class Qwen3TTSModel:
         o.use_graph = 1 if use_graph else 0
         o.weights_from_broadcast = 1 if weights_from_broadcast else 0
         o.n_streams = n_streams
-        o.persistent = persistent
         h = C.c_void_p()
         st = lib.q3tts_model_load(model_path.encode(), C.byref(o), C.byref(h))
         if st != 0:

@@ -1,7 +1,5 @@
-"""Persistent stack kernel (kernels/stack_persist.hip) vs the launch-per-op path: same arithmetic, so on configurations
-where both use the RMSNorm prologue (hidden <= 1024: every tiny preset, the 0.6B talker, every code predictor) the two
-paths must agree bit for bit -- logits under teacher forcing, sampled codes and PCM. Any stale cross-workgroup read
-(the coherence protocol of the persistent kernel) would show up here as a mismatch."""
+"""Scheduling switches that only regroup work must leave results bit-identical: projected embedding tables vs run-time
+projection, a replica filled through the weight arena, rows per launch / row split / gate-up pairing."""
 import numpy as np
 import pytest
 
@@ -14,57 +12,6 @@ def _req(max_tokens=2048, **kw):
     from qwen3tts import GenerationRequest
     r = tiny_request(**kw)
     return GenerationRequest(r["text_ids"], r["target_token_count"], r["instruct_ids"], r["speaker"], r["language"], max_tokens)
-
-
-@pytest.fixture(scope="module")
-def pairs(ckpt_dirs):
-    from qwen3tts import Qwen3TTSModel
-    out = {}
-    for name, d in ckpt_dirs.items():
-        a = Qwen3TTSModel.from_pretrained(d, max_batch=6, max_frames=64, max_prompt=96, persistent=0)
-        b = Qwen3TTSModel.from_pretrained(d, max_batch=6, max_frames=64, max_prompt=96, persistent=1)
-        out[name] = (a, b)
-    yield out
-    for a, b in out.values():
-        a.close()
-        b.close()
-
-
-@pytest.mark.parametrize("name", ["tiny-a", "tiny-b"])
-def test_forced_logits_identical(pairs, name):
-    a, b = pairs[name]
-    rng = np.random.default_rng(3)
-    reqs = [_req(row=0, n_text=12), _req(row=1, n_text=7), _req(row=2, n_text=19, speaker="vivian")]
-    forced = np.concatenate([rng.integers(0, 2048, size=(3, 6, 1)), rng.integers(0, 256, size=(3, 6, 15))], -1).astype(np.int32)
-    ta, ca, sa = a.debug_generate_forced(reqs, forced, temperature=0.0)
-    tb, cb, sb = b.debug_generate_forced(reqs, forced, temperature=0.0)
-    assert (ta == tb).all() and (ca == cb).all() and (sa == sb).all()
-
-
-@pytest.mark.parametrize("name", ["tiny-a", "tiny-b"])
-@pytest.mark.parametrize("nreq", [1, 5])
-def test_sampled_generation_identical(pairs, name, nreq):
-    a, b = pairs[name]
-    reqs = [_req(row=i, n_text=6 + 3 * i) for i in range(nreq)]
-    kw = dict(temperature=0.9, top_k=40, top_p=0.95, repetition_penalty=1.05, seed=17, force_frames=40)
-    ra, rb = a.generate_batch(reqs, **kw), b.generate_batch(reqs, **kw)  # hipGraph replay of the frame step on both
-    for x, y in zip(ra, rb):
-        assert (x.codes == y.codes).all()
-        assert x.audio.shape == y.audio.shape and (x.audio == y.audio).all()
-    again = b.generate_batch(reqs, **kw)
-    for x, y in zip(rb, again):
-        assert (x.codes == y.codes).all()
-
-
-def test_variable_length_and_events(pairs):
-    a, b = pairs["tiny-b"]
-    reqs = [_req(max_tokens=48, row=i, n_text=5 + i) for i in range(3)]
-    ev_a, ev_b = [], []
-    ra = a.generate_batch(reqs, temperature=0.9, seed=5, on_event=lambda i, k, p: ev_a.append((i, k)))
-    rb = b.generate_batch(reqs, temperature=0.9, seed=5, on_event=lambda i, k, p: ev_b.append((i, k)))
-    for x, y in zip(ra, rb):
-        assert x.status == y.status and (x.codes == y.codes).all()
-    assert sorted(ev_a) == sorted(ev_b)
 
 
 def test_projected_embedding_tables_change_nothing(ckpt_dirs, monkeypatch):
