@@ -74,13 +74,37 @@ def build_requests(preset: str, lo: int, hi: int, n_text: int, n_instruct: int, 
     return reqs
 
 
+def _tensor_files(d: str):
+    out = {}
+    for root, _, files in os.walk(d):
+        for f in files:
+            if f.endswith(".safetensors") or f.endswith(".json"):
+                p = os.path.join(root, f)
+                out[os.path.relpath(p, d)] = os.path.getsize(p)
+    return out
+
+
 def ensure_checkpoint(preset: str, rank: int, dist) -> str:
+    """Synthetic checkpoint directory shared by bench.py and tests/test_full_size.py. The `.complete` marker is written
+    last and lists every file with its size; a directory whose files do not match it (a writer that died half way, or
+    two writers) is rebuilt instead of being trusted."""
     from qwen3tts import synth
     d = os.environ.get("Q3TTS_BENCH_CKPT", f"/tmp/q3tts_synth_{preset}_seed1234")
     marker = os.path.join(d, ".complete")
-    if rank == 0 and not os.path.exists(marker):
-        synth.write_checkpoint(d, preset, seed=1234)
-        open(marker, "w").write("ok")
+    if rank == 0:
+        ok = False
+        if os.path.exists(marker):
+            try:
+                ok = json.load(open(marker)) == _tensor_files(d)
+            except ValueError:
+                ok = False
+        if not ok:
+            if os.path.exists(marker):
+                os.remove(marker)
+            synth.write_checkpoint(d, preset, seed=1234)
+            tmp = marker + f".tmp{os.getpid()}"
+            json.dump(_tensor_files(d), open(tmp, "w"))
+            os.replace(tmp, marker)
     if dist is not None:
         dist.barrier()
     return d

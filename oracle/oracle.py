@@ -354,6 +354,9 @@ class Request:
     ref_audio: Optional[np.ndarray] = None      # voice clone: 24 kHz mono float32 (Qwen3.swift:1009-1013)
     ref_text_ids: Optional[List[int]] = None    # tokens of "<|im_start|>assistant\n{refText}<|im_end|>\n" (:448-449)
     max_tokens: int = 2048
+    # tests only: reference codes [16][T] to use instead of encoding ref_audio (the encoder is checked on its own; a
+    # near-tie in its RVQ search may legitimately flip between summation orders and would change the whole prompt)
+    ref_codes_override: Optional[np.ndarray] = None
 
 
 @dataclass
@@ -682,6 +685,59 @@ class OracleModel:
                             C.c_float(self.dc["rms_norm_eps"]), C.c_int(x.shape[0]), C.c_int(x.shape[1]), _pf(out))
         return out
 
+    def _dec_transformer_layer(self, x, p, nh, hd):
+        """DecoderTransformerLayer (SpeechTokenizer.swift:567-602): RMSNorm -> MHA without positions or mask (:512-528)
+        -> LayerScale -> + x -> RMSNorm -> SwiGLU -> LayerScale -> + x. x: [F][hidden]."""
+        cw = self.codec
+        F = x.shape[0]
+        xn = self._rms(x, p + ".input_layernorm")
+        q = self._lin(xn, p + ".self_attn.q_proj", False)
+        k = self._lin(xn, p + ".self_attn.k_proj", False)
+        v = self._lin(xn, p + ".self_attn.v_proj", False)
+        ao = np.empty_like(q)
+        lib().o_attention_full_f32(_pf(q), _pf(k), _pf(v), C.c_int(F), C.c_int(nh), C.c_int(hd), _pf(ao))
+        y = self._lin(ao, p + ".self_attn.o_proj", False)
+        x = (x + y * cw[p + ".self_attn_layer_scale.scale"]).astype(np.float32)
+        xn = self._rms(x, p + ".post_attention_layernorm")
+        g = self._lin(xn, p + ".mlp.gate_proj", False)
+        u = self._lin(xn, p + ".mlp.up_proj", False)
+        a = np.empty_like(g)
+        lib().o_silu_mul_f32(_pf(g), _pf(u), C.c_int64(g.size), _pf(a))
+        y = self._lin(a, p + ".mlp.down_proj", False)
+        return (x + y * cw[p + ".mlp_layer_scale.scale"]).astype(np.float32)
+
+    def _convnext(self, h, p):
+        """ConvNeXtBlock (SpeechTokenizer.swift:359-402): depthwise causal k7 -> LayerNorm(1e-6) -> Linear C->4C ->
+        GELU(erf) -> Linear 4C->C -> * gamma -> + residual. h: [T][C] channels-last."""
+        cw = self.codec
+        res = h
+        d = self._conv(h, p + ".dwconv.conv", 7, groups=h.shape[1])
+        n = np.empty_like(d)
+        lib().o_layernorm_f32(_pf(d), _pf(cw[p + ".norm.weight"]), _pf(cw[p + ".norm.bias"]),
+                              C.c_float(1e-6), C.c_int(d.shape[0]), C.c_int(d.shape[1]), _pf(n))
+        a = self._lin(n, p + ".pwconv1", True)
+        ga = np.empty_like(a)
+        lib().o_gelu_f32(_pf(a), C.c_int64(a.size), _pf(ga))
+        b2 = self._lin(ga, p + ".pwconv2", True)
+        return (res + cw[p + ".gamma"] * b2).astype(np.float32)
+
+    def _resunit(self, h, rp, dil):
+        """DecoderResidualUnit (SpeechTokenizer.swift:408-438): snake -> conv k7 dilated -> snake -> conv k1 -> + x."""
+        y = self._snake(h, rp + ".act1")
+        y = self._conv(y, rp + ".conv1.conv", 7, dil=dil)
+        y = self._snake(y, rp + ".act2")
+        y = self._conv(y, rp + ".conv2.conv", 1)
+        return (h + y).astype(np.float32)
+
+    def _decoder_block(self, h, p, rate):
+        """DecoderBlock (SpeechTokenizer.swift:444-481): snake -> transposed conv k=2r, stride r (right trim) -> three
+        residual units with dilations 1, 3, 9."""
+        h = self._snake(h, p + ".snake")
+        h = self._convtr(h, p + ".upsample.conv", 2 * rate, rate)
+        for j, dil in ((1, 1), (2, 3), (3, 9)):
+            h = self._resunit(h, f"{p}.res{j}", dil)
+        return h
+
     def codec_decode(self, codes: np.ndarray, stages: Optional[dict] = None):
         """Qwen3TTSSpeechTokenizer.decode for one utterance (SpeechTokenizer.swift:823-836 ->
         754-784). codes [F][16] int. Returns (pcm float32 [1920*F], valid_len). Intermediate
@@ -715,56 +771,21 @@ class OracleModel:
         pt = "decoder.pre_transformer"
         x = self._lin(h, pt + ".input_proj", True)
         for l in range(dc["num_hidden_layers"]):
-            p = f"{pt}.layers.{l}"
-            xn = self._rms(x, p + ".input_layernorm")
-            q = self._lin(xn, p + ".self_attn.q_proj", False)
-            k = self._lin(xn, p + ".self_attn.k_proj", False)
-            v = self._lin(xn, p + ".self_attn.v_proj", False)
-            ao = np.empty_like(q)
-            lib().o_attention_full_f32(_pf(q), _pf(k), _pf(v), C.c_int(F), C.c_int(nh), C.c_int(hd), _pf(ao))
-            y = self._lin(ao, p + ".self_attn.o_proj", False)
-            x = (x + y * cw[p + ".self_attn_layer_scale.scale"]).astype(np.float32)
-            xn = self._rms(x, p + ".post_attention_layernorm")
-            g = self._lin(xn, p + ".mlp.gate_proj", False)
-            u = self._lin(xn, p + ".mlp.up_proj", False)
-            a = np.empty_like(g)
-            lib().o_silu_mul_f32(_pf(g), _pf(u), C.c_int64(g.size), _pf(a))
-            y = self._lin(a, p + ".mlp.down_proj", False)
-            x = (x + y * cw[p + ".mlp_layer_scale.scale"]).astype(np.float32)
+            x = self._dec_transformer_layer(x, f"{pt}.layers.{l}", nh, hd)
         x = self._rms(x, pt + ".norm")
         h = self._lin(x, pt + ".output_proj", True)
         if stages is not None:
             stages["pre_transformer"] = h
         for i, r in enumerate(dc["upsampling_ratios"]):  # :767-775
             h = self._convtr(h, f"decoder.upsample.{i}.0.conv", r, r)
-            p = f"decoder.upsample.{i}.1"
-            res = h
-            d = self._conv(h, p + ".dwconv.conv", 7, groups=h.shape[1])
-            n = np.empty_like(d)
-            lib().o_layernorm_f32(_pf(d), _pf(cw[p + ".norm.weight"]), _pf(cw[p + ".norm.bias"]),
-                                  C.c_float(1e-6), C.c_int(d.shape[0]), C.c_int(d.shape[1]), _pf(n))
-            a = self._lin(n, p + ".pwconv1", True)
-            ga = np.empty_like(a)
-            lib().o_gelu_f32(_pf(a), C.c_int64(a.size), _pf(ga))
-            b2 = self._lin(ga, p + ".pwconv2", True)
-            h = (res + cw[p + ".gamma"] * b2).astype(np.float32)
+            h = self._convnext(h, f"decoder.upsample.{i}.1")
             if stages is not None:
                 stages[f"upsample{i}"] = h
         h = self._conv(h, "decoder.decoder.initConv.conv", 7)  # MainDecoder :681-690
         if stages is not None:
             stages["init_conv"] = h
         for b, rate in enumerate(dc["upsample_rates"]):
-            p = f"decoder.decoder.block{b}"
-            h = self._snake(h, p + ".snake")
-            h = self._convtr(h, p + ".upsample.conv", 2 * rate, rate)
-            for j, dil in ((1, 1), (2, 3), (3, 9)):
-                rp = f"{p}.res{j}"
-                r0 = h
-                y = self._snake(h, rp + ".act1")
-                y = self._conv(y, rp + ".conv1.conv", 7, dil=dil)
-                y = self._snake(y, rp + ".act2")
-                y = self._conv(y, rp + ".conv2.conv", 1)
-                h = (r0 + y).astype(np.float32)
+            h = self._decoder_block(h, f"decoder.decoder.block{b}", rate)
             if stages is not None:
                 stages[f"block{b}"] = h
         h = self._snake(h, "decoder.decoder.outSnake")
@@ -1052,7 +1073,7 @@ class OracleModel:
         if not self.has_encoder:
             raise RuntimeError("Model not initialized: Speech tokenizer encoder not available")
         audio = np.asarray(req.ref_audio, np.float32).reshape(-1)
-        ref_codes = self.codec_encode(audio)  # :443
+        ref_codes = self.codec_encode(audio) if req.ref_codes_override is None else np.asarray(req.ref_codes_override)  # :443
         ref_ids, target_ids = list(req.ref_text_ids), list(req.text_ids)
         ref_text_ids = ref_ids[3: len(ref_ids) - 2]  # :451
         text_ids = target_ids[3: len(target_ids) - 5]  # :457

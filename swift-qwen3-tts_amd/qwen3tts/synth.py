@@ -303,9 +303,14 @@ def talker_tensors(cfg: dict, g: _Gen, std: float = 0.02) -> Dict[str, Tuple[str
     return out
 
 
-def codec_tensors(dc: dict, g: _Gen, std: float = 0.02) -> Dict[str, Tuple[str, np.ndarray]]:
+FULL_WIDTH_OUT_WSTD = 0.0012
+
+
+def codec_tensors(dc: dict, g: _Gen, std: float = 0.02, out_wstd: float | None = None) -> Dict[str, Tuple[str, np.ndarray]]:
     """speech_tokenizer tensors with the upstream key names / PyTorch layouts that
-    sanitizeSpeechTokenizerWeights (Qwen3.swift:1498-1750) expects as input."""
+    sanitizeSpeechTokenizerWeights (Qwen3.swift:1498-1750) expects as input. `out_wstd`: std of the tail conv's weights;
+    at the real layer widths 0.0012 keeps the waveform inside (-1, 1) (the real checkpoint: block3 rms 8.3 -> audio std
+    0.17, Tests/Qwen3TTSTests/Qwen3TTSTests.swift:231, :271) so that the final clip does not hide errors."""
     out: Dict[str, Tuple[str, np.ndarray]] = {}
     cd, latent, dd = dc["codebook_dim"], dc["latent_dim"], dc["decoder_dim"]
     inner = cd // 2
@@ -384,7 +389,7 @@ def codec_tensors(dc: dict, g: _Gen, std: float = 0.02) -> Dict[str, Tuple[str, 
             snake(f"{p}.{j}.act2", c)
             conv(f"{p}.{j}.conv2.conv", c, c, 1, wstd=0.05)
     snake("decoder.decoder.5", c)
-    conv("decoder.decoder.6.conv", 1, c, 7, wstd=0.05)
+    conv("decoder.decoder.6.conv", 1, c, 7, wstd=0.05 if out_wstd is None else out_wstd)
     return out
 
 
@@ -495,7 +500,7 @@ def write_checkpoint(model_dir: str, name: str = "tiny-a", seed: int = 1234,
     with open(os.path.join(model_dir, "speech_tokenizer", "config.json"), "w") as f:
         json.dump(p["speech_tokenizer"], f, indent=1)
     main = talker_tensors(p["config"], g)
-    codec = codec_tensors(p["speech_tokenizer"]["decoder_config"], g)
+    codec = codec_tensors(p["speech_tokenizer"]["decoder_config"], g, out_wstd=FULL_WIDTH_OUT_WSTD if big else None)
     if p["config"].get("speaker_encoder_config"):
         main.update(speaker_encoder_tensors(p["config"]["speaker_encoder_config"], g))
     if p["speech_tokenizer"].get("encoder_config"):

@@ -1,0 +1,254 @@
+"""Independent cross-checks of the oracle's COMPOSITIONS against Hugging Face reference implementations of the same
+blocks: `transformers.models.qwen3_omni_moe` holds the upstream Code2Wav decoder blocks the
+reference's codec decoder was ported from (SnakeBeta, causal conv, residual unit, ConvNeXt block, decoder block), and
+`transformers.models.mimi` is the upstream of the codec ENCODER (SEANet + causal transformer + stride-2 downsample +
+split RVQ): the synthetic checkpoints use Mimi's own key names, so its weights load into `MimiModel` by name, which also
+checks the sanitiser's index -> name mapping (Qwen3.swift:1517-1528) against the real module tree.
+
+Divergences respected (reference behaviour on the left, restated by the oracle):
+  * transposed convs are trimmed on the right only (SpeechTokenizer.swift:346-351); HF trims K - s on both sides, so
+    HF's output is the oracle's minus its first K - s samples;
+  * the encoder MLP uses the tanh GELU approximation (SpeechTokenizerEncoder.swift:1080-1082): HF configured with
+    hidden_act = gelu_pytorch_tanh;
+  * the stride-2 downsample conv zero-pads (`padMode: "edge"` is stored but never read, :184, :697): HF's replicate
+    padding is switched to constant for the comparison;
+  * no 250-frame sliding window in the encoder transformer (:1039-1043): clips stay below 250 frames.
+CPU only; nothing here runs on the GPU box's product path."""
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def base(tmp_path_factory):
+    from oracle import oracle as O
+    from qwen3tts import synth
+    d = str(tmp_path_factory.mktemp("tiny_base_hf"))
+    synth.write_checkpoint(d, "tiny-base", seed=2024)
+    return d, O.OracleModel(d)
+
+
+def t2n(x):
+    return x.detach().cpu().numpy().astype(np.float32)
+
+
+def close(a, b, tol):
+    return float(np.abs(a - b).max()) <= tol * max(1.0, float(np.abs(b).max()))
+
+
+def _torch_conv_weight(w_mlx):  # oracle / MLX [O][K][I/g] -> torch [O][I/g][K]
+    return torch.from_numpy(np.ascontiguousarray(np.transpose(w_mlx, (0, 2, 1))))
+
+
+def _load_causal_conv(mod, cw, prefix):
+    mod.conv.weight.data = _torch_conv_weight(cw[prefix + ".weight"])
+    mod.conv.bias.data = torch.from_numpy(cw[prefix + ".bias"].copy())
+
+
+def _load_snake(mod, cw, prefix):
+    mod.alpha.data = torch.from_numpy(cw[prefix + ".alpha"].copy())
+    mod.beta.data = torch.from_numpy(cw[prefix + ".beta"].copy())
+
+
+# ---------------------------------------------------------------------------------------------------------
+# codec decoder blocks vs transformers.models.qwen3_omni_moe (C3, C6, C7)
+# ---------------------------------------------------------------------------------------------------------
+def test_convnext_block_matches_hf(base):
+    from transformers.models.qwen3_omni_moe import modeling_qwen3_omni_moe as M
+    _, om = base
+    cw = om.codec
+    p = "decoder.upsample.0.1"
+    C_ = cw[p + ".gamma"].shape[0]
+    blk = M.Qwen3OmniMoeConvNeXtBlock(C_).eval()
+    _load_causal_conv(blk.dwconv, cw, p + ".dwconv.conv")
+    for nm in ("norm", "pwconv1", "pwconv2"):
+        getattr(blk, nm).weight.data = torch.from_numpy(cw[f"{p}.{nm}.weight"].copy())
+        getattr(blk, nm).bias.data = torch.from_numpy(cw[f"{p}.{nm}.bias"].copy())
+    blk.gamma.data = torch.from_numpy(cw[p + ".gamma"].copy())
+    x = np.random.default_rng(1).standard_normal((23, C_)).astype(np.float32)
+    with torch.no_grad():
+        want = t2n(blk(torch.from_numpy(x.T[None]))[0].T)
+    got = om._convnext(x, p)
+    assert got.shape == want.shape and close(got, want, 2e-6), float(np.abs(got - want).max())
+
+
+@pytest.mark.parametrize("j,dil", [(1, 1), (2, 3), (3, 9)])
+def test_residual_unit_matches_hf(base, j, dil):
+    from transformers.models.qwen3_omni_moe import modeling_qwen3_omni_moe as M
+    _, om = base
+    cw = om.codec
+    rp = f"decoder.decoder.block1.res{j}"
+    C_ = cw[rp + ".act1.alpha"].shape[0]
+    unit = M.Qwen3OmniMoeCode2WavDecoderResidualUnit(C_, dil).eval()
+    _load_snake(unit.act1, cw, rp + ".act1")
+    _load_snake(unit.act2, cw, rp + ".act2")
+    _load_causal_conv(unit.conv1, cw, rp + ".conv1.conv")
+    _load_causal_conv(unit.conv2, cw, rp + ".conv2.conv")
+    x = np.random.default_rng(j).standard_normal((61, C_)).astype(np.float32)
+    with torch.no_grad():
+        want = t2n(unit(torch.from_numpy(x.T[None]))[0].T)
+    got = om._resunit(x, rp, dil)
+    assert close(got, want, 2e-6), float(np.abs(got - want).max())
+
+
+def test_decoder_block_matches_hf_behind_the_trim_offset(base):
+    """Whole DecoderBlock. HF's transposed conv drops K - s samples on BOTH sides, the reference on the right only, so
+    HF's block output equals the oracle's shifted by K - s once the causal receptive field of the three residual units
+    (6 * (1 + 3 + 9) = 78 samples) no longer reaches the dropped samples."""
+    from transformers.models.qwen3_omni_moe import modeling_qwen3_omni_moe as M
+    _, om = base
+    cw, dc = om.codec, om.dc
+    b = 1
+    rate = dc["upsample_rates"][b]
+    p = f"decoder.decoder.block{b}"
+    cin, cout = cw[p + ".snake.alpha"].shape[0], cw[p + ".res1.act1.alpha"].shape[0]
+    sn = M.Qwen3OmniMoeSnakeBeta(cin).eval()
+    _load_snake(sn, cw, p + ".snake")
+    tc = M.Qwen3OmniMoeCausalTransConvNet(cin, cout, 2 * rate, rate).eval()
+    w = cw[p + ".upsample.conv.weight"]  # oracle / MLX ConvTransposed1d [O][K][I] -> torch [I][O][K]
+    tc.conv.weight.data = torch.from_numpy(np.ascontiguousarray(np.transpose(w, (2, 0, 1))))
+    tc.conv.bias.data = torch.from_numpy(cw[p + ".upsample.conv.bias"].copy())
+    units = []
+    for j, dil in ((1, 1), (2, 3), (3, 9)):
+        u = M.Qwen3OmniMoeCode2WavDecoderResidualUnit(cout, dil).eval()
+        rp = f"{p}.res{j}"
+        _load_snake(u.act1, cw, rp + ".act1")
+        _load_snake(u.act2, cw, rp + ".act2")
+        _load_causal_conv(u.conv1, cw, rp + ".conv1.conv")
+        _load_causal_conv(u.conv2, cw, rp + ".conv2.conv")
+        units.append(u)
+    T = 40
+    x = np.random.default_rng(5).standard_normal((T, cin)).astype(np.float32)
+    with torch.no_grad():
+        h = tc(sn(torch.from_numpy(x.T[None])))
+        up_hf = t2n(h[0].T)
+        for u in units:
+            h = u(h)
+        want = t2n(h[0].T)
+    off = 2 * rate - rate  # K - s
+    got_up = om._convtr(om._snake(x, p + ".snake"), p + ".upsample.conv", 2 * rate, rate)
+    assert got_up.shape[0] == T * rate and up_hf.shape[0] == T * rate - off
+    assert close(got_up[off:], up_hf, 2e-6)  # the transposed conv alone: exact relation
+    got = om._decoder_block(x, p, rate)
+    rf = 6 * (1 + 3 + 9)
+    assert close(got[off + rf:], want[rf:], 5e-6), float(np.abs(got[off + rf:] - want[rf:]).max())
+
+
+def test_decoder_transformer_layer_matches_hf_without_positions(base):
+    """DecoderTransformerLayer (C5). The reference applies neither RoPE nor a mask (SpeechTokenizer.swift:512-528, 763)
+    although upstream does: HF's layer is driven with cos = 1, sin = 0 and no mask, which removes exactly those two."""
+    from transformers.models.qwen3_omni_moe import modeling_qwen3_omni_moe as M
+    from transformers.models.qwen3_omni_moe.configuration_qwen3_omni_moe import Qwen3OmniMoeCode2WavConfig
+    _, om = base
+    cw, dc = om.codec, om.dc
+    p = "decoder.pre_transformer.layers.1"
+    nh, hd = dc["num_attention_heads"], dc["head_dim"]
+    hidden, inter = cw[p + ".self_attn.q_proj.weight"].shape[1], cw[p + ".mlp.gate_proj.weight"].shape[0]
+    cfg = Qwen3OmniMoeCode2WavConfig(hidden_size=hidden, intermediate_size=inter, num_attention_heads=nh,
+                                     num_key_value_heads=nh, head_dim=hd, rms_norm_eps=dc["rms_norm_eps"],
+                                     num_hidden_layers=2, sliding_window=10000, attention_bias=False, hidden_act="silu")
+    cfg._attn_implementation = "eager"
+    layer = M.Qwen3OmniMoeCode2WavTransformerLayer(cfg, 0).eval()
+    sd = {k[len(p) + 1:]: torch.from_numpy(v.copy()) for k, v in cw.items() if k.startswith(p + ".")}
+    res = layer.load_state_dict(sd, strict=True)
+    F = 19
+    x = np.random.default_rng(11).standard_normal((F, hidden)).astype(np.float32)
+    cos, sin = torch.ones(1, F, hd), torch.zeros(1, F, hd)
+    with torch.no_grad():
+        want = t2n(layer(torch.from_numpy(x[None]), attention_mask=None, position_embeddings=(cos, sin))[0])
+    got = om._dec_transformer_layer(x, p, nh, hd)
+    assert close(got, want, 3e-6), float(np.abs(got - want).max())
+
+
+# ---------------------------------------------------------------------------------------------------------
+# codec encoder vs transformers.models.mimi (V1)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def mimi(base):
+    from safetensors.numpy import load_file
+    from transformers.models.mimi import modeling_mimi as MM
+    from transformers.models.mimi.configuration_mimi import MimiConfig
+    d, om = base
+    ec = om.ec
+    cfg = MimiConfig(sampling_rate=ec["sampling_rate"], audio_channels=ec["audio_channels"], hidden_size=ec["hidden_size"],
+                     num_filters=ec["num_filters"], num_residual_layers=ec["num_residual_layers"],
+                     upsampling_ratios=list(ec["upsampling_ratios"]), kernel_size=ec["kernel_size"],
+                     last_kernel_size=ec["last_kernel_size"], residual_kernel_size=ec["residual_kernel_size"],
+                     dilation_growth_rate=ec["dilation_growth_rate"], use_causal_conv=True, pad_mode="constant",
+                     compress=ec["compress"], codebook_size=ec["codebook_size"], codebook_dim=ec["codebook_dim"],
+                     num_quantizers=ec["num_quantizers"], use_conv_shortcut=False,
+                     vector_quantization_hidden_dimension=ec["codebook_dim"], num_semantic_quantizers=1,
+                     upsample_groups=ec["hidden_size"], num_hidden_layers=ec["num_hidden_layers"],
+                     intermediate_size=ec["intermediate_size"], num_attention_heads=ec["num_attention_heads"],
+                     num_key_value_heads=ec["num_key_value_heads"], head_dim=ec["hidden_size"] // ec["num_attention_heads"],
+                     hidden_act="gelu_pytorch_tanh", norm_eps=1e-5, sliding_window=ec["sliding_window"],
+                     layer_scale_initial_scale=ec["layer_scale_initial_scale"],
+                     rope_parameters={"rope_type": "default", "rope_theta": ec["rope_theta"]})
+    cfg._attn_implementation = "eager"
+    model = MM.MimiModel(cfg).eval()
+    raw = load_file(os.path.join(d, "speech_tokenizer", "model.safetensors"))
+    sd = {k[len("encoder."):]: torch.from_numpy(v.copy()) for k, v in raw.items() if k.startswith("encoder.")}
+    res = model.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys  # every encoder tensor of the checkpoint has a home in Mimi
+    enc_missing = [k for k in res.missing_keys
+                   if k.startswith(("encoder.", "encoder_transformer.", "downsample.")) or ("quantizer" in k and "codebook" in k)]
+    assert not enc_missing, enc_missing
+    model.downsample.pad_mode = "constant"  # the reference zero-pads here (module docstring)
+    return model
+
+
+def test_mimi_encoder_stages_match_hf(base, mimi):
+    _, om = base
+    from qwen3tts import synth
+    audio = synth.synthetic_reference_audio(3, 1.3)
+    st = {}
+    codes = om.codec_encode(audio, st)
+    x = torch.from_numpy(audio.reshape(1, 1, -1))
+    with torch.no_grad():
+        e = mimi.encoder(x)
+        assert close(st["seanet"], t2n(e[0].T), 3e-5), float(np.abs(st["seanet"] - t2n(e[0].T)).max())
+        tr = mimi.encoder_transformer(e.transpose(1, 2), return_dict=True).last_hidden_state
+        assert close(st["transformer"], t2n(tr[0]), 5e-5), float(np.abs(st["transformer"] - t2n(tr[0])).max())
+        ds = mimi.downsample(tr.transpose(1, 2))
+        assert close(st["downsample"], t2n(ds[0].T), 5e-5)
+        assert ds.shape[-1] == codes.shape[1] == om.codec_encode(audio).shape[1]
+        # RVQ search on the ORACLE's downsampled frames (so that both sides quantise identical inputs)
+        hf_codes = mimi.quantizer.encode(torch.from_numpy(st["downsample"].T[None].copy()), 32)[:, 0].numpy()
+    assert hf_codes.shape == (32, ds.shape[-1]) and codes.shape == (16, ds.shape[-1])  # the reference keeps 16 (:1055)
+    # layer by layer; a mismatch is only acceptable at a near-tie (HF minimises ||x - e||, the reference ||e||^2/2 - x.e)
+    # and hides the later layers of that frame within its quantiser (semantic: layer 0; acoustic: layers 1..31)
+    alive = np.ones(codes.shape[1], bool)
+    n_diff = 0
+    gaps = st["gaps"]
+    for layer in range(16):
+        if layer == 1:
+            alive[:] = True
+        diff = (hf_codes[layer] != codes[layer]) & alive
+        assert (gaps[layer][diff] < 1e-4).all(), (layer, gaps[layer][diff])
+        n_diff += int(diff.sum())
+        alive &= ~diff
+    assert n_diff <= 2
+
+
+def test_mimi_full_encode_matches_hf(base, mimi):
+    """MimiModel.encode end to end (the whole of V1) against the oracle's codec_encode: first 16 codebooks."""
+    _, om = base
+    from qwen3tts import synth
+    audio = synth.synthetic_reference_audio(1, 0.9)
+    st = {}
+    want = om.codec_encode(audio, st)
+    with torch.no_grad():
+        got = mimi.encode(torch.from_numpy(audio.reshape(1, 1, -1)), num_quantizers=32).audio_codes[0, :16].numpy()
+    assert got.shape == want.shape
+    alive = np.ones(want.shape[1], bool)
+    for layer in range(16):
+        if layer == 1:
+            alive[:] = True
+        diff = (got[layer] != want[layer]) & alive
+        # upstream activations differ at the 1e-5 level between the two implementations: accept flips at small gaps only
+        assert (st["gaps"][layer][diff] < 1e-3).all(), (layer, st["gaps"][layer][diff])
+        alive &= ~diff
+    assert (got == want).mean() > 0.9

@@ -23,7 +23,7 @@ if not os.path.exists(os.path.join(d, ".complete")):
     json.dump(p["speech_tokenizer"], open(os.path.join(d, "speech_tokenizer", "config.json"), "w"))
     synth.save_safetensors(os.path.join(d, "model.safetensors"), synth.talker_tensors(p["config"], g))
     synth.save_safetensors(os.path.join(d, "speech_tokenizer", "model.safetensors"),
-                           synth.codec_tensors(p["speech_tokenizer"]["decoder_config"], g))
+                           synth.codec_tensors(p["speech_tokenizer"]["decoder_config"], g, out_wstd=synth.FULL_WIDTH_OUT_WSTD))
     open(os.path.join(d, ".complete"), "w").write("ok")
 rng = np.random.default_rng(0)
 codes = rng.integers(1, 2048, size=(B, F, 16)).astype(np.int32)
