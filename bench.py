@@ -32,7 +32,20 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "swift-qwen3-tts_amd"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (16x the 157.3 TFLOP/s fp32 matrix rate, MI355X_MICROARCH.md)
 FRAME_SECONDS = 0.08   # 1 codec frame = 1920 samples @ 24 kHz
+
+
+def kernel_sources_sha16() -> str:
+    """Hash of the sources that decide what a frame step launches (kernels + engine): ties a committed PMC measurement to a build."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "swift-qwen3-tts_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(base, "kernels", "*")) + [os.path.join(base, "engine.cc")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def shard_rows(total_rows: int, rank: int, world: int):
@@ -149,6 +162,7 @@ def main():
     ap.add_argument("--greedy", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (profiling)")
     ap.add_argument("--streams", type=int, default=0, help="lanes per GPU (0 = engine default)")
+    ap.add_argument("--no-pipeline", action="store_true", help="one batch at a time (no codec / AR overlap between steps)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -201,9 +215,10 @@ def main():
     reqs = build_requests(args.preset, lo, hi, args.n_text, n_instruct)
     temp = 0.0 if args.greedy else 0.9
 
+    gen_kw = dict(temperature=temp, top_k=50, top_p=1.0, repetition_penalty=rep, seed=1234, force_frames=args.frames)
+
     def step():
-        return model.generate_batch(reqs, temperature=temp, top_k=50, top_p=1.0, repetition_penalty=rep, seed=1234,
-                                    force_frames=args.frames)
+        return model.generate_batch(reqs, **gen_kw)
 
     def sync_all():
         if dist is not None:
@@ -211,17 +226,22 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    solo = None  # phase times of one batch running alone (last warm-up step): nothing overlaps there
     for _ in range(args.warmup):
         step()
+        tm = model.last_timing()
+        solo = {"prefill": tm.prefill_ms, "ar_decode": tm.decode_ms, "codec_decode": tm.codec_ms, "voice_frontend": tm.frontend_ms,
+                "frame_step": tm.decode_ms / max(tm.frame_steps, 1)}
     sync_all()
     t0 = time.perf_counter()
     dec_ms = pre_ms = codec_ms = fe_ms = 0.0
     frame_steps = 0
     kv_bytes = 0
     frames_done = 0
-    for _ in range(args.steps):
-        res = step()  # generate_batch returns after the PCM is on the host (stream-synchronised)
-        tm = model.last_timing()
+
+    def account(res):
+        nonlocal dec_ms, pre_ms, codec_ms, fe_ms, frame_steps, kv_bytes, frames_done
+        tm = model.last_timing()  # timing of the job that just ended
         pre_ms += tm.prefill_ms
         dec_ms += tm.decode_ms
         codec_ms += tm.codec_ms
@@ -229,6 +249,20 @@ def main():
         frame_steps += tm.frame_steps
         kv_bytes += tm.kv_bytes_read
         frames_done += sum(r.codes.shape[0] for r in res)
+
+    # K steps, all of their work inside the timed region. Back-to-back batches are pipelined two deep: step i+1's prompt
+    # assembly, prefill and AR loop are issued while step i's codec decode runs on the engine's second stream; a step's
+    # PCM is on the host when its generate_batch_end returns. --no-pipeline issues the steps strictly one after another.
+    if args.no_pipeline:
+        for _ in range(args.steps):
+            account(step())
+    else:
+        job = model.generate_batch_begin(reqs, **gen_kw)
+        for _ in range(args.steps - 1):
+            nxt = model.generate_batch_begin(reqs, **gen_kw)
+            account(model.generate_batch_end(job))
+            job = nxt
+        account(model.generate_batch_end(job))
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -239,14 +273,27 @@ def main():
             dist.destroy_process_group()
         return
     value = frames_done / elapsed
-    # memory-side bytes per frame step from the PMC passes committed under profiles/ (default workload only)
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01g_frame_traffic.json")
+    # memory-side bytes per frame step from the PMC passes committed under profiles/ (default workload only); the file
+    # names the kernel sources it was measured on, and a figure from other sources is not reported
+    traffic = traffic_src = None
+    tpath = os.path.join(ROOT, "profiles", "frame_traffic.json")
     if args.preset == "1.7b" and B == 32 and os.path.exists(tpath):
-        traffic = json.load(open(tpath))["traffic_bytes_per_frame_step"]
+        tj = json.load(open(tpath))
+        if tj.get("kernel_sources_sha16") == kernel_sources_sha16():
+            traffic = tj["traffic_bytes_per_frame_step"]
+            traffic_src = "profiles/frame_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, Infinity-Cache hits included; " \
+                          "measured on these kernel sources)"
+        else:
+            traffic_src = "profiles/frame_traffic.json is from other kernel sources: not reported"
     step_ms = dec_ms / max(frame_steps, 1)
     algo_bytes = model.info.weight_bytes + kv_bytes / max(frame_steps, 1)
     achieved = algo_bytes / (step_ms * 1e-3) / 1e9
+    pipelined = not args.no_pipeline and args.steps > 1
+    # codec decoder: 2.484 GMAC per frame; every fp32 product block is six bf16 MFMA products
+    n_frames_step = B * args.frames
+    codec_solo_ms = solo["codec_decode"] if solo else codec_ms / args.steps
+    codec_flops_bf16 = 6 * 2 * 2.484e9 * n_frames_step
+    latency_ms = (solo["voice_frontend"] + solo["prefill"] + solo["ar_decode"] + solo["codec_decode"]) if solo else None
     out = {
         "metric": "codec_tokens_per_s", "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -255,17 +302,32 @@ def main():
                                f"{args.n_text} text + {n_instruct} instruct tokens, T={temp} top-k 50, "
                                + ("voice clone: 3.0 s reference clip per row -> codec encoder + speaker encoder + ICL prompt, "
                                   if clone else "")
-                               + "prompt assembly + prefill + hipGraph AR decode + fp32 codec decode -> 24 kHz PCM",
+                               + "prompt assembly + prefill + hipGraph AR decode + fp32-equivalent (bf16x3 split) codec decode -> 24 kHz PCM"
+                               + ("; steps pipelined two deep (a step's codec decode overlaps the next step's AR loop)" if pipelined else ""),
                    "batch_per_gpu": B, "frames_per_utterance": args.frames, "parallelism": f"batch-shard x{world}"},
         "rtf_audio_s_per_wall_s": value * FRAME_SECONDS, "rtf_wall_s_per_audio_s": 1.0 / (value * FRAME_SECONDS),
+        # throughput reading: audio seconds per wall second, per utterance of the batch
         "rtf_per_utterance": value * FRAME_SECONDS / (B * world),
+        # latency reading: one batch running alone, request in -> PCM out (last warm-up step)
+        "utterance_latency_ms": latency_ms,
+        "rtf_per_utterance_latency": (args.frames * FRAME_SECONDS * 1e3 / latency_ms) if latency_ms else None,
         "phase_ms_per_step": {"voice_frontend": fe_ms / args.steps, "prefill": pre_ms / args.steps,
-                              "ar_decode": dec_ms / args.steps, "codec_decode": codec_ms / args.steps},
+                              "ar_decode": dec_ms / args.steps, "codec_decode": codec_ms / args.steps,
+                              "note": ("HIP events per phase on the phase's own stream; codec_decode of step i runs beside "
+                                       "prefill / ar_decode of step i+1, so the phases add up to more than ms_per_step")
+                              if pipelined else "phases run back to back on one batch"},
+        "phase_ms_alone": solo,
         "roofline": {"bound": "hbm", "kernel": "frame_step (hipGraph: talker step + 16 code-predictor passes + samplers)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_source": "profiles/r01g_frame_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, "
-                     "Infinity-Cache hits included)" if traffic else None,
-                     "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": step_ms},
+                     "traffic": traffic, "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": step_ms,
+                     "avg_launch_ms_alone": solo["frame_step"] if solo else None},
+        "roofline_codec": {"bound": "mfma", "kernel": "codec decoder (conv_gemm_split / resunit_split: bf16 MFMA, six products per "
+                           "fp32 product block)", "achieved": codec_flops_bf16 / (codec_solo_ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": codec_flops_bf16 / (codec_solo_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                           "fp32_equivalent_tflops": 2 * 2.484e9 * n_frames_step / (codec_solo_ms * 1e-3) / 1e12,
+                           "algorithmic_gmac_per_frame": 2.484, "frames_per_launch_sequence": n_frames_step,
+                           "ms": codec_solo_ms, "measured": "one batch alone (last warm-up step)" if solo else "overlapped steps"},
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ckpt, args.preset, args.n_text, n_instruct, args.cpu_frames)

@@ -166,6 +166,20 @@ q3tts_status q3tts_generate(q3tts_model* m, const q3tts_request* reqs, int32_t n
                             q3tts_result* results);
 void q3tts_result_free(q3tts_result* results, int32_t n);
 
+/* q3tts_generate in two halves, for callers with a queue of batches (the reference has neither batches nor a queue:
+ * its generate() decodes one-shot after the loop, Qwen3.swift:943-959, which is what each job still does).
+ *   begin: prompt assembly, prefill and the AR loop of this batch (TOKEN events fire here); returns once the codes exist
+ *          and their codec decode has been queued on the engine's second HIP stream.
+ *   end:   waits for that decode, fills `results` (n_reqs entries of the begin call), fires INFO and AUDIO events, and
+ *          releases the job.
+ * A second begin may be issued before the first job's end: its AR loop (a latency-bound chain of small launches) then
+ * overlaps the first job's decode (matrix-core work). At most 2 jobs may be outstanding per model handle; results do
+ * not depend on the interleaving (the decode reads job-owned copies of the codes). q3tts_generate == begin + end. */
+typedef struct q3tts_job q3tts_job;
+q3tts_status q3tts_generate_begin(q3tts_model* m, const q3tts_request* reqs, int32_t n_reqs,
+                                  const q3tts_sampling* sampling, q3tts_event_cb cb, void* user, q3tts_job** job);
+q3tts_status q3tts_generate_end(q3tts_model* m, q3tts_job* job, q3tts_result* results);
+
 /* Qwen3TTSSpeechTokenizer.decode (Models/SpeechTokenizer.swift:823-836): codes
  * [batch][max_frames][num_code_groups] -> pcm [batch][max_frames*1920] (caller-allocated),
  * audio_lengths[batch] = count(code0 > 0) * 1920. n_frames[b] <= max_frames are the valid rows. */

@@ -101,15 +101,24 @@ O_API void o_rmsnorm_bf16(const uint16_t* x, const uint16_t* w, float eps, int r
 /* y = x W^T (+ b): MLXNN.Linear (Talker.swift:183-186,413-415,480-481,607;
  * CodePredictor.swift:90-93,152-154,296,305). fp32 accumulate over k in index order, bias added
  * in fp32, one rounding to bf16. W is [N][K] row-major (out, in). */
+/* Test switch: 0 = sum over k in index order (the restatement), 1 = in reverse order. MLX's own accumulation order is
+ * not visible from the Swift, so any fp32 order is an equally valid reading of "fp32 accumulate"; the distance between
+ * the two orders after 28 layers of bf16 roundings is the noise floor the full-size parity tests measure their
+ * tolerance against (tests/test_full_size.py). */
+static int g_sum_order = 0;
+O_API void o_set_sum_order(int mode) { g_sum_order = mode; }
+
 O_API void o_linear_bf16(const uint16_t* x, const uint16_t* W, const uint16_t* bias, int M, int K,
                          int N, uint16_t* out) {
+    const int rev = g_sum_order;
 #pragma omp parallel for schedule(static)
     for (int n = 0; n < N; ++n) {
         const uint16_t* wr = W + (size_t)n * K;
         for (int m = 0; m < M; ++m) {
             const uint16_t* xr = x + (size_t)m * K;
             float acc = 0.f;
-            for (int k = 0; k < K; ++k) acc += bf2f(xr[k]) * bf2f(wr[k]);
+            if (rev) for (int k = K - 1; k >= 0; --k) acc += bf2f(xr[k]) * bf2f(wr[k]);
+            else for (int k = 0; k < K; ++k) acc += bf2f(xr[k]) * bf2f(wr[k]);
             if (bias) acc += bf2f(bias[n]);
             out[(size_t)m * N + n] = f2bf(acc);
         }
@@ -130,7 +139,8 @@ O_API void o_qlinear_bf16(const uint16_t* x, const uint32_t* Wq, const uint16_t*
         for (int m = 0; m < M; ++m) {
             const uint16_t* xr = x + (size_t)m * K;
             float acc = 0.f;
-            for (int k = 0; k < K; ++k) {
+            for (int kk = 0; kk < K; ++kk) {
+                const int k = g_sum_order ? K - 1 - kk : kk;
                 uint32_t q = (wr[k >> 3] >> (4 * (k & 7))) & 0xFu;
                 int g = k / group;
                 float w = rbf((float)q * bf2f(scales[(size_t)n * gpr + g]) +

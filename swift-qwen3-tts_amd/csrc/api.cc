@@ -143,6 +143,38 @@ q3tts_status q3tts_generate(q3tts_model* m, const q3tts_request* reqs, int32_t n
     });
 }
 
+struct q3tts_job {
+    int slot = -1;
+    int n = 0;
+};
+
+q3tts_status q3tts_generate_begin(q3tts_model* m, const q3tts_request* reqs, int32_t n_reqs, const q3tts_sampling* sampling,
+                                  q3tts_event_cb cb, void* user, q3tts_job** job) {
+    return guarded(m, [&] {
+        Q3_CHECK(m && reqs && job, 3, "Invalid input: null argument");
+        *job = nullptr;
+        q3tts_sampling sp;
+        if (sampling) sp = *sampling;
+        else q3tts_default_sampling(&sp);
+        auto j = std::make_unique<q3tts_job>();
+        j->slot = m->eng->begin(reqs, n_reqs, sp, cb, user);
+        j->n = n_reqs;
+        *job = j.release();
+    });
+}
+
+q3tts_status q3tts_generate_end(q3tts_model* m, q3tts_job* job, q3tts_result* results) {
+    return guarded(m, [&] {
+        Q3_CHECK(m && job && results, 3, "Invalid input: null argument");
+        std::unique_ptr<q3tts_job> j(job);  // the job is released whatever happens
+        std::memset(results, 0, sizeof(q3tts_result) * size_t(j->n > 0 ? j->n : 0));
+        m->eng->end(j->slot, results);
+        for (int i = 0; i < j->n; ++i)
+            if (results[i].status == Q3TTS_ERR_GENERATION_FAILED)
+                m->eng->last_error = "Generation failed: No tokens generated";  // Qwen3.swift:940
+    });
+}
+
 void q3tts_result_free(q3tts_result* results, int32_t n) {
     if (!results) return;
     for (int i = 0; i < n; ++i) {

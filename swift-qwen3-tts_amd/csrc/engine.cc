@@ -36,7 +36,29 @@ struct Bump {
 
 Engine::Engine(Model* model, const q3tts_load_opts& opts) : m_(model), opts_(opts) {
     Q3_HIP(hipSetDevice(m_->device));
-    Q3_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
+    {
+        // The AR loop is a chain of short dependent launches (latency), the codec decode a few hundred large ones
+        // (matrix cores): the decode of a finished batch runs on its own, lower-priority stream so that the next
+        // batch's AR loop can overlap it (begin / end). Q3TTS_CODEC_CUS=n confines the codec stream to n CUs
+        // (mask bits interleave over the XCDs), which bounds what it can take away from the AR chain.
+        int least = 0, greatest = 0;
+        Q3_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        Q3_HIP(hipStreamCreateWithPriority(&st_, hipStreamNonBlocking, greatest));
+        int cus = 0;
+        if (const char* e = std::getenv("Q3TTS_CODEC_CUS")) cus = std::atoi(e);
+        if (cus > 0) {
+            hipDeviceProp_t prop{};
+            Q3_HIP(hipGetDeviceProperties(&prop, m_->device));
+            cus = std::min(cus, prop.multiProcessorCount);
+            std::vector<uint32_t> mask(size_t(ceil_div(prop.multiProcessorCount, 32)), 0u);
+            for (int i = 0; i < cus; ++i) mask[size_t(i / 32)] |= 1u << (i % 32);
+            Q3_HIP(hipExtStreamCreateWithCUMask(&st_codec_, uint32_t(mask.size()), mask.data()));
+        } else {
+            Q3_HIP(hipStreamCreateWithPriority(&st_codec_, hipStreamNonBlocking, least));
+        }
+    }
+    for (auto& J : jobs_)
+        for (auto& e : J.ev_codec) Q3_HIP(hipEventCreate(&e));
     for (auto& e : ev_) Q3_HIP(hipEventCreate(&e));
     for (auto& e : burst_ev_) Q3_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : ev_fe_) Q3_HIP(hipEventCreate(&e));
@@ -54,7 +76,7 @@ Engine::Engine(Model* model, const q3tts_load_opts& opts) : m_(model), opts_(opt
     for (auto& kv : m_->cfg.talker.spk_id) speakers.push_back(kv.first);
     std::sort(speakers.begin(), speakers.end());
     alloc_workspace();
-    if (m_->has_codec) codec_ = std::make_unique<CodecRunner>(*m_, st_);
+    if (m_->has_codec) codec_ = std::make_unique<CodecRunner>(*m_, st_codec_);
     if (m_->has_codec_encoder || m_->has_speaker_encoder) fe_ = std::make_unique<VoiceFrontEnd>(*m_, st_);
 }
 
@@ -68,8 +90,14 @@ Engine::~Engine() {
         if (L.done) (void)hipEventDestroy(L.done);
         if (L.st) (void)hipStreamDestroy(L.st);
     }
-    for (void* p : {(void*)ref_audio_dev_, (void*)ref_codes_dev_, (void*)extra_, (void*)spk_f32_, (void*)dec_codes_})
+    for (void* p : {(void*)ref_audio_dev_, (void*)ref_codes_dev_, (void*)extra_, (void*)spk_f32_})
         if (p) (void)hipFree(p);
+    for (auto& J : jobs_) {
+        if (J.dec_codes) (void)hipFree(J.dec_codes);
+        if (J.pcm_host) (void)hipHostFree(J.pcm_host);
+        for (auto& e : J.ev_codec)
+            if (e) (void)hipEventDestroy(e);
+    }
     if (ws_) (void)hipFree(ws_);
     for (void* p : {(void*)forced_dev_, (void*)sampled_dev_, (void*)tl_dump_, (void*)cl_dump_})
         if (p) (void)hipFree(p);
@@ -80,6 +108,7 @@ Engine::~Engine() {
     for (auto& e : ev_fe_)
         if (e) (void)hipEventDestroy(e);
     if (fe_uploaded_) (void)hipEventDestroy(fe_uploaded_);
+    if (st_codec_) (void)hipStreamDestroy(st_codec_);
     if (st_) (void)hipStreamDestroy(st_);
 }
 
@@ -812,11 +841,17 @@ void Engine::debug_prepare_inputs(const q3tts_request& req, uint16_t* input_embe
 // ------------------------------------------------------------------------------------------------
 void Engine::generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3tts_event_cb cb, void* user,
                       q3tts_result* results, const DebugOpts* dbg) {
+    end(begin(reqs, n, sp, cb, user, dbg), results);
+}
+
+int Engine::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3tts_event_cb cb, void* user, const DebugOpts* dbg) {
     const TalkerConfig& t = m_->cfg.talker;
     const int H = t.hidden_size, V = t.vocab_size, Vc = t.cp.vocab_size, groups = t.num_code_groups;
     Q3_HIP(hipSetDevice(m_->device));  // lanes run on their own host threads
     Q3_CHECK(n >= 1 && n <= Bm_, 3, "Invalid input: batch size must be between 1 and max_batch");
     Q3_CHECK(groups == 16, 3, "Invalid input: num_code_groups must be 16");
+    Q3_CHECK(!jobs_[job_seq_ % kJobSlots].busy, 3,
+             "Invalid input: two jobs are already outstanding (q3tts_generate_end must be called first)");
     const double t_start = now_s();
     std::vector<ResolvedRequest> rr;
     for (int i = 0; i < n; ++i) rr.push_back(resolve(reqs[i], sp));
@@ -979,92 +1014,134 @@ void Engine::generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp
         if (dbg->cp_logits) Q3_HIP(hipMemcpy(dbg->cp_logits, cl_dump_, nf * (groups - 1) * Vc * 2, hipMemcpyDeviceToHost));
     }
 
-    // ---- codec decode (Qwen3.swift:943-961) ----
-    std::vector<int> frames((size_t)(n));
-    int Fmax = 0;
+    // ---- hand the codes to the codec decoder (Qwen3.swift:943-961) on its own stream ----
+    const int slot = int(job_seq_ % kJobSlots);
+    Job& J = jobs_[slot];
+    Q3_CHECK(!J.busy, 3, "Invalid input: two jobs are already outstanding (q3tts_generate_end must be called first)");
+    J.n = n;
+    J.up = codec_->upsample();
+    J.frames.assign(size_t(n), 0);
+    J.ref_T.assign(size_t(n), 0);
+    J.target_tokens.assign(size_t(n), 0);
+    J.ref_code0.assign(size_t(n), {});
+    std::vector<int> dframes((size_t)(n), 0);  // frames the decoder sees per row: [reference ++] generated (:1176-1186)
+    int Fdec = 0;
     for (int b = 0; b < n; ++b) {
-        frames[size_t(b)] = h_nframes[size_t(b)];
-        Fmax = std::max(Fmax, frames[size_t(b)]);
+        const int F = h_nframes[size_t(b)];
+        J.frames[size_t(b)] = F;
+        J.ref_T[size_t(b)] = rr[size_t(b)].clone ? rr[size_t(b)].ref_T : 0;
+        J.target_tokens[size_t(b)] = rr[size_t(b)].target_token_count;
+        dframes[size_t(b)] = F > 0 ? F + J.ref_T[size_t(b)] : 0;
+        Fdec = std::max(Fdec, dframes[size_t(b)]);
     }
-    float* pcm_dev = nullptr;
-    const int up = codec_->upsample();
-    std::vector<std::vector<int32_t>> ref_code0((size_t)(n));  // first code row of each reference (valid-length count)
-    if (any_clone && Fmax > 0) {  // decode [reference ++ generated] (Qwen3.swift:1176-1186)
-        std::vector<int> dframes((size_t)(n), 0);
-        int Fdec = 0;
-        for (int b = 0; b < n; ++b) {
-            const int F = frames[size_t(b)];
-            dframes[size_t(b)] = F > 0 ? F + (rr[size_t(b)].clone ? rr[size_t(b)].ref_T : 0) : 0;
-            Fdec = std::max(Fdec, dframes[size_t(b)]);
-        }
+    J.Fdec = Fdec;
+    J.codes_host.resize(size_t(n) * Fcap_ * 16);
+    Q3_HIP(hipMemcpyAsync(J.codes_host.data(), codes_, J.codes_host.size() * 4, hipMemcpyDeviceToHost, st_));
+    if (Fdec > 0) {
+        // The decoder reads a copy owned by the job: the next begin() overwrites codes_ while this decode may still run.
         const size_t need = size_t(n) * Fdec * 16;
-        if (need > dec_codes_cap_) {
-            if (dec_codes_) Q3_HIP(hipFree(dec_codes_));
-            dec_codes_ = nullptr;
-            Q3_HIP(hipMalloc(reinterpret_cast<void**>(&dec_codes_), need * 4));
-            dec_codes_cap_ = need;
+        if (need > J.dec_codes_cap) {
+            if (J.dec_codes) Q3_HIP(hipFree(J.dec_codes));
+            J.dec_codes = nullptr;
+            Q3_HIP(hipMalloc(reinterpret_cast<void**>(&J.dec_codes), need * 4));
+            J.dec_codes_cap = need;
         }
-        for (int b = 0; b < n; ++b) {
-            const auto& r = rr[size_t(b)];
-            if (frames[size_t(b)] == 0) continue;
-            launch_build_decode_codes(r.clone ? ref_codes_dev_ + r.ref_off : nullptr, r.clone ? r.ref_T : 0,
-                                      codes_ + size_t(b) * Fcap_ * 16, frames[size_t(b)], dec_codes_ + size_t(b) * Fdec * 16, st_);
-            if (r.clone) {
-                ref_code0[size_t(b)].resize(size_t(r.ref_T));
-                Q3_HIP(hipMemcpyAsync(ref_code0[size_t(b)].data(), ref_codes_dev_ + r.ref_off, size_t(r.ref_T) * 4,
-                                      hipMemcpyDeviceToHost, st_));
+        if (any_clone) {
+            for (int b = 0; b < n; ++b) {
+                const auto& r = rr[size_t(b)];
+                if (J.frames[size_t(b)] == 0) continue;
+                launch_build_decode_codes(r.clone ? ref_codes_dev_ + r.ref_off : nullptr, r.clone ? r.ref_T : 0,
+                                          codes_ + size_t(b) * Fcap_ * 16, J.frames[size_t(b)], J.dec_codes + size_t(b) * Fdec * 16, st_);
+                if (r.clone) {
+                    J.ref_code0[size_t(b)].resize(size_t(r.ref_T));
+                    Q3_HIP(hipMemcpyAsync(J.ref_code0[size_t(b)].data(), ref_codes_dev_ + r.ref_off, size_t(r.ref_T) * 4,
+                                          hipMemcpyDeviceToHost, st_));
+                }
             }
+        } else {
+            Q3_HIP(hipMemcpy2DAsync(J.dec_codes, size_t(Fdec) * 64, codes_, size_t(Fcap_) * 64, size_t(Fdec) * 64, size_t(n),
+                                    hipMemcpyDeviceToDevice, st_));
         }
-        codec_->decode(dec_codes_, Fdec, dframes, &pcm_dev);
-        Fmax = Fdec;
-    } else if (Fmax > 0) {
-        codec_->decode(codes_, Fcap_, frames, &pcm_dev);
     }
-    Q3_HIP(hipEventRecord(ev_[3], st_));
-    Q3_HIP(hipStreamSynchronize(st_));
+    Q3_HIP(hipStreamSynchronize(st_));  // everything of this call on st_ is done; only the decode is still to come
+    Q3_HIP(hipEventRecord(J.ev_codec[0], st_codec_));
+    J.decoded = false;
+    if (Fdec > 0) {
+        float* pcm_dev = nullptr;
+        codec_->decode(J.dec_codes, Fdec, dframes, &pcm_dev);
+        const size_t floats = size_t(n) * Fdec * J.up;
+        if (floats > J.pcm_host_cap) {
+            if (J.pcm_host) Q3_HIP(hipHostFree(J.pcm_host));
+            J.pcm_host = nullptr;
+            Q3_HIP(hipHostMalloc(reinterpret_cast<void**>(&J.pcm_host), floats * 4, hipHostMallocDefault));
+            J.pcm_host_cap = floats;
+        }
+        Q3_HIP(hipMemcpyAsync(J.pcm_host, pcm_dev, floats * 4, hipMemcpyDeviceToHost, st_codec_));
+        J.decoded = true;
+    }
+    Q3_HIP(hipEventRecord(J.ev_codec[1], st_codec_));
+    J.timing = q3tts_timing{};
     float ms = 0;
     Q3_HIP(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
-    timing.prefill_ms = ms;
+    J.timing.prefill_ms = ms;
     Q3_HIP(hipEventElapsedTime(&ms, ev_[1], ev_[2]));
-    timing.decode_ms = ms;
-    Q3_HIP(hipEventElapsedTime(&ms, ev_[2], ev_[3]));
-    timing.codec_ms = ms;
+    J.timing.decode_ms = ms;
     Q3_HIP(hipEventElapsedTime(&ms, ev_fe_[0], ev_fe_[1]));
-    timing.frontend_ms = ms;
-    timing.frame_steps = launched;
-    timing.rows = n;
+    J.timing.frontend_ms = ms;
+    J.timing.frame_steps = launched;
+    J.timing.rows = n;
     {
         int64_t kvb = 0;
         const int64_t per_tok = int64_t(t.num_hidden_layers) * t.num_key_value_heads * kHeadDim * 2 * 2;
         for (int b = 0; b < n; ++b)
-            for (int f = 0; f < frames[size_t(b)]; ++f) kvb += int64_t(np[size_t(b)] - 1 + f) * per_tok;
-        timing.kv_bytes_read = kvb;
+            for (int f = 0; f < J.frames[size_t(b)]; ++f) kvb += int64_t(np[size_t(b)] - 1 + f) * per_tok;
+        J.timing.kv_bytes_read = kvb;
     }
-    const double total = now_s() - t_start;
+    J.t_start = t_start;
+    J.cb = cb;
+    J.user = user;
+    J.request_base = request_base;
+    J.seq = job_seq_++;
+    J.busy = true;
+    return slot;
+}
+
+void Engine::end(int job, q3tts_result* results) {
+    Q3_CHECK(job >= 0 && job < kJobSlots && jobs_[job].busy, 3, "Invalid input: no such outstanding job");
+    Job& J = jobs_[job];
+    Q3_HIP(hipSetDevice(m_->device));
+    Q3_HIP(hipEventSynchronize(J.ev_codec[1]));
+    J.busy = false;
+    float ms = 0;
+    Q3_HIP(hipEventElapsedTime(&ms, J.ev_codec[0], J.ev_codec[1]));
+    J.timing.codec_ms = ms;  // on the codec stream: includes whatever the next batch's AR loop took away from it
+    timing = J.timing;
+    const int n = J.n, up = J.up, Fdec = J.Fdec;
+    const double total = now_s() - J.t_start;
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     for (int b = 0; b < n; ++b) {
         q3tts_result& r = results[b];
         std::memset(&r, 0, sizeof(r));
-        const int F = frames[size_t(b)];
-        r.info.prompt_token_count = rr[size_t(b)].target_token_count;  // tokens of `text` (Qwen3+Streaming.swift:106)
+        const int F = J.frames[size_t(b)];
+        r.info.prompt_token_count = J.target_tokens[size_t(b)];  // tokens of `text` (Qwen3+Streaming.swift:106)
         r.info.generation_token_count = F;
         r.info.prefill_time = 0;  // hard-coded in the reference (Qwen3+Streaming.swift:112)
         r.info.generate_time = total;
         r.info.tokens_per_second = total > 0 ? double(F) / total : 0;
         r.info.peak_memory_usage = double(total_b - free_b) / 1e9;
-        if (F == 0) {  // Qwen3.swift:939-941
+        if (F == 0 || !J.decoded) {  // Qwen3.swift:939-941
             r.status = Q3TTS_ERR_GENERATION_FAILED;
             continue;
         }
         r.n_frames = F;
         r.codes = static_cast<int32_t*>(std::malloc(size_t(F) * 16 * 4));
-        Q3_HIP(hipMemcpy(r.codes, codes_ + size_t(b) * Fcap_ * 16, size_t(F) * 16 * 4, hipMemcpyDeviceToHost));
+        std::memcpy(r.codes, J.codes_host.data() + size_t(b) * Fcap_ * 16, size_t(F) * 16 * 4);
         // audioLengths = count(code0 > 0) * 1920, trim when 0 < valid < len (SpeechTokenizer.swift:831-833, Qwen3.swift:954-959)
         int valid_tok = 0;
         for (int f = 0; f < F; ++f) valid_tok += r.codes[size_t(f) * 16] > 0 ? 1 : 0;
-        for (int32_t c : ref_code0[size_t(b)]) valid_tok += c > 0 ? 1 : 0;
-        const int ref_T = rr[size_t(b)].clone ? rr[size_t(b)].ref_T : 0, total_f = ref_T + F;
+        for (int32_t c : J.ref_code0[size_t(b)]) valid_tok += c > 0 ? 1 : 0;
+        const int ref_T = J.ref_T[size_t(b)], total_f = ref_T + F;
         int64_t ns = int64_t(total_f) * up;
         const int64_t valid = int64_t(valid_tok) * up;
         if (valid > 0 && valid < ns) ns = valid;
@@ -1076,24 +1153,24 @@ void Engine::generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp
         ns -= cut;
         r.n_samples = ns;
         r.pcm = static_cast<float*>(std::malloc(size_t(ns) * 4));
-        Q3_HIP(hipMemcpy(r.pcm, pcm_dev + size_t(b) * Fmax * up + cut, size_t(ns) * 4, hipMemcpyDeviceToHost));
+        std::memcpy(r.pcm, J.pcm_host + size_t(b) * Fdec * up + cut, size_t(ns) * 4);
         r.status = Q3TTS_OK;
     }
-    if (cb) {
+    if (J.cb) {
         std::unique_lock<std::mutex> lk;
         if (cb_mutex) lk = std::unique_lock<std::mutex>(*cb_mutex);
         for (int b = 0; b < n; ++b) {
             if (results[b].status != Q3TTS_OK) continue;
             q3tts_event ev{};
             ev.kind = Q3TTS_EVENT_INFO;
-            ev.request_index = request_base + b;
+            ev.request_index = J.request_base + b;
             ev.info = &results[b].info;
-            cb(user, &ev);
+            J.cb(J.user, &ev);
             ev.kind = Q3TTS_EVENT_AUDIO;
             ev.info = nullptr;
             ev.pcm = results[b].pcm;
             ev.n_samples = results[b].n_samples;
-            cb(user, &ev);
+            J.cb(J.user, &ev);
         }
     }
 }
@@ -1178,15 +1255,15 @@ void Engine::codec_decode(const int32_t* codes, const int32_t* n_frames, int bat
         Fmax = std::max(Fmax, n_frames[b]);
     }
     float* pcm_dev = nullptr;
-    Q3_HIP(hipEventRecord(ev_[2], st_));
+    Q3_HIP(hipEventRecord(ev_[2], st_codec_));
     try {
         if (Fmax > 0) codec_->decode(dcodes, max_frames, frames, &pcm_dev);
     } catch (...) {
         (void)hipFree(dcodes);
         throw;
     }
-    Q3_HIP(hipEventRecord(ev_[3], st_));
-    Q3_HIP(hipStreamSynchronize(st_));
+    Q3_HIP(hipEventRecord(ev_[3], st_codec_));
+    Q3_HIP(hipStreamSynchronize(st_codec_));
     float ms = 0;
     Q3_HIP(hipEventElapsedTime(&ms, ev_[2], ev_[3]));
     timing.codec_ms = ms;
@@ -1239,6 +1316,38 @@ EngineGroup::EngineGroup(std::unique_ptr<Model> model, const q3tts_load_opts& op
         lanes_.back()->max_inflight_frames = std::max(2, 12000 / 650 / lanes);
     }
     speakers = lanes_[0]->speakers;
+}
+
+int EngineGroup::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3tts_event_cb cb, void* user) {
+    Q3_CHECK(n >= 1 && n <= opts_.max_batch, 3, "Invalid input: batch size must be between 1 and max_batch");
+    if (lanes_.size() == 1) {
+        Engine& e = *lanes_[0];
+        e.row_offset = 0;
+        e.request_base = 0;
+        return e.begin(reqs, n, sp, cb, user, nullptr);
+    }
+    int slot = -1;
+    for (int i = 0; i < Engine::kJobSlots; ++i)
+        if (!parked_[i].busy) slot = i;
+    Q3_CHECK(slot >= 0, 3, "Invalid input: two jobs are already outstanding (q3tts_generate_end must be called first)");
+    parked_[slot].results.assign(size_t(n), q3tts_result{});
+    generate(reqs, n, sp, cb, user, parked_[slot].results.data(), nullptr);
+    parked_[slot].timing = timing;
+    parked_[slot].busy = true;
+    return slot;
+}
+
+void EngineGroup::end(int job, q3tts_result* results) {
+    if (lanes_.size() == 1) {
+        lanes_[0]->end(job, results);
+        timing = lanes_[0]->timing;
+        return;
+    }
+    Q3_CHECK(job >= 0 && job < Engine::kJobSlots && parked_[job].busy, 3, "Invalid input: no such outstanding job");
+    std::copy(parked_[job].results.begin(), parked_[job].results.end(), results);  // buffers change owner
+    timing = parked_[job].timing;
+    parked_[job].results.clear();
+    parked_[job].busy = false;
 }
 
 void EngineGroup::generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3tts_event_cb cb, void* user,

@@ -57,6 +57,13 @@ class Engine {
 
     void generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3tts_event_cb cb, void* user,
                   q3tts_result* results, const DebugOpts* dbg);
+    // generate() in two halves (q3tts_generate_begin / _end): begin returns once the AR loop has finished and the codec
+    // decode of its codes is queued on the codec stream; end waits for the PCM and fills the results. A second begin()
+    // may run between the two: its AR loop (a latency-bound chain that leaves the matrix cores idle) then overlaps the
+    // first job's decode (matrix-core bound). Jobs end in begin order; at most kJobSlots are outstanding.
+    static constexpr int kJobSlots = 2;
+    int begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3tts_event_cb cb, void* user, const DebugOpts* dbg);
+    void end(int job, q3tts_result* results);
     void debug_prepare_inputs(const q3tts_request& req, uint16_t* input_embeds, int cap_prompt, int* n_prompt,
                               uint16_t* trailing, int cap_trailing, int* n_trailing, uint16_t* tts_pad);
     void debug_sample(const uint16_t* logits, int rows, int V, const q3tts_sampling& sp, const uint8_t* seen,
@@ -83,6 +90,7 @@ class Engine {
   private:
     q3tts_load_opts opts_;
     hipStream_t st_ = nullptr;
+    hipStream_t st_codec_ = nullptr;  // codec decode of a finished batch, lower priority than st_
     hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t burst_ev_[2] = {nullptr, nullptr};
     hipEvent_t ev_fe_[2] = {nullptr, nullptr};
@@ -122,6 +130,29 @@ class Engine {
     int32_t *forced_dev_ = nullptr, *sampled_dev_ = nullptr;
     uint16_t *tl_dump_ = nullptr, *cl_dump_ = nullptr;
 
+    // One slot per outstanding job: everything the second half (codec decode -> results) needs after the next begin()
+    // has started to overwrite the engine's per-call state.
+    struct Job {
+        bool busy = false;
+        uint64_t seq = 0;                 // begin order
+        int n = 0, Fdec = 0, up = 0;
+        std::vector<int> frames, ref_T, target_tokens, n_prompt;
+        std::vector<std::vector<int32_t>> ref_code0;  // first code row of each reference (valid-length count)
+        std::vector<int32_t> codes_host;  // [n][Fcap][16]
+        int32_t* dec_codes = nullptr;     // device [n][Fdec][16]: what the decoder reads (reference ++ generated for clone rows)
+        size_t dec_codes_cap = 0;
+        float* pcm_host = nullptr;        // pinned [n][Fdec * up]
+        size_t pcm_host_cap = 0;
+        hipEvent_t ev_codec[2] = {nullptr, nullptr};
+        q3tts_timing timing{};
+        double t_start = 0;
+        q3tts_event_cb cb = nullptr;
+        void* user = nullptr;
+        int request_base = 0;
+        bool decoded = false;
+    } jobs_[kJobSlots];
+    uint64_t job_seq_ = 0;
+
     std::map<int, hipGraphExec_t> graphs_;  // keyed by batch size
     std::unique_ptr<CodecRunner> codec_;
     std::unique_ptr<VoiceFrontEnd> fe_;
@@ -133,8 +164,6 @@ class Engine {
     uint16_t* extra_ = nullptr;  // [rows][H] bf16: speaker x-vectors and reference-frame embedding sums
     size_t extra_cap_ = 0;
     float* spk_f32_ = nullptr;
-    int32_t* dec_codes_ = nullptr;  // [n][Fdec][16]: reference ++ generated codes for the decoder
-    size_t dec_codes_cap_ = 0;
     // Clone rows are independent and their front-end kernels are small: a few of them run side by side, each on its
     // own stream with its own scratch.
     struct FeLane {
@@ -176,11 +205,19 @@ class EngineGroup {
     const q3tts_load_opts& opts() const { return opts_; }
     void generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3tts_event_cb cb, void* user,
                   q3tts_result* results, const DebugOpts* dbg);
+    // Two-deep pipeline (Engine::begin / end). With more than one lane a job runs to completion inside begin.
+    int begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3tts_event_cb cb, void* user);
+    void end(int job, q3tts_result* results);
     std::string last_error;
     q3tts_timing timing{};
     std::vector<std::string> speakers;
 
   private:
+    struct Parked {  // lanes > 1: finished results waiting for end()
+        bool busy = false;
+        std::vector<q3tts_result> results;
+        q3tts_timing timing{};
+    } parked_[Engine::kJobSlots];
     std::unique_ptr<Model> model_;
     q3tts_load_opts opts_;
     std::vector<std::unique_ptr<Engine>> lanes_;

