@@ -257,12 +257,19 @@ def main():
         for _ in range(args.steps):
             account(step())
     else:
-        job = model.generate_batch_begin(reqs, **gen_kw)
+        trace = os.environ.get("Q3TTS_BENCH_TRACE") == "1"  # host wall time of each half, to stderr
+        def timed(what, f, *a, **k):
+            t = time.perf_counter()
+            r = f(*a, **k)
+            if trace:
+                print(f"[trace] {what} {1e3 * (time.perf_counter() - t):.1f} ms", file=sys.stderr)
+            return r
+        job = timed("begin", model.generate_batch_begin, reqs, **gen_kw)
         for _ in range(args.steps - 1):
-            nxt = model.generate_batch_begin(reqs, **gen_kw)
-            account(model.generate_batch_end(job))
+            nxt = timed("begin", model.generate_batch_begin, reqs, **gen_kw)
+            account(timed("end", model.generate_batch_end, job))
             job = nxt
-        account(model.generate_batch_end(job))
+        account(timed("end", model.generate_batch_end, job))
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:

@@ -199,6 +199,12 @@ int32_t q3tts_codec_encoded_frames(const q3tts_model* m, int64_t n_samples);
 q3tts_status q3tts_speaker_embedding(q3tts_model* m, const float* audio, int64_t n_samples, int32_t sample_rate,
                                      float* out, int32_t cap);
 
+/* 16-bit PCM as the reference's CLI writes it (Sources/Qwen3TTSDemo/main.swift:134-165): each sample is clamped to
+ * [-1, 1], multiplied by 32767 in Float and converted with Int16(_:), i.e. truncated toward zero (:158-162).
+ * q3tts_write_wav writes the same 44-byte RIFF/WAVE header (PCM, mono, 16 bit) followed by those samples. Host code. */
+void q3tts_pcm_to_int16(const float* pcm, int64_t n_samples, int16_t* out);
+q3tts_status q3tts_write_wav(const char* path, const float* pcm, int64_t n_samples, int32_t sample_rate);
+
 /* Text tokeniser: the Qwen2 byte-level BPE that the checkpoints ship as tokenizer.json (or vocab.json + merges.txt),
  * which the reference loads through swift-transformers (`AutoTokenizer.from(modelFolder:)`, Models/Qwen3.swift:1458) and
  * calls at :274-275, :364-365, :448-457, :822. Optional: callers that tokenise themselves never touch it. `path` is a

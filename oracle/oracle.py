@@ -334,6 +334,13 @@ def dequantize_mlx_affine(w: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
 # model
 # ----------------------------------------------------------------------------------------------
 
+def pcm_to_int16(pcm: np.ndarray) -> np.ndarray:
+    """The reference CLI's WAV quantisation (Sources/Qwen3TTSDemo/main.swift:158-162): clamp to [-1, 1], multiply by
+    32767 in Float, Int16(_:) truncates toward zero."""
+    x = np.clip(np.asarray(pcm, np.float32), np.float32(-1.0), np.float32(1.0))
+    return np.trunc((x * np.float32(32767.0)).astype(np.float32)).astype(np.int16)
+
+
 @dataclass
 class Sampling:
     temperature: float = 0.9

@@ -1,6 +1,9 @@
 // api.cc -- extern "C" surface declared in include/q3tts.h. No exception crosses the boundary:
 // every entry point returns a q3tts_status and records the message for q3tts_last_error().
+#include <cmath>
+#include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "engine.h"
 #include "tokenizer.h"
@@ -172,6 +175,37 @@ q3tts_status q3tts_generate_end(q3tts_model* m, q3tts_job* job, q3tts_result* re
         for (int i = 0; i < j->n; ++i)
             if (results[i].status == Q3TTS_ERR_GENERATION_FAILED)
                 m->eng->last_error = "Generation failed: No tokens generated";  // Qwen3.swift:940
+    });
+}
+
+void q3tts_pcm_to_int16(const float* pcm, int64_t n_samples, int16_t* out) {
+    for (int64_t i = 0; i < n_samples; ++i) {
+        const float clamped = std::fmax(-1.0f, std::fmin(1.0f, pcm[i]));  // main.swift:159
+        out[i] = static_cast<int16_t>(clamped * 32767.0f);                // Int16(Float): toward zero (:160)
+    }
+}
+
+q3tts_status q3tts_write_wav(const char* path, const float* pcm, int64_t n_samples, int32_t sample_rate) {
+    return guarded(nullptr, [&] {
+        Q3_CHECK(path && (pcm || n_samples == 0) && n_samples >= 0 && sample_rate > 0, 3, "Invalid input: null argument");
+        Q3_CHECK(n_samples <= (int64_t(0xffffffffu) - 36) / 2, 3, "Invalid input: too many samples for a RIFF file");
+        std::vector<uint8_t> d;
+        d.reserve(size_t(44 + n_samples * 2));
+        auto u32 = [&](uint32_t v) { for (int i = 0; i < 4; ++i) d.push_back(uint8_t(v >> (8 * i))); };
+        auto u16 = [&](uint16_t v) { d.push_back(uint8_t(v)); d.push_back(uint8_t(v >> 8)); };
+        auto tag = [&](const char* t) { d.insert(d.end(), t, t + 4); };
+        tag("RIFF"); u32(uint32_t(36 + n_samples * 2)); tag("WAVE");          // main.swift:138-142
+        tag("fmt "); u32(16); u16(1); u16(1); u32(uint32_t(sample_rate));      // :145-149
+        u32(uint32_t(sample_rate) * 2); u16(2); u16(16);                       // :150-152
+        tag("data"); u32(uint32_t(n_samples * 2));                             // :155-156
+        std::vector<int16_t> s16(static_cast<size_t>(n_samples));
+        q3tts_pcm_to_int16(pcm, n_samples, s16.data());
+        for (int16_t v : s16) u16(uint16_t(v));
+        FILE* f = std::fopen(path, "wb");
+        Q3_CHECK(f != nullptr, 3, std::string("Invalid input: cannot open ") + path);
+        const size_t w = std::fwrite(d.data(), 1, d.size(), f);
+        const int rc = std::fclose(f);
+        Q3_CHECK(w == d.size() && rc == 0, 3, std::string("Invalid input: short write to ") + path);
     });
 }
 

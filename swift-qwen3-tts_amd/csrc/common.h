@@ -138,6 +138,19 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 
 using bf16x8 = __attribute__((ext_vector_type(8))) short;  // MFMA bf16 A/B fragment (4 VGPRs)
+// 16-byte global load; NT = non-temporal (`global_load_dwordx4 ... nt`): for bytes that are read once per frame step out
+// of a working set far larger than the 256 MB Infinity Cache (the talker's layer weights, its KV cache). The hint has to
+// be a compile-time property of the load: hipcc merges the two arms of a run-time select into one plain load.
+template <bool NT>
+__device__ __forceinline__ uint4 ld16(const uint4* p) {
+    using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+    if constexpr (NT) {
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+        return make_uint4(v.x, v.y, v.z, v.w);
+    } else {
+        return *p;
+    }
+}
 using f32x4 = __attribute__((ext_vector_type(4))) float;   // 16x16 accumulator fragment
 using f32x16 = __attribute__((ext_vector_type(16))) float; // 32x32 accumulator fragment
 

@@ -247,6 +247,14 @@ void Engine::enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, 
     // since the norm-prologue kernels request x before the weight tiles, take at most two row blocks per workgroup and
     // the 6144-wide gate/up runs as one round of workgroups (gemm_decode.hip); wider stacks keep the row-norm kernel.
     const bool prologue_qkv = H <= 2048, prologue_mlp = H <= 2048;
+    // The talker's layer weights and KV cache are read once per frame step out of gigabytes; the code predictor's
+    // 0.22 GB are read fifteen times per step. Non-temporal loads on the former leave the Infinity Cache (256 MB) to the
+    // latter: measured 3.53 -> 3.42 ms per 1.7B frame step with both (either one alone: < 1 %; on the predictor's
+    // weights as well: 3.62 ms). Q3TTS_NT=0 turns the hint off (diagnostics).
+    static const bool nt_off = std::getenv("Q3TTS_NT") && std::atoi(std::getenv("Q3TTS_NT")) == 0;
+    const bool is_talker = &s == &m_->talker;
+    const int ntw = is_talker && !nt_off ? 1 : 0;
+    const int ntkv = ntw;
     auto norm_into_xn = [&](const uint16_t* nw) {
         NormRowsArgs n{};
         n.h = w.h; n.hMB = MBL; n.w = nw; n.eps = s.eps; n.out = w.xn; n.outMB = MBL; n.M = M; n.H = H;
@@ -256,7 +264,7 @@ void Engine::enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, 
         const LayerW& L = s.layers[l];
         if (!prologue_qkv) norm_into_xn(L.ln1);
         GemmArgs q = gemm_args(L.qkv, prologue_qkv ? w.h : w.xn, M);
-        q.epi = 0; q.y = w.qkv; q.ldy = w.ld_qkv;
+        q.epi = 0; q.y = w.qkv; q.ldy = w.ld_qkv; q.nt_weights = ntw;
         if (prologue_qkv) {
             q.norm_w = L.ln1; q.ss_in = w.ss_a; q.ss_count = (l == 0) ? ss_count_in : tiles; q.norm_dim = H; q.norm_eps = s.eps;
         }
@@ -269,20 +277,21 @@ void Engine::enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, 
         at.fixed_len = fixed_len; at.identity_pages = fixed_len >= 0 ? 1 : 0;
         at.chunk = chunk; at.chunk_n_prompt = chunk_n_prompt; at.chunk_r_base = chunk_r_base;
         at.scale = powf(float(kHeadDim), -0.5f);  // Talker.swift:179
+        at.nt_kv = ntkv;
         launch_gemm_skinny(q, st_);
         launch_attn_decode(at, st_);
         GemmArgs o = gemm_args(L.o, w.ao, M);
-        o.epi = 3; o.y = w.h; o.yMB = MBL; o.resid = 1; o.ss_out = w.ss_b;
+        o.epi = 3; o.y = w.h; o.yMB = MBL; o.resid = 1; o.ss_out = w.ss_b; o.nt_weights = ntw;
         launch_gemm_skinny(o, st_);
         if (!prologue_mlp) norm_into_xn(L.ln2);
         GemmArgs g = gemm_args(L.gateup, prologue_mlp ? w.h : w.xn, M);
-        g.epi = 2; g.y = w.act; g.yMB = MBL;
+        g.epi = 2; g.y = w.act; g.yMB = MBL; g.nt_weights = ntw;
         if (prologue_mlp) {
             g.norm_w = L.ln2; g.ss_in = w.ss_b; g.ss_count = tiles; g.norm_dim = H; g.norm_eps = s.eps;
         }
         launch_gemm_skinny(g, st_);
         GemmArgs d = gemm_args(L.down, w.act, M);
-        d.epi = 3; d.y = w.h; d.yMB = MBL; d.resid = 1; d.ss_out = w.ss_a;
+        d.epi = 3; d.y = w.h; d.yMB = MBL; d.resid = 1; d.ss_out = w.ss_a; d.nt_weights = ntw;
         launch_gemm_skinny(d, st_);
     }
 }

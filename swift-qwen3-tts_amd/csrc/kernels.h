@@ -30,6 +30,7 @@ struct GemmArgs {
     int ss_count, ss_ld, norm_dim;
     float norm_eps;
     // epi 3
+    int nt_weights;          // 1: load the weight tiles non-temporally (read once per step, working set >> Infinity Cache)
     int resid;               // 1: y = bf16(y_old + bf16(acc+bias)); 0: y = bf16(acc+bias)
     float* ss_out;           // [N/16][ss_ld] this tile's share of sum(y^2) per row, or nullptr
 };
@@ -78,6 +79,7 @@ struct AttnArgs {
     int chunk;
     const int32_t* chunk_n_prompt;
     int chunk_r_base;
+    int nt_kv;           // 1: cache rows are loaded non-temporally (long caches read once per step)
 };
 void launch_attn_decode(const AttnArgs& a, hipStream_t st);
 

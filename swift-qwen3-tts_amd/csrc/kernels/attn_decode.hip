@@ -21,9 +21,9 @@ namespace {
 
 #include "attn_body.inc"
 
-template <int REP, int NTH>
+template <int REP, int NTH, bool NTKV = false>
 __global__ __launch_bounds__(NTH) void attn_decode_kernel(AttnArgs a) {
-    attn_decode_body<REP, NTH>(a, blockIdx.x, blockIdx.y);
+    attn_decode_body<REP, NTH, NTKV>(a, blockIdx.x, blockIdx.y);
 }
 
 // Several consecutive positions of every row in one launch (chunked prompt prefill; the code predictor's step 0,
@@ -209,7 +209,8 @@ void launch_attn_decode(const AttnArgs& a, hipStream_t st) {
             else hipLaunchKernelGGL((attn_decode_kernel<1, 256>), grid, dim3(256), 0, st, a);
             break;
         case 2:
-            if (wide) hipLaunchKernelGGL((attn_decode_kernel<2, 512>), grid, dim3(512), 0, st, a);
+            if (wide && a.nt_kv) hipLaunchKernelGGL((attn_decode_kernel<2, 512, true>), grid, dim3(512), 0, st, a);
+            else if (wide) hipLaunchKernelGGL((attn_decode_kernel<2, 512>), grid, dim3(512), 0, st, a);
             else hipLaunchKernelGGL((attn_decode_kernel<2, 256>), grid, dim3(256), 0, st, a);
             break;
         case 3: hipLaunchKernelGGL((attn_decode_kernel<3, 256>), grid, dim3(256), 0, st, a); break;

@@ -37,24 +37,24 @@ namespace {
 
 #include "gemm_body.inc"
 
-template <int MB, int EPI, int NW, int CH, bool NORM, bool QUANT, int NP = 1>
+template <int MB, int EPI, int NW, int CH, bool NORM, bool QUANT, int NP = 1, bool NTW = false>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
-    gemm_skinny_body<MB, EPI, NW, CH, NORM, QUANT, NP>(a, blockIdx.x, blockIdx.y * MB);
+    gemm_skinny_body<MB, EPI, NW, CH, NORM, QUANT, NP, NTW>(a, blockIdx.x, blockIdx.y * MB);
 }
 
-template <int MB, int EPI, bool NORM, bool QUANT>
+template <int MB, int EPI, bool NORM, bool QUANT, bool NTW>
 void launch_mb(const GemmArgs& a, int split, hipStream_t st) {
     const int KC = a.K / 128;
     const int nw = KC <= 4 ? 4 : 8;  // no idle waves on short K
     const int ch = (KC + nw - 1) / nw;
     const int tiles = a.N / 16;
 #define Q3_GEMM(NWv, CHv) \
-    hipLaunchKernelGGL((gemm_skinny_kernel<MB, EPI, NWv, CHv, NORM, QUANT>), dim3(tiles, split), dim3(NWv * 64), 0, st, a)
+    hipLaunchKernelGGL((gemm_skinny_kernel<MB, EPI, NWv, CHv, NORM, QUANT, 1, NTW>), dim3(tiles, split), dim3(NWv * 64), 0, st, a)
     if constexpr (EPI == 2 && !QUANT && MB <= 2) {
         // more than one round of workgroups on 256 CUs, and an even pair count: two pairs per workgroup, one round
         static const bool one_pair = std::getenv("Q3TTS_GEMM_ONE_PAIR") != nullptr;
         if (!one_pair && nw == 8 && ch == 2 && tiles > 256 && tiles <= 512 && tiles % 2 == 0) {
-            hipLaunchKernelGGL((gemm_skinny_kernel<MB, 2, 8, 2, NORM, false, 2>), dim3(tiles / 2, split), dim3(512), 0, st, a);
+            hipLaunchKernelGGL((gemm_skinny_kernel<MB, 2, 8, 2, NORM, false, 2, NTW>), dim3(tiles / 2, split), dim3(512), 0, st, a);
             return;
         }
     }
@@ -93,11 +93,18 @@ void launch_q(const GemmArgs& a, hipStream_t st) {
         while (MBt / split > cap || MBt % split != 0) ++split;
     }
     while (MBt / split > 4 || MBt % split != 0) ++split;
-    switch (MBt / split) {
-        case 1: launch_mb<1, EPI, NORM, QUANT>(a, split, st); break;
-        case 2: launch_mb<2, EPI, NORM, QUANT>(a, split, st); break;
-        case 3: launch_mb<3, EPI, NORM, QUANT>(a, split, st); break;
-        case 4: launch_mb<4, EPI, NORM, QUANT>(a, split, st); break;
+    // non-temporal weight loads: only the one- and two-row-block forms the talker's decode step uses are instantiated
+    const int mbw = MBt / split;
+    if (a.nt_weights && mbw <= 2) {
+        if (mbw == 1) launch_mb<1, EPI, NORM, QUANT, true>(a, split, st);
+        else launch_mb<2, EPI, NORM, QUANT, true>(a, split, st);
+        return;
+    }
+    switch (mbw) {
+        case 1: launch_mb<1, EPI, NORM, QUANT, false>(a, split, st); break;
+        case 2: launch_mb<2, EPI, NORM, QUANT, false>(a, split, st); break;
+        case 3: launch_mb<3, EPI, NORM, QUANT, false>(a, split, st); break;
+        case 4: launch_mb<4, EPI, NORM, QUANT, false>(a, split, st); break;
         default: throw Error(3, "gemm_skinny: more than 4 row blocks per workgroup");
     }
 }

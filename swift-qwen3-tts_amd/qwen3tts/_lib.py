@@ -98,6 +98,9 @@ def lib() -> C.CDLL:
                                  C.POINTER(Result)]
     L.q3tts_generate_begin.argtypes = [vp, C.POINTER(Request), C.c_int32, C.POINTER(Sampling), EVENT_CB, vp, C.POINTER(vp)]
     L.q3tts_generate_end.argtypes = [vp, vp, C.POINTER(Result)]
+    L.q3tts_pcm_to_int16.argtypes = [f32p, C.c_int64, C.POINTER(C.c_int16)]
+    L.q3tts_pcm_to_int16.restype = None
+    L.q3tts_write_wav.argtypes = [C.c_char_p, f32p, C.c_int64, C.c_int32]
     L.q3tts_result_free.argtypes = [C.POINTER(Result), C.c_int32]
     L.q3tts_result_free.restype = None
     L.q3tts_codec_decode.argtypes = [vp, i32p, i32p, C.c_int32, C.c_int32, f32p, C.POINTER(C.c_int64)]

@@ -76,6 +76,7 @@ class Qwen3TTSModel:
         self._check(lib.q3tts_model_get_info(self._h, C.byref(info)))
         self.info = info
         self.tokenizer: Optional[Callable[[str], List[int]]] = None
+        self.last_info: Optional[AudioGenerationInfo] = None  # .info of the last call's first request
 
     # -- loading ---------------------------------------------------------------------------------
     @classmethod
@@ -230,6 +231,7 @@ class Qwen3TTSModel:
                 audio = np.ctypeslib.as_array(r.pcm, shape=(r.n_samples,)).copy()
                 codes = np.ctypeslib.as_array(r.codes, shape=(r.n_frames, 16)).copy()
                 out.append(GenerationResult(audio, codes, info, 0))
+            self.last_info = out[0].info if out else None
             return out
         finally:
             self._lib.q3tts_result_free(res, n)
@@ -254,6 +256,32 @@ class Qwen3TTSModel:
         req = self._request_from_text(text, speaker, instruct, language, max_tokens, text_ids, instruct_ids,
                                       target_token_count)
         r = self.generate_batch([req], temperature, top_k, top_p, repetition_penalty, seed)[0]
+        if r.status != 0:
+            raise Qwen3TTSError(r.status, "Generation failed: No tokens generated")
+        return r.audio
+
+    def generate_voice_design(self, text: Optional[str] = None, language: str = "auto", instruct: Optional[str] = None,
+                              temperature: float = 0.9, top_k: int = 50, top_p: float = 1.0,
+                              repetition_penalty: float = 1.05, max_tokens: int = 2048,
+                              on_token: Optional[Callable[[int], None]] = None, *, seed: int = 0, text_ids=None,
+                              instruct_ids=None, target_token_count=None) -> np.ndarray:
+        """generateVoiceDesign(text:language:instruct:...:onToken:) (Qwen3.swift:587-597); on_token sees every first-codebook
+        id as it is generated (:698)."""
+        req = self._request_from_text(text, None, instruct, language, max_tokens, text_ids, instruct_ids, target_token_count)
+        return self._one(req, temperature, top_k, top_p, repetition_penalty, seed, on_token)
+
+    def generate_custom_voice(self, text: Optional[str] = None, speaker: str = "", language: str = "auto",
+                              instruct: Optional[str] = None, temperature: float = 0.9, top_k: int = 50,
+                              top_p: float = 1.0, repetition_penalty: float = 1.05, max_tokens: int = 2048,
+                              on_token: Optional[Callable[[int], None]] = None, *, seed: int = 0, text_ids=None,
+                              instruct_ids=None, target_token_count=None) -> np.ndarray:
+        """generateCustomVoice(text:speaker:language:instruct:...:onToken:) (Qwen3.swift:783-794)."""
+        req = self._request_from_text(text, speaker, instruct, language, max_tokens, text_ids, instruct_ids, target_token_count)
+        return self._one(req, temperature, top_k, top_p, repetition_penalty, seed, on_token)
+
+    def _one(self, req, temperature, top_k, top_p, repetition_penalty, seed, on_token) -> np.ndarray:
+        cb = (lambda i, k, p: on_token(p) if k == "token" else None) if on_token else None
+        r = self.generate_batch([req], temperature, top_k, top_p, repetition_penalty, seed, on_event=cb)[0]
         if r.status != 0:
             raise Qwen3TTSError(r.status, "Generation failed: No tokens generated")
         return r.audio

@@ -90,6 +90,27 @@ public final class Qwen3TTSModel {
                 topP: topP, repetitionPenalty: repetitionPenalty, maxTokens: maxTokens, seed: seed, onEvent: nil)
     }
 
+    /// generateVoiceDesign(text:language:instruct:...:onToken:) -- Qwen3.swift:587-597. `onToken` receives every first-codebook
+    /// id as it is generated (:698), EOS excluded. (The engine routes by tts_model_type like generate(); a direct call on a
+    /// checkpoint of another type is rejected there instead of running the VoiceDesign prompt.)
+    public func generateVoiceDesign(text: String, language: String = "auto", instruct: String? = nil, temperature: Float = 0.9,
+                                    topK: Int = 50, topP: Float = 1.0, repetitionPenalty: Float = 1.05, maxTokens: Int = 2048,
+                                    seed: UInt64 = 0, onToken: ((Int) -> Void)? = nil) throws -> [Float] {
+        try run(text: text, speaker: nil, instruct: instruct, language: language, temperature: temperature, topK: topK,
+                topP: topP, repetitionPenalty: repetitionPenalty, maxTokens: maxTokens, seed: seed,
+                onEvent: onToken.map { cb in { ev in if case .token(let t) = ev { cb(t) } } })
+    }
+
+    /// generateCustomVoice(text:speaker:language:instruct:...:onToken:) -- Qwen3.swift:783-794; the speaker is validated against
+    /// talker_config.spk_id with the reference's message (:803-811).
+    public func generateCustomVoice(text: String, speaker: String, language: String = "auto", instruct: String? = nil,
+                                    temperature: Float = 0.9, topK: Int = 50, topP: Float = 1.0, repetitionPenalty: Float = 1.05,
+                                    maxTokens: Int = 2048, seed: UInt64 = 0, onToken: ((Int) -> Void)? = nil) throws -> [Float] {
+        try run(text: text, speaker: speaker, instruct: instruct, language: language, temperature: temperature, topK: topK,
+                topP: topP, repetitionPenalty: repetitionPenalty, maxTokens: maxTokens, seed: seed,
+                onEvent: onToken.map { cb in { ev in if case .token(let t) = ev { cb(t) } } })
+    }
+
     /// generateStream(...) -- Qwen3+Streaming.swift:8-18: .token per frame, then .info, then .audio
     public func generateStream(text: String, speaker: String? = nil, instruct: String? = nil, language: String = "auto",
                                temperature: Float = 0.9, topK: Int = 50, topP: Float = 1.0, repetitionPenalty: Float = 1.05,

@@ -81,3 +81,31 @@ def test_layout_heuristic_matches_reference_cases():
     assert not f((1024, 1, 7)) and not f((96, 96, 1))           # depthwise / k1 conv in torch layout
     assert f((96, 1, 96))                                       # k1 conv already MLX
     assert not f((1536, 768, 16))                               # ConvTranspose1d torch [in,out,k]
+
+
+def test_int16_quantisation_and_wav_file_follow_the_reference_cli(tmp_path):
+    """f3: Int16(clamp(x) * 32767) truncates toward zero (Sources/Qwen3TTSDemo/main.swift:158-162); the WAV file is the
+    44-byte PCM header the CLI writes (:138-156) + those samples. Host code behind the C ABI, checked against the oracle's
+    restatement and against Python's own WAV reader."""
+    import struct
+    import wave
+    from oracle import oracle as O
+    from qwen3tts import audio
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-1.3, 1.3, 5000).astype(np.float32),
+                        np.array([0.0, -0.0, 1.0, -1.0, 0.99999, -0.99999, 1.5, -7.0, 3.0518e-05, -3.0518e-05, 0.5, -0.5], np.float32)])
+    got = audio.pcm_to_int16(x)
+    assert got.dtype == np.int16 and (got == O.pcm_to_int16(x)).all()
+    assert got[5002] == 32767 and got[5003] == -32767 and got[5006] == 32767 and got[5007] == -32767  # never -32768
+    assert got[5008] == 0 and got[5009] == 0                                                            # toward zero, both signs
+    path = tmp_path / "o.wav"
+    audio.write_wav(str(path), x, 24000)
+    raw = path.read_bytes()
+    assert len(raw) == 44 + 2 * x.size and raw[:4] == b"RIFF" and raw[8:16] == b"WAVEfmt " and raw[36:40] == b"data"
+    assert struct.unpack("<IHHIIHH", raw[16:36]) == (16, 1, 1, 24000, 48000, 2, 16)
+    assert struct.unpack("<I", raw[4:8])[0] == 36 + 2 * x.size and struct.unpack("<I", raw[40:44])[0] == 2 * x.size
+    with wave.open(str(path), "rb") as w:
+        assert (w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()) == (1, 2, 24000, x.size)
+        assert (np.frombuffer(w.readframes(x.size), "<i2") == got).all()
+    sr, back = audio.read_wav(str(path))
+    assert sr == 24000 and np.abs(back - np.clip(x, -1, 1)).max() < 1.0 / 16384
