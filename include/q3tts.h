@@ -122,6 +122,9 @@ typedef struct {
     float repetition_penalty;
     uint64_t seed;        /* new: the reference draws from MLX's global key and has no seed API */
     int32_t force_frames; /* bench only: mask EOS and emit exactly this many frames per row */
+    int32_t audio_chunk_frames; /* new (the reference decodes one-shot, README.md:140): > 0 delivers the waveform in pieces of
+                                   this many codec frames through AUDIO_CHUNK events as the causal tail of the decoder
+                                   produces them, before INFO / AUDIO; the samples are bit-identical to the one-shot decode */
 } q3tts_sampling;
 void q3tts_default_sampling(q3tts_sampling* s);
 
@@ -138,14 +141,19 @@ typedef struct {
 /* enum AudioGeneration { token, info, audio } (Core/GenerationTypes.swift:51-58). Per request the
  * order is TOKEN* (EOS is not reported: Qwen3.swift:868-871), INFO, AUDIO -- the order
  * generateStream yields them (Qwen3+Streaming.swift:24-27,118-120). */
-typedef enum { Q3TTS_EVENT_TOKEN = 0, Q3TTS_EVENT_INFO = 1, Q3TTS_EVENT_AUDIO = 2 } q3tts_event_kind;
+typedef enum {
+    Q3TTS_EVENT_TOKEN = 0, Q3TTS_EVENT_INFO = 1, Q3TTS_EVENT_AUDIO = 2,
+    Q3TTS_EVENT_AUDIO_CHUNK = 3 /* only with q3tts_sampling.audio_chunk_frames > 0: samples [sample_offset, +n_samples) of
+                                   the request's final audio, in order, between the last TOKEN and INFO */
+} q3tts_event_kind;
 typedef struct {
     q3tts_event_kind kind;
     int32_t request_index;
     int32_t token;              /* TOKEN */
     const q3tts_gen_info* info; /* INFO  */
-    const float* pcm;           /* AUDIO: valid during the callback */
+    const float* pcm;           /* AUDIO, AUDIO_CHUNK: valid during the callback */
     int64_t n_samples;
+    int64_t sample_offset;      /* AUDIO_CHUNK: position of pcm[0] in the request's final audio */
 } q3tts_event;
 typedef void (*q3tts_event_cb)(void* user, const q3tts_event* ev);
 

@@ -57,6 +57,7 @@ void q3tts_default_sampling(q3tts_sampling* s) {  // Qwen3.swift:1296-1299
     s->repetition_penalty = 1.05f;
     s->seed = 0;
     s->force_frames = 0;
+    s->audio_chunk_frames = 0;
 }
 
 q3tts_status q3tts_model_load(const char* model_dir, const q3tts_load_opts* opts, q3tts_model** out) {

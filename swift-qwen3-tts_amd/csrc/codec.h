@@ -19,9 +19,32 @@ class CodecRunner {
     int decode(const int32_t* codes_dev, int code_stride_frames, const std::vector<int>& frames, float** pcm_dev,
                const std::string& stage = std::string(), std::vector<float>* stage_out = nullptr, int* stage_T = nullptr,
                int* stage_C = nullptr);
+    // The same decode with the causal tail (everything behind the pre-transformer) evaluated `chunk_frames` frames at a
+    // time (row f1 of SURVEY 8f): each chunk's samples land in pcm_host ([B][Fmax * upsample], pinned host memory) at
+    // their final place and chunk_done[k] is recorded behind chunk k's copy. Bit-identical to decode(). Returns the
+    // number of chunks; chunk k covers frames [k * chunk_frames, min(Fmax, (k + 1) * chunk_frames)).
+    int decode_chunked(const int32_t* codes_dev, int code_stride_frames, const std::vector<int>& frames, int chunk_frames,
+                       float* pcm_host, std::vector<hipEvent_t>& chunk_done);
+    int tail_context_frames() const;
     int upsample() const { return up_; }
 
   private:
+    struct Pass {  // one pass of kernels over `nb` rows
+        int nb = 0;
+        const int32_t* fr = nullptr;  // device: valid frames per row
+        const std::string* stage = nullptr;
+        std::vector<float>* stage_out = nullptr;
+        int* stage_T = nullptr;
+        int* stage_C = nullptr;
+    };
+    void conv(const Pass& ps, const struct ConvW& cw, const float* x, int Tmax, int ppf, float* out, const struct SnakeW* sn,
+              const float* res, int act, const struct SnakeW* post = nullptr, float* out2 = nullptr);
+    void capture(const Pass& ps, const char* name, const float* t, int T, int C);
+    void run_front(const Pass& ps, const int32_t* codes, int code_stride_frames, int Fmax, float* const* bufs);
+    void run_tail(const Pass& ps, int Tframes, float* const* bufs, float* pcm);
+    size_t floats_per_frame() const;
+    void upload_lens(const int32_t* lens, int n);
+    int32_t* lens_host_ = nullptr;
     const Model& m_;
     hipStream_t st_;
     int up_ = 1920;

@@ -93,6 +93,8 @@ Engine::~Engine() {
     for (void* p : {(void*)ref_audio_dev_, (void*)ref_codes_dev_, (void*)extra_, (void*)spk_f32_})
         if (p) (void)hipFree(p);
     for (auto& J : jobs_) {
+        for (auto& e : J.chunk_done)
+            if (e) (void)hipEventDestroy(e);
         if (J.dec_codes) (void)hipFree(J.dec_codes);
         if (J.pcm_host) (void)hipHostFree(J.pcm_host);
         for (auto& e : J.ev_codec)
@@ -1075,9 +1077,9 @@ int Engine::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3
     Q3_HIP(hipStreamSynchronize(st_));  // everything of this call on st_ is done; only the decode is still to come
     Q3_HIP(hipEventRecord(J.ev_codec[0], st_codec_));
     J.decoded = false;
+    J.n_chunks = 0;
+    J.chunk_frames = sp.audio_chunk_frames > 0 ? sp.audio_chunk_frames : 0;
     if (Fdec > 0) {
-        float* pcm_dev = nullptr;
-        codec_->decode(J.dec_codes, Fdec, dframes, &pcm_dev);
         const size_t floats = size_t(n) * Fdec * J.up;
         if (floats > J.pcm_host_cap) {
             if (J.pcm_host) Q3_HIP(hipHostFree(J.pcm_host));
@@ -1085,7 +1087,14 @@ int Engine::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3
             Q3_HIP(hipHostMalloc(reinterpret_cast<void**>(&J.pcm_host), floats * 4, hipHostMallocDefault));
             J.pcm_host_cap = floats;
         }
-        Q3_HIP(hipMemcpyAsync(J.pcm_host, pcm_dev, floats * 4, hipMemcpyDeviceToHost, st_codec_));
+        if (J.chunk_frames > 0) {
+            // pre-transformer once over all frames, then the causal tail chunk by chunk (codec.h decode_chunked)
+            J.n_chunks = codec_->decode_chunked(J.dec_codes, Fdec, dframes, J.chunk_frames, J.pcm_host, J.chunk_done);
+        } else {
+            float* pcm_dev = nullptr;
+            codec_->decode(J.dec_codes, Fdec, dframes, &pcm_dev);
+            Q3_HIP(hipMemcpyAsync(J.pcm_host, pcm_dev, floats * 4, hipMemcpyDeviceToHost, st_codec_));
+        }
         J.decoded = true;
     }
     Q3_HIP(hipEventRecord(J.ev_codec[1], st_codec_));
@@ -1119,13 +1128,55 @@ void Engine::end(int job, q3tts_result* results) {
     Q3_CHECK(job >= 0 && job < kJobSlots && jobs_[job].busy, 3, "Invalid input: no such outstanding job");
     Job& J = jobs_[job];
     Q3_HIP(hipSetDevice(m_->device));
+    const int n = J.n, up = J.up, Fdec = J.Fdec;
+    // samples [cut, cut + ns) of row b's decoded stream are its audio: audioLengths = count(code0 > 0) * 1920, trimmed
+    // when 0 < valid < len (SpeechTokenizer.swift:831-833, Qwen3.swift:954-959); clone rows lose the reference's share
+    // (Qwen3.swift:1195-1199, Float arithmetic)
+    std::vector<int64_t> row_cut((size_t)(n), 0), row_ns((size_t)(n), 0);
+    for (int b = 0; b < n; ++b) {
+        const int F = J.frames[size_t(b)];
+        if (F == 0 || !J.decoded) continue;
+        const int32_t* codes = J.codes_host.data() + size_t(b) * Fcap_ * 16;
+        int valid_tok = 0;
+        for (int f = 0; f < F; ++f) valid_tok += codes[size_t(f) * 16] > 0 ? 1 : 0;
+        for (int32_t c : J.ref_code0[size_t(b)]) valid_tok += c > 0 ? 1 : 0;
+        const int ref_T = J.ref_T[size_t(b)], total_f = ref_T + F;
+        int64_t ns = int64_t(total_f) * up;
+        const int64_t valid = int64_t(valid_tok) * up;
+        if (valid > 0 && valid < ns) ns = valid;
+        int64_t cut = 0;
+        if (ref_T > 0) {
+            cut = int64_t(float(ref_T) / float(std::max(total_f, 1)) * float(ns));
+            if (!(cut > 0 && cut < ns)) cut = 0;
+        }
+        row_cut[size_t(b)] = cut;
+        row_ns[size_t(b)] = ns - cut;
+    }
+    if (J.n_chunks > 0 && J.cb) {  // AUDIO_CHUNK events as the tail of the decoder delivers them
+        for (int k = 0; k < J.n_chunks; ++k) {
+            Q3_HIP(hipEventSynchronize(J.chunk_done[size_t(k)]));
+            const int64_t c0 = int64_t(k) * J.chunk_frames * up, c1 = std::min<int64_t>(int64_t(Fdec), int64_t(k + 1) * J.chunk_frames) * up;
+            std::unique_lock<std::mutex> lk;
+            if (cb_mutex) lk = std::unique_lock<std::mutex>(*cb_mutex);
+            for (int b = 0; b < n; ++b) {
+                const int64_t lo = std::max(c0, row_cut[size_t(b)]), hi = std::min(c1, row_cut[size_t(b)] + row_ns[size_t(b)]);
+                if (hi <= lo) continue;
+                q3tts_event ev{};
+                ev.kind = Q3TTS_EVENT_AUDIO_CHUNK;
+                ev.request_index = J.request_base + b;
+                ev.pcm = J.pcm_host + size_t(b) * Fdec * up + lo;
+                ev.n_samples = hi - lo;
+                ev.sample_offset = lo - row_cut[size_t(b)];
+                J.cb(J.user, &ev);
+            }
+        }
+    }
     Q3_HIP(hipEventSynchronize(J.ev_codec[1]));
     J.busy = false;
     float ms = 0;
     Q3_HIP(hipEventElapsedTime(&ms, J.ev_codec[0], J.ev_codec[1]));
     J.timing.codec_ms = ms;  // on the codec stream: includes whatever the next batch's AR loop took away from it
     timing = J.timing;
-    const int n = J.n, up = J.up, Fdec = J.Fdec;
     const double total = now_s() - J.t_start;
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
@@ -1146,20 +1197,7 @@ void Engine::end(int job, q3tts_result* results) {
         r.n_frames = F;
         r.codes = static_cast<int32_t*>(std::malloc(size_t(F) * 16 * 4));
         std::memcpy(r.codes, J.codes_host.data() + size_t(b) * Fcap_ * 16, size_t(F) * 16 * 4);
-        // audioLengths = count(code0 > 0) * 1920, trim when 0 < valid < len (SpeechTokenizer.swift:831-833, Qwen3.swift:954-959)
-        int valid_tok = 0;
-        for (int f = 0; f < F; ++f) valid_tok += r.codes[size_t(f) * 16] > 0 ? 1 : 0;
-        for (int32_t c : J.ref_code0[size_t(b)]) valid_tok += c > 0 ? 1 : 0;
-        const int ref_T = J.ref_T[size_t(b)], total_f = ref_T + F;
-        int64_t ns = int64_t(total_f) * up;
-        const int64_t valid = int64_t(valid_tok) * up;
-        if (valid > 0 && valid < ns) ns = valid;
-        int64_t cut = 0;
-        if (ref_T > 0) {  // proportional removal of the reference part (Qwen3.swift:1195-1199), Float arithmetic
-            cut = int64_t(float(ref_T) / float(std::max(total_f, 1)) * float(ns));
-            if (!(cut > 0 && cut < ns)) cut = 0;
-        }
-        ns -= cut;
+        const int64_t ns = row_ns[size_t(b)], cut = row_cut[size_t(b)];
         r.n_samples = ns;
         r.pcm = static_cast<float*>(std::malloc(size_t(ns) * 4));
         std::memcpy(r.pcm, J.pcm_host + size_t(b) * Fdec * up + cut, size_t(ns) * 4);

@@ -144,6 +144,8 @@ class Engine {
         float* pcm_host = nullptr;        // pinned [n][Fdec * up]
         size_t pcm_host_cap = 0;
         hipEvent_t ev_codec[2] = {nullptr, nullptr};
+        std::vector<hipEvent_t> chunk_done;  // chunked decode (audio_chunk_frames > 0): one per chunk, behind its copy
+        int n_chunks = 0, chunk_frames = 0;
         q3tts_timing timing{};
         double t_start = 0;
         q3tts_event_cb cb = nullptr;

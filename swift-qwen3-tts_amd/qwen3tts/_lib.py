@@ -41,7 +41,7 @@ class Request(C.Structure):
 
 class Sampling(C.Structure):
     _fields_ = [("temperature", C.c_float), ("top_k", C.c_int32), ("top_p", C.c_float),
-                ("repetition_penalty", C.c_float), ("seed", C.c_uint64), ("force_frames", C.c_int32)]
+                ("repetition_penalty", C.c_float), ("seed", C.c_uint64), ("force_frames", C.c_int32), ("audio_chunk_frames", C.c_int32)]
 
 
 class GenInfo(C.Structure):
@@ -52,7 +52,7 @@ class GenInfo(C.Structure):
 
 class Event(C.Structure):
     _fields_ = [("kind", C.c_int), ("request_index", C.c_int32), ("token", C.c_int32),
-                ("info", C.POINTER(GenInfo)), ("pcm", f32p), ("n_samples", C.c_int64)]
+                ("info", C.POINTER(GenInfo)), ("pcm", f32p), ("n_samples", C.c_int64), ("sample_offset", C.c_int64)]
 
 
 EVENT_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(Event))

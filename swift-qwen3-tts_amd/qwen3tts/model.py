@@ -172,32 +172,39 @@ class Qwen3TTSModel:
         return arr, keep
 
     @staticmethod
-    def _sampling(temperature, top_k, top_p, repetition_penalty, seed, force_frames) -> L.Sampling:
+    def _sampling(temperature, top_k, top_p, repetition_penalty, seed, force_frames, audio_chunk_frames=0) -> L.Sampling:
         s = L.Sampling()
         s.temperature, s.top_k, s.top_p = temperature, top_k, top_p
         s.repetition_penalty, s.seed, s.force_frames = repetition_penalty, seed, force_frames
+        s.audio_chunk_frames = audio_chunk_frames
         return s
 
     def generate_batch(self, reqs: Sequence[GenerationRequest], temperature: float = 0.9, top_k: int = 50,
                        top_p: float = 1.0, repetition_penalty: float = 1.05, seed: int = 0, force_frames: int = 0,
-                       on_event: Optional[Callable[[int, str, object], None]] = None) -> List[GenerationResult]:
+                       on_event: Optional[Callable[[int, str, object], None]] = None,
+                       audio_chunk_frames: int = 0) -> List[GenerationResult]:
         """n utterances in one call (row-independent). `on_event(request_index, kind, payload)` receives
-        ("token", id) / ("info", AudioGenerationInfo) / ("audio", ndarray) in the reference's order."""
+        ("token", id) / ("info", AudioGenerationInfo) / ("audio", ndarray) in the reference's order; with
+        audio_chunk_frames > 0 also ("audio_chunk", (sample_offset, ndarray)) pieces of the final audio, in order,
+        between the last token and info (the decoder's causal tail run chunk by chunk; same samples)."""
         return self.generate_batch_end(self.generate_batch_begin(reqs, temperature, top_k, top_p, repetition_penalty, seed,
-                                                                 force_frames, on_event))
+                                                                 force_frames, on_event, audio_chunk_frames))
 
     def generate_batch_begin(self, reqs: Sequence[GenerationRequest], temperature: float = 0.9, top_k: int = 50,
                              top_p: float = 1.0, repetition_penalty: float = 1.05, seed: int = 0, force_frames: int = 0,
-                             on_event: Optional[Callable[[int, str, object], None]] = None):
+                             on_event: Optional[Callable[[int, str, object], None]] = None, audio_chunk_frames: int = 0):
         """First half of generate_batch (q3tts_generate_begin): returns a job once the AR loop has produced the codes and
         their codec decode is queued. The next batch may be begun before this one is ended: its AR loop then overlaps
         this batch's decode. At most two jobs may be outstanding."""
         arr, keep = self._marshal(reqs)
-        s = self._sampling(temperature, top_k, top_p, repetition_penalty, seed, force_frames)
+        s = self._sampling(temperature, top_k, top_p, repetition_penalty, seed, force_frames, audio_chunk_frames)
 
         def _cb(_user, evp):
             ev = evp.contents
-            if ev.kind == 0:
+            if ev.kind == 3:
+                on_event(ev.request_index, "audio_chunk",
+                         (int(ev.sample_offset), np.ctypeslib.as_array(ev.pcm, shape=(ev.n_samples,)).copy()))
+            elif ev.kind == 0:
                 on_event(ev.request_index, "token", int(ev.token))
             elif ev.kind == 1:
                 i = ev.info.contents
