@@ -5,6 +5,7 @@
 #include <cctype>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <thread>
 
 #include "codec.h"
@@ -76,6 +77,10 @@ Engine::Engine(Model* model, const q3tts_load_opts& opts) : m_(model), opts_(opt
     for (auto& kv : m_->cfg.talker.spk_id) speakers.push_back(kv.first);
     std::sort(speakers.begin(), speakers.end());
     alloc_workspace();
+    if (std::getenv("Q3TTS_FRAME_STAMPS")) {
+        Q3_HIP(hipMalloc(reinterpret_cast<void**>(&stamps_), 64 * 8));
+        Q3_HIP(hipMemset(stamps_, 0, 64 * 8));
+    }
     if (m_->has_codec) codec_ = std::make_unique<CodecRunner>(*m_, st_codec_);
     if (m_->has_codec_encoder || m_->has_speaker_encoder) fe_ = std::make_unique<VoiceFrontEnd>(*m_, st_);
 }
@@ -110,6 +115,16 @@ Engine::~Engine() {
     for (auto& e : ev_fe_)
         if (e) (void)hipEventDestroy(e);
     if (fe_uploaded_) (void)hipEventDestroy(fe_uploaded_);
+    if (stamps_) {  // phase times of the frame step, accumulated over every frame step this engine ran
+        unsigned long long h[64];
+        if (hipMemcpy(h, stamps_, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess && h[0] > 0) {
+            static const char* nm[] = {"", "talker layers", "codec_head + norm + sampler (+ proj)", "predictor pair pass",
+                                       "pass-0 head + sampler", "predictor passes 1..14 (layers)", "their heads + samplers", "frame_end"};
+            std::fprintf(stderr, "[q3tts frame stamps] %llu frame steps\n", h[0]);
+            for (int k = 1; k < 8; ++k) std::fprintf(stderr, "  %-40s %8.1f us per step\n", nm[k], double(h[k]) / 100.0 / double(h[0]));
+        }
+        (void)hipFree(stamps_);
+    }
     if (st_codec_) (void)hipStreamDestroy(st_codec_);
     if (st_) (void)hipStreamDestroy(st_);
 }
@@ -337,7 +352,9 @@ void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
     const TalkerConfig& t = m_->cfg.talker;
     const int H = t.hidden_size, V = t.vocab_size, Vc = t.cp.vocab_size, CH = t.cp.hidden_size;
     const int groups = t.num_code_groups, MBL = Mp_ / 16;
+    stamp(0);
     enqueue_talker_step(B, true);
+    stamp(1);
     {   // final norm (prologue) + codec_head (Talker.swift:573, 644)
         GemmArgs hd = gemm_args(m_->codec_head, tk_.h, B);
         hd.epi = 0; hd.y = tk_.logits; hd.ldy = tk_.ld_logits;
@@ -382,9 +399,11 @@ void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
             launch_gemm_skinny(p, st_);
             ss_count = CH / 16;
         }
+        stamp(2);
         enqueue_layers(m_->cp, cp_, B, cp_kpool_, cp_vpool_, cp_kv_layer_stride_, cp_block_table_, 1, cp_len_, nullptr, ss_count, 0, 2,
                        nullptr, 0);
         launch_advance_len(cp_len_, nullptr, B, st_);
+        stamp(3);
     } else {
         launch_sampler(sa, st_);
         // code predictor, step 0 = [hidden, embed(code0)] run as two positions
@@ -398,7 +417,10 @@ void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
     for (int i = 0; i < groups - 1; ++i) {
         const bool second_of_pair = pair && i == 0;  // its stack forward already ran above; rows B..2B-1 hold it
         const int Mh = second_of_pair ? 2 * B : B;
-        if (!second_of_pair) enqueue_cp_pass(B, false, i, i + 1, cp_tables_ && i >= 1);
+        if (!second_of_pair) {
+            enqueue_cp_pass(B, false, i, i + 1, cp_tables_ && i >= 1);
+            stamp(5);
+        }
         {
             GemmArgs lh = gemm_args(m_->lm_head[size_t(i)], cp_.h, Mh);
             lh.epi = 0; lh.y = cp_.logits; lh.ldy = cp_.ld_logits;
@@ -423,6 +445,7 @@ void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
         }
         sc.logits_dump = (dbg && dbg->cp_logits) ? cl_dump_ : nullptr; sc.dump_ld = (groups - 1) * Vc; sc.dump_off = i * Vc;
         launch_sampler(sc, st_);
+        stamp(second_of_pair ? 4 : 6);
     }
     FrameEndArgs fe{};
     fe.cur_codes = cur_codes_; fe.codec_emb = m_->codec_emb; fe.cp_emb = m_->cp_emb_dev;
@@ -430,6 +453,7 @@ void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
     fe.tts_pad = tts_pad_; fe.h = tk_.h; fe.hMB = MBL; fe.ss_out = tk_.ss_a; fe.H = H; fe.B = B; fe.groups = groups;
     fe.n_frames = n_frames_; fe.max_frames = max_frames_; fe.finished = finished_; fe.active = active_; fe.cp_len = cp_len_;
     launch_frame_end(fe, st_);
+    stamp(7);
 }
 
 hipGraphExec_t Engine::frame_graph(int B) {

@@ -155,6 +155,10 @@ class Engine {
     } jobs_[kJobSlots];
     uint64_t job_seq_ = 0;
 
+    unsigned long long* stamps_ = nullptr;  // Q3TTS_FRAME_STAMPS=1: [0] frame steps, [k] ticks of phase k, [63] last stamp
+    void stamp(int k) {
+        if (stamps_) launch_stamp(stamps_, stamps_ + 63, k, st_);
+    }
     std::map<int, hipGraphExec_t> graphs_;  // keyed by batch size
     std::unique_ptr<CodecRunner> codec_;
     std::unique_ptr<VoiceFrontEnd> fe_;

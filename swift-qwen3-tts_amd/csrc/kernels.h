@@ -155,6 +155,7 @@ struct PrefillLoadArgs {
 };
 void launch_prefill_load(const PrefillLoadArgs& a, hipStream_t st);
 void launch_advance_len(int32_t* kv_len, const uint8_t* active, int B, hipStream_t st);
+void launch_stamp(unsigned long long* acc, unsigned long long* last, int k, hipStream_t st);  // diagnostics
 // chunked prefill: C positions per row per step; a.step carries r_base (prompt index of element 0 = r_base + n_prompt[b])
 void launch_prefill_chunk_load(const PrefillLoadArgs& a, int C, hipStream_t st);
 void launch_advance_len_chunk(int32_t* kv_len, const int32_t* n_prompt, int r_base, int C, int B, hipStream_t st);

@@ -47,14 +47,20 @@ void launch_mb(const GemmArgs& a, int split, hipStream_t st) {
     const int KC = a.K / 128;
     const int nw = KC <= 4 ? 4 : 8;  // no idle waves on short K
     const int ch = (KC + nw - 1) / nw;
-    const int tiles = a.N / 16;
+    const int tiles = EPI == 2 ? a.N / 8 : a.N / 16;  // EPI 2: eight columns per (gate | up) tile
 #define Q3_GEMM(NWv, CHv) \
     hipLaunchKernelGGL((gemm_skinny_kernel<MB, EPI, NWv, CHv, NORM, QUANT, 1, NTW>), dim3(tiles, split), dim3(NWv * 64), 0, st, a)
-    if constexpr (EPI == 2 && !QUANT && MB <= 2) {
-        // more than one round of workgroups on 256 CUs, and an even pair count: two pairs per workgroup, one round
-        static const bool one_pair = std::getenv("Q3TTS_GEMM_ONE_PAIR") != nullptr;
-        if (!one_pair && nw == 8 && ch == 2 && tiles > 256 && tiles <= 512 && tiles % 2 == 0) {
-            hipLaunchKernelGGL((gemm_skinny_kernel<MB, 2, 8, 2, NORM, false, 2, NTW>), dim3(tiles / 2, split), dim3(512), 0, st, a);
+    if constexpr (EPI == 2 && MB <= 2) {
+        // gate/up tiles are self-contained, so a workgroup takes as many as it needs for the launch to be ONE round of at
+        // most 256 workgroups: 768 tiles (6144 columns) -> 3 each, 384 (3072) -> 2 each
+        static const bool one_tile = std::getenv("Q3TTS_GEMM_ONE_PAIR") != nullptr;
+        const int np = one_tile ? 1 : (tiles > 512 ? 3 : (tiles > 256 ? 2 : 1));
+        if (nw == 8 && (ch == 1 || ch == 2) && np > 1) {
+            const dim3 grid((tiles + np - 1) / np, split);
+#define Q3_GEMM_NP(CHv, NPv) hipLaunchKernelGGL((gemm_skinny_kernel<MB, 2, 8, CHv, NORM, QUANT, NPv, NTW>), grid, dim3(512), 0, st, a)
+            if (ch == 1) { if (np == 2) Q3_GEMM_NP(1, 2); else Q3_GEMM_NP(1, 3); }
+            else { if (np == 2) Q3_GEMM_NP(2, 2); else Q3_GEMM_NP(2, 3); }
+#undef Q3_GEMM_NP
             return;
         }
     }
@@ -80,7 +86,11 @@ void launch_q(const GemmArgs& a, hipStream_t st) {
     // to separate workgroups instead (grid.y); tile x of both lands on the same XCD (128 = 0 mod 8), so the second
     // read of the weight tile is an L2 hit. Per-row arithmetic does not depend on the grouping: results are unchanged.
     static const bool no_split = std::getenv("Q3TTS_GEMM_NO_ROW_SPLIT") != nullptr;
-    const int tiles = a.N / 16;
+    int tiles = a.N / 16;  // workgroups along x
+    if constexpr (EPI == 2) {  // eight columns per tile, up to three tiles per workgroup (launch_mb)
+        const int t8 = a.N / 8;
+        tiles = t8 > 512 ? (t8 + 2) / 3 : (t8 > 256 ? (t8 + 1) / 2 : t8);
+    }
     int split = 1;
     if (!no_split) {
         if (MBt % 4 == 0 && tiles * 4 <= 256) split = 4;
@@ -118,7 +128,7 @@ void launch_epi(const GemmArgs& a, hipStream_t st) {
 }  // namespace
 
 void launch_gemm_skinny(const GemmArgs& a, hipStream_t st) {
-    Q3_CHECK(a.K % 128 == 0 && a.N % 16 == 0, 3, "gemm_skinny: K must be a multiple of 128 and N of 16");
+    Q3_CHECK(a.K % 128 == 0 && a.N % (a.epi == 2 ? 8 : 16) == 0, 3, "gemm_skinny: K must be a multiple of 128 and N of 16");
     Q3_CHECK(a.Mpad % 16 == 0 && a.M <= a.Mpad && a.Mpad <= 256, 3, "gemm_skinny: bad M padding");
     Q3_CHECK(a.xMB * 16 >= a.Mpad, 3, "gemm_skinny: x allocation has fewer row blocks than the batch");
     const bool norm = a.norm_w != nullptr;

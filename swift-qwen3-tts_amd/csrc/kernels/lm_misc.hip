@@ -200,6 +200,15 @@ __global__ void advance_len_chunk_kernel(int32_t* kv_len, const int32_t* n_promp
     kv_len[b] += C - p0;
 }
 
+// Diagnostics (Q3TTS_FRAME_STAMPS=1): slot[k] accumulates the time between this stamp and the previous one of the same
+// frame step, so that the phases of a REPLAYED graph can be timed (a tracing profiler perturbs a chain of 5 us launches).
+__global__ void stamp_kernel(unsigned long long* acc, unsigned long long* last, int k) {
+    const unsigned long long t = wall_clock64();  // 100 MHz constant clock
+    if (k > 0) acc[k] += t - *last;
+    else acc[0] += 1;  // frame steps seen
+    *last = t;
+}
+
 __global__ void advance_len_kernel(int32_t* kv_len, const uint8_t* active, int B) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b < B && (!active || active[b])) kv_len[b] += 1;
@@ -323,6 +332,9 @@ void launch_prefill_chunk_load(const PrefillLoadArgs& a, int C, hipStream_t st) 
 }
 void launch_advance_len_chunk(int32_t* kv_len, const int32_t* n_prompt, int r_base, int C, int B, hipStream_t st) {
     hipLaunchKernelGGL(advance_len_chunk_kernel, dim3(1), dim3(64), 0, st, kv_len, n_prompt, r_base, C, B);
+}
+void launch_stamp(unsigned long long* acc, unsigned long long* last, int k, hipStream_t st) {
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, st, acc, last, k);
 }
 void launch_advance_len(int32_t* kv_len, const uint8_t* active, int B, hipStream_t st) {
     hipLaunchKernelGGL(advance_len_kernel, dim3(1), dim3(64), 0, st, kv_len, active, B);

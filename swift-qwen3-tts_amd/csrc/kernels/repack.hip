@@ -9,11 +9,16 @@
 namespace q3 {
 namespace {
 
+// rpt / row_off: source rows per destination tile (16, or 8 when two matrices share every tile: gate rows in tile rows
+// 0..7, up rows in 8..15) and the tile row the first of them lands on; lanes outside [row_off, row_off + rpt) leave
+// their part of the tile alone.
 __global__ __launch_bounds__(256) void tile_weights_kernel(const uint16_t* src, int N, int K, uint16_t* dst, int KC,
-                                                           int tile_off, int tile_stride) {
+                                                           int tile_off, int tile_stride, int rpt, int row_off) {
     const int kc = blockIdx.x, j = blockIdx.y;
     const int i = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int row = 16 * j + (lane & 15);
+    const int pos = (lane & 15) - row_off;
+    if (pos < 0 || pos >= rpt) return;
+    const int row = rpt * j + pos;
     const int k = kc * 128 + 32 * (lane >> 4) + 8 * i;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (row < N && k + 8 <= K) {
@@ -32,9 +37,11 @@ __global__ __launch_bounds__(256) void tile_weights_kernel(const uint16_t* src, 
 //   sb tiles [tile][kc][lane] uint32: {scale, bias} of that lane's group (k/64)
 __global__ __launch_bounds__(64) void tile_int4_kernel(const uint32_t* wq, const uint16_t* scales, const uint16_t* biases,
                                                        int N, int K, uint4* dq, uint32_t* dsb, int KC, int tile_off,
-                                                       int tile_stride) {
+                                                       int tile_stride, int rpt, int row_off) {
     const int kc = blockIdx.x, j = blockIdx.y, lane = threadIdx.x;
-    const int row = 16 * j + (lane & 15), h = lane >> 4;
+    const int pos = (lane & 15) - row_off;
+    if (pos < 0 || pos >= rpt) return;
+    const int row = rpt * j + pos, h = lane >> 4;
     const int k = kc * 128 + 32 * h;
     uint4 v = make_uint4(0, 0, 0, 0);
     uint32_t sb = 0;
@@ -51,18 +58,20 @@ __global__ __launch_bounds__(64) void tile_int4_kernel(const uint32_t* wq, const
 }  // namespace
 
 void launch_tile_int4(const uint32_t* wq, const uint16_t* scales, const uint16_t* biases, int N, int K, void* dq,
-                      uint32_t* dsb, int KC, int tile_off, int tile_stride, hipStream_t st) {
+                      uint32_t* dsb, int KC, int tile_off, int tile_stride, hipStream_t st, int rpt, int row_off) {
     Q3_CHECK(K % 64 == 0, 6, "int4 weights need an inner size that is a multiple of the group size 64");
-    dim3 grid(KC, (N + 15) / 16);
+    Q3_CHECK((rpt == 16 && row_off == 0) || (rpt == 8 && (row_off == 0 || row_off == 8)), 7, "tile_int4: bad row mapping");
+    dim3 grid(KC, (N + rpt - 1) / rpt);
     hipLaunchKernelGGL(tile_int4_kernel, grid, dim3(64), 0, st, wq, scales, biases, N, K, reinterpret_cast<uint4*>(dq), dsb, KC,
-                       tile_off, tile_stride);
+                       tile_off, tile_stride, rpt, row_off);
 }
 
 void launch_tile_weights(const uint16_t* src, int N, int K, uint16_t* dst, int KC, int tile_off, int tile_stride,
-                         hipStream_t st) {
+                         hipStream_t st, int rpt, int row_off) {
     Q3_CHECK(K % 8 == 0, 6, "linear weights need an inner size that is a multiple of 8");
-    dim3 grid(KC, (N + 15) / 16);
-    hipLaunchKernelGGL(tile_weights_kernel, grid, dim3(256), 0, st, src, N, K, dst, KC, tile_off, tile_stride);
+    Q3_CHECK((rpt == 16 && row_off == 0) || (rpt == 8 && (row_off == 0 || row_off == 8)), 7, "tile_weights: bad row mapping");
+    dim3 grid(KC, (N + rpt - 1) / rpt);
+    hipLaunchKernelGGL(tile_weights_kernel, grid, dim3(256), 0, st, src, N, K, dst, KC, tile_off, tile_stride, rpt, row_off);
 }
 
 }  // namespace q3

@@ -376,6 +376,7 @@ const uint16_t* put_bf16(Builder& b, const TensorView& tv) {
 struct RowSrc {
     LinSrc src;
     int tile_off, tile_stride;
+    int rows_per_tile = 16, row_off = 0;  // 8 / {0, 8}: two matrices share every tile (gate rows 0..7, up rows 8..15)
 };
 LinearW put_linear(Builder& b, const std::vector<RowSrc>& srcs, int N, int K, int total_tiles, const TensorView* bias) {
     LinearW L;
@@ -402,10 +403,11 @@ LinearW put_linear(Builder& b, const std::vector<RowSrc>& srcs, int N, int K, in
                 Q3_HIP(hipMemcpyAsync(ds, s.src.scales->data, s.src.scales->nbytes, hipMemcpyHostToDevice, nullptr));
                 Q3_HIP(hipMemcpyAsync(db, s.src.biases->data, s.src.biases->nbytes, hipMemcpyHostToDevice, nullptr));
                 launch_tile_int4(reinterpret_cast<const uint32_t*>(b.staging), reinterpret_cast<const uint16_t*>(ds),
-                                 reinterpret_cast<const uint16_t*>(db), n, K, dst, dsb, KC, s.tile_off, s.tile_stride, nullptr);
+                                 reinterpret_cast<const uint16_t*>(db), n, K, dst, dsb, KC, s.tile_off, s.tile_stride, nullptr,
+                                 s.rows_per_tile, s.row_off);
             } else {
                 launch_tile_weights(reinterpret_cast<const uint16_t*>(b.staging), n, K, reinterpret_cast<uint16_t*>(dst), KC,
-                                    s.tile_off, s.tile_stride, nullptr);
+                                    s.tile_off, s.tile_stride, nullptr, s.rows_per_tile, s.row_off);
             }
             Q3_HIP(hipStreamSynchronize(nullptr));
         }
@@ -432,9 +434,12 @@ const uint16_t* put_embedding(Builder& b, const SafetensorsDir& st, const std::s
     }
     const TensorView& sc = st.at(name + ".scales");
     const TensorView& bi = st.at(name + ".biases");
+    Q3_CHECK(w.shape.size() == 2 && dim % 64 == 0, 6, "unexpected quantised embedding '" + name + "'");
     const int64_t rows = w.shape[0];
-    Q3_CHECK(w.dtype == DType::U32 && w.shape[1] == dim / 8 && sc.shape == std::vector<int64_t>({rows, dim / 64}), 6,
-             "unexpected quantised embedding '" + name + "'");
+    Q3_CHECK(w.dtype == DType::U32 && w.shape[1] == dim / 8, 6, "quantised embedding '" + name + "' must be uint32 [rows][dim/8] (4-bit)");
+    Q3_CHECK(sc.dtype == DType::BF16 && bi.dtype == DType::BF16 && sc.shape == std::vector<int64_t>({rows, dim / 64}) &&
+                 bi.shape == sc.shape,
+             6, "quantised embedding '" + name + "' needs bf16 scales/biases [rows][dim/64] (group size 64)");
     if (rows_out) *rows_out = rows;
     std::vector<uint16_t> deq;
     if (!b.dry && b.fill) {
@@ -480,10 +485,13 @@ void build_stack(Builder& b, const MainTensors& mt, const std::string& prefix, S
                                {lin_src(st, p + ".self_attn.v_proj", kd, hidden), (qd + kd) / 16, 1}},
                            qd + 2 * kd, hidden, (qd + 2 * kd) / 16, nullptr);
         L.o = put_linear(b, {{lin_src(st, p + ".self_attn.o_proj", hidden, qd), 0, 1}}, hidden, qd, hidden / 16, nullptr);
-        const int it = L.inter_p / 16;  // gate/up tile pairs, padded so that act has inter_p columns
-        L.gateup = put_linear(b, {{lin_src(st, p + ".mlp.gate_proj", I, hidden), 0, 2}, {lin_src(st, p + ".mlp.up_proj", I, hidden), 1, 2}},
-                              I, hidden, 2 * it, nullptr);
-        L.gateup.Np = L.inter_p;  // logical output columns (pairs of tiles)
+        // gate and up share every 16-row tile: rows 0..7 = eight gate rows, rows 8..15 = the up rows of the same eight
+        // columns, so a tile is a self-contained unit of the SwiGLU epilogue (8 outputs) and a workgroup may take any
+        // number of them: 6144 columns = 768 tiles = 256 workgroups x 3 (tile PAIRS would be 384 = 1.5 per CU)
+        const int it = L.inter_p / 8;  // padded so that act has inter_p columns
+        L.gateup = put_linear(b, {{lin_src(st, p + ".mlp.gate_proj", I, hidden), 0, 1, 8, 0}, {lin_src(st, p + ".mlp.up_proj", I, hidden), 0, 1, 8, 8}},
+                              I, hidden, it, nullptr);
+        L.gateup.Np = L.inter_p;  // logical output columns (8 per tile)
         L.down = put_linear(b, {{lin_src(st, p + ".mlp.down_proj", hidden, I), 0, 1}}, hidden, I, hidden / 16, nullptr);
     }
     s.final_norm = put_bf16(b, mt.bf16(prefix + ".norm.weight", {hidden}));
@@ -1015,6 +1023,13 @@ void build_all(Builder& b, Model& m, const SafetensorsDir& main, const TMap* cod
     if (main.has("talker.model.text_token_map")) {  // Qwen3.swift:1434-1444
         const TensorView& tm = main.at("talker.model.text_token_map");
         Q3_CHECK(tm.dtype == DType::I32, 6, "text_token_map must be int32");
+        // ids are validated against text_vocab_size per request; the map must cover them and stay inside the compact table
+        Q3_CHECK(tm.numel() >= t.text_vocab_size, 6, "text_token_map is shorter than text_vocab_size");
+        if (!b.dry) {
+            const int32_t* mp = reinterpret_cast<const int32_t*>(tm.data);
+            for (int64_t i = 0; i < tm.numel(); ++i)
+                Q3_CHECK(mp[i] >= 0 && mp[i] < m.text_emb_rows, 6, "text_token_map points outside the text embedding table");
+        }
         m.token_map = b.put<int32_t>(reinterpret_cast<const int32_t*>(tm.data), size_t(tm.numel()));
     }
     std::vector<int> inter;

@@ -195,8 +195,8 @@ std::unique_ptr<Model> load_model(const std::string& dir, const LoadOptions& opt
 
 // GPU repack helpers (repack.hip)
 void launch_tile_weights(const uint16_t* src, int N, int K, uint16_t* dst, int KC, int tile_off, int tile_stride,
-                         hipStream_t st);
+                         hipStream_t st, int rows_per_tile = 16, int row_off = 0);
 void launch_tile_int4(const uint32_t* wq, const uint16_t* scales, const uint16_t* biases, int N, int K, void* dq,
-                      uint32_t* dsb, int KC, int tile_off, int tile_stride, hipStream_t st);
+                      uint32_t* dsb, int KC, int tile_off, int tile_stride, hipStream_t st, int rows_per_tile = 16, int row_off = 0);
 
 }  // namespace q3

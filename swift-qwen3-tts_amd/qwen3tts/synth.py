@@ -156,6 +156,12 @@ def preset(name: str) -> dict:
         p["config"]["quantization"] = {"group_size": 64, "bits": 4}
         p["config"]["talker_config"]["pruned_text_rows"] = 600  # writer-only hint, ignored by the loaders
         return p
+    if name == "tiny-qe":
+        # tiny-q with QuantizedEmbedding tables as well: the reference quantises an embedding exactly when its `.scales`
+        # key exists in the checkpoint (Qwen3.swift:1402-1406, 1419-1422)
+        p = preset("tiny-q")
+        p["config"]["talker_config"]["quantized_embeddings"] = True  # writer-only hint, ignored by the loaders
+        return p
     if name == "0.6b-q4":  # BASELINE config 5: 0.6B, int4-g64 Linears, pruned text vocabulary (47,427 rows)
         p = preset("0.6b")
         p["config"]["quantization"] = {"group_size": 64, "bits": 4}
@@ -260,6 +266,19 @@ def talker_tensors(cfg: dict, g: _Gen, std: float = 0.02) -> Dict[str, Tuple[str
         if bias:
             out[name + ".bias"] = g.normal_bf16((n,), std)
 
+    def emb(name, rows, dim):
+        if quant and t.get("quantized_embeddings"):  # QuantizedEmbedding: same packing as a quantised Linear, row = q*scale + bias
+            q = g.rng.integers(0, 16, size=(rows, dim), dtype=np.uint32)
+            packed = np.zeros((rows, dim // 8), np.uint32)
+            for j in range(8):
+                packed |= q[:, j::8] << np.uint32(4 * j)
+            sc = g.uniform((rows, dim // 64), 0.002, 0.006)
+            out[name + ".weight"] = ("U32", packed)
+            out[name + ".scales"] = ("BF16", f32_to_bf16_bits(sc))
+            out[name + ".biases"] = ("BF16", f32_to_bf16_bits(-7.5 * sc + g.normal((rows, dim // 64), 0.0005)))
+        else:
+            out[name + ".weight"] = g.normal_bf16((rows, dim), std)
+
     def norm(name, d):
         # norm weights 1 with a small perturbation so a forgotten weight multiply is caught
         out[name + ".weight"] = g.normal_bf16((d,), 0.05, 1.0)
@@ -281,13 +300,13 @@ def talker_tensors(cfg: dict, g: _Gen, std: float = 0.02) -> Dict[str, Tuple[str
         norm(prefix + ".norm", hidden)
 
     inter = t.get("per_layer_intermediate_sizes") or [t["intermediate_size"]] * t["num_hidden_layers"]
-    out["talker.model.codec_embedding.weight"] = g.normal_bf16((V, H), std)
+    emb("talker.model.codec_embedding", V, H)
     pruned = t.get("pruned_text_rows")
     if pruned:  # compact table + original-id -> compact-index map (Qwen3.swift:1434-1444, Talker.swift:627-633)
-        out["talker.model.text_embedding.weight"] = g.normal_bf16((pruned, TH), std)
+        emb("talker.model.text_embedding", pruned, TH)
         out["talker.model.text_token_map"] = ("I32", g.rng.integers(0, pruned, size=(TV,)).astype(np.int32))
     else:
-        out["talker.model.text_embedding.weight"] = g.normal_bf16((TV, TH), std)
+        emb("talker.model.text_embedding", TV, TH)
     stack("talker.model", H, inter, nh, nkv, hd)
     lin("talker.text_projection.linear_fc1", TH, TH, bias=True)
     lin("talker.text_projection.linear_fc2", H, TH, bias=True)
@@ -296,7 +315,7 @@ def talker_tensors(cfg: dict, g: _Gen, std: float = 0.02) -> Dict[str, Tuple[str
     if ch != H:
         lin("talker.code_predictor.small_to_mtp_projection", ch, H, bias=True)
     for i in range(cp["num_code_groups"] - 1):
-        out[f"talker.code_predictor.model.codec_embedding.{i}.weight"] = g.normal_bf16((cp["vocab_size"], H), std)
+        emb(f"talker.code_predictor.model.codec_embedding.{i}", cp["vocab_size"], H)
         lin(f"talker.code_predictor.lm_head.{i}", cp["vocab_size"], ch)
     stack("talker.code_predictor.model", ch, [cp["intermediate_size"]] * cp["num_hidden_layers"],
           cp["num_attention_heads"], cp["num_key_value_heads"], cp["head_dim"])

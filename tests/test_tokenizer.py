@@ -89,3 +89,10 @@ def test_errors():
     with pytest.raises(Qwen3TTSError) as e:
         NativeTokenizer("/nonexistent/dir")
     assert e.value.status == 1 and "Tokenizer not loaded" in str(e.value)
+
+
+@pytest.mark.gpu
+def test_committed_cases_on_the_gpu_box(native):
+    """The same committed cases again under the gpu marker, so that the tokeniser (row f2) is exercised by the GPU-box
+    run as well: it is host code inside libq3tts_hip.so and needs neither the tokenizers wheel nor the card."""
+    test_committed_cases(native)

@@ -23,6 +23,7 @@ static float time_it(std::function<void(hipStream_t)> f, hipStream_t st, int ite
 
 int main(int argc, char** argv) {
     int M = argc > 1 ? atoi(argv[1]) : 32;
+    const int nt = argc > 2 ? atoi(argv[2]) : 0;  // 1: non-temporal weight loads
     hipStream_t st; CK(hipStreamCreate(&st));
     struct Shape { const char* name; int N, K, epi, norm; };
     std::vector<Shape> shapes = {
@@ -48,6 +49,7 @@ int main(int argc, char** argv) {
             a.epi = s.epi; a.y = y; a.ldy = s.N; a.yMB = Mp / 16; a.ss_ld = Mp;
             if (s.norm) { a.norm_w = nw; a.ss_in = ssi; a.ss_count = s.K / 16; a.norm_dim = s.K; a.norm_eps = 1e-6f; }
             if (s.epi == 3) { a.resid = 1; a.ss_out = sso; }
+            a.nt_weights = nt;
             launch_gemm_skinny(a, q);
         };
         float us = time_it(f, st, 200);
