@@ -27,6 +27,8 @@ class CodecRunner {
                        float* pcm_host, std::vector<hipEvent_t>& chunk_done);
     int tail_context_frames() const;
     int upsample() const { return up_; }
+    hipStream_t stream() const { return st_; }
+    void set_stream(hipStream_t st) { st_ = st; }  // the caller drains the old stream first (shared scratch)
 
   private:
     struct Pass {  // one pass of kernels over `nb` rows

@@ -39,23 +39,25 @@ Engine::Engine(Model* model, const q3tts_load_opts& opts) : m_(model), opts_(opt
     Q3_HIP(hipSetDevice(m_->device));
     {
         // The AR loop is a chain of short dependent launches (latency), the codec decode a few hundred large ones
-        // (matrix cores): the decode of a finished batch runs on its own, lower-priority stream so that the next
-        // batch's AR loop can overlap it (begin / end). Q3TTS_CODEC_CUS=n confines the codec stream to n CUs
-        // (mask bits interleave over the XCDs), which bounds what it can take away from the AR chain.
+        // (matrix cores): the decode of a finished batch runs on its own stream so that the NEXT batch's AR loop can
+        // overlap it (begin / end). Stream priorities alone do not help: a decode kernel's workgroups fill every CU and the
+        // AR chain's workgroups then queue behind them (prefill 23 -> 165 ms, nothing gained). Confined to half of the CUs
+        // (mask bits interleave over the XCDs) the decode takes 1.7x as long but leaves the chain room: 879 -> 826 ms
+        // per pipelined step at 1.7B / batch 32 (96 CUs: 841, 160: 841, 192: 856). A decode that nothing overlaps
+        // (generate(), codec_decode) uses the unmasked stream. Q3TTS_CODEC_CUS overrides the CU count (0: never mask).
         int least = 0, greatest = 0;
         Q3_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
         Q3_HIP(hipStreamCreateWithPriority(&st_, hipStreamNonBlocking, greatest));
-        int cus = 0;
+        Q3_HIP(hipStreamCreateWithPriority(&st_codec_, hipStreamNonBlocking, least));
+        hipDeviceProp_t prop{};
+        Q3_HIP(hipGetDeviceProperties(&prop, m_->device));
+        int cus = prop.multiProcessorCount / 2;
         if (const char* e = std::getenv("Q3TTS_CODEC_CUS")) cus = std::atoi(e);
-        if (cus > 0) {
-            hipDeviceProp_t prop{};
-            Q3_HIP(hipGetDeviceProperties(&prop, m_->device));
-            cus = std::min(cus, prop.multiProcessorCount);
+        cus = std::min(cus, prop.multiProcessorCount) / 8 * 8;
+        if (cus > 0 && cus < prop.multiProcessorCount) {
             std::vector<uint32_t> mask(size_t(ceil_div(prop.multiProcessorCount, 32)), 0u);
             for (int i = 0; i < cus; ++i) mask[size_t(i / 32)] |= 1u << (i % 32);
-            Q3_HIP(hipExtStreamCreateWithCUMask(&st_codec_, uint32_t(mask.size()), mask.data()));
-        } else {
-            Q3_HIP(hipStreamCreateWithPriority(&st_codec_, hipStreamNonBlocking, least));
+            Q3_HIP(hipExtStreamCreateWithCUMask(&st_codec_part_, uint32_t(mask.size()), mask.data()));
         }
     }
     for (auto& J : jobs_)
@@ -125,6 +127,7 @@ Engine::~Engine() {
         }
         (void)hipFree(stamps_);
     }
+    if (st_codec_part_) (void)hipStreamDestroy(st_codec_part_);
     if (st_codec_) (void)hipStreamDestroy(st_codec_);
     if (st_) (void)hipStreamDestroy(st_);
 }
@@ -876,10 +879,21 @@ void Engine::debug_prepare_inputs(const q3tts_request& req, uint16_t* input_embe
 // ------------------------------------------------------------------------------------------------
 void Engine::generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3tts_event_cb cb, void* user,
                       q3tts_result* results, const DebugOpts* dbg) {
-    end(begin(reqs, n, sp, cb, user, dbg), results);
+    end(begin(reqs, n, sp, cb, user, dbg, false), results);
 }
 
-int Engine::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3tts_event_cb cb, void* user, const DebugOpts* dbg) {
+// The codec runner's scratch is shared by both codec streams: before it moves to the other one, the one it ran on drains.
+hipStream_t Engine::codec_stream(bool overlapped) {
+    hipStream_t want = overlapped && st_codec_part_ ? st_codec_part_ : st_codec_;
+    if (want != codec_->stream()) {
+        Q3_HIP(hipStreamSynchronize(codec_->stream()));
+        codec_->set_stream(want);
+    }
+    return want;
+}
+
+int Engine::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3tts_event_cb cb, void* user, const DebugOpts* dbg,
+                  bool overlapped) {
     const TalkerConfig& t = m_->cfg.talker;
     const int H = t.hidden_size, V = t.vocab_size, Vc = t.cp.vocab_size, groups = t.num_code_groups;
     Q3_HIP(hipSetDevice(m_->device));  // lanes run on their own host threads
@@ -1099,7 +1113,8 @@ int Engine::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3
         }
     }
     Q3_HIP(hipStreamSynchronize(st_));  // everything of this call on st_ is done; only the decode is still to come
-    Q3_HIP(hipEventRecord(J.ev_codec[0], st_codec_));
+    hipStream_t cst = codec_stream(overlapped);
+    Q3_HIP(hipEventRecord(J.ev_codec[0], cst));
     J.decoded = false;
     J.n_chunks = 0;
     J.chunk_frames = sp.audio_chunk_frames > 0 ? sp.audio_chunk_frames : 0;
@@ -1117,11 +1132,11 @@ int Engine::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3
         } else {
             float* pcm_dev = nullptr;
             codec_->decode(J.dec_codes, Fdec, dframes, &pcm_dev);
-            Q3_HIP(hipMemcpyAsync(J.pcm_host, pcm_dev, floats * 4, hipMemcpyDeviceToHost, st_codec_));
+            Q3_HIP(hipMemcpyAsync(J.pcm_host, pcm_dev, floats * 4, hipMemcpyDeviceToHost, cst));
         }
         J.decoded = true;
     }
-    Q3_HIP(hipEventRecord(J.ev_codec[1], st_codec_));
+    Q3_HIP(hipEventRecord(J.ev_codec[1], cst));
     J.timing = q3tts_timing{};
     float ms = 0;
     Q3_HIP(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
@@ -1326,15 +1341,16 @@ void Engine::codec_decode(const int32_t* codes, const int32_t* n_frames, int bat
         Fmax = std::max(Fmax, n_frames[b]);
     }
     float* pcm_dev = nullptr;
-    Q3_HIP(hipEventRecord(ev_[2], st_codec_));
+    hipStream_t cst = codec_stream(false);
+    Q3_HIP(hipEventRecord(ev_[2], cst));
     try {
         if (Fmax > 0) codec_->decode(dcodes, max_frames, frames, &pcm_dev);
     } catch (...) {
         (void)hipFree(dcodes);
         throw;
     }
-    Q3_HIP(hipEventRecord(ev_[3], st_codec_));
-    Q3_HIP(hipStreamSynchronize(st_codec_));
+    Q3_HIP(hipEventRecord(ev_[3], cst));
+    Q3_HIP(hipStreamSynchronize(cst));
     float ms = 0;
     Q3_HIP(hipEventElapsedTime(&ms, ev_[2], ev_[3]));
     timing.codec_ms = ms;
@@ -1357,6 +1373,7 @@ void Engine::debug_codec_stage(const int32_t* codes, int n_frames, const char* s
     Q3_HIP(hipMemcpy(dcodes, codes, size_t(n_frames) * 16 * 4, hipMemcpyHostToDevice));
     std::vector<float> so;
     float* pcm_dev = nullptr;
+    (void)codec_stream(false);
     try {
         codec_->decode(dcodes, n_frames, {n_frames}, &pcm_dev, stage, &so, T, C);
     } catch (...) {
@@ -1395,7 +1412,7 @@ int EngineGroup::begin(const q3tts_request* reqs, int n, const q3tts_sampling& s
         Engine& e = *lanes_[0];
         e.row_offset = 0;
         e.request_base = 0;
-        return e.begin(reqs, n, sp, cb, user, nullptr);
+        return e.begin(reqs, n, sp, cb, user, nullptr, true);
     }
     int slot = -1;
     for (int i = 0; i < Engine::kJobSlots; ++i)

@@ -62,7 +62,8 @@ class Engine {
     // may run between the two: its AR loop (a latency-bound chain that leaves the matrix cores idle) then overlaps the
     // first job's decode (matrix-core bound). Jobs end in begin order; at most kJobSlots are outstanding.
     static constexpr int kJobSlots = 2;
-    int begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3tts_event_cb cb, void* user, const DebugOpts* dbg);
+    int begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3tts_event_cb cb, void* user, const DebugOpts* dbg,
+              bool overlapped);  // overlapped: another batch's AR loop is expected to run beside this one's decode
     void end(int job, q3tts_result* results);
     void debug_prepare_inputs(const q3tts_request& req, uint16_t* input_embeds, int cap_prompt, int* n_prompt,
                               uint16_t* trailing, int cap_trailing, int* n_trailing, uint16_t* tts_pad);
@@ -90,7 +91,9 @@ class Engine {
   private:
     q3tts_load_opts opts_;
     hipStream_t st_ = nullptr;
-    hipStream_t st_codec_ = nullptr;  // codec decode of a finished batch, lower priority than st_
+    hipStream_t st_codec_ = nullptr;       // codec decode that nothing overlaps (lower priority than st_)
+    hipStream_t st_codec_part_ = nullptr;  // codec decode beside the next batch's AR loop: confined to half of the CUs
+    hipStream_t codec_stream(bool overlapped);
     hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t burst_ev_[2] = {nullptr, nullptr};
     hipEvent_t ev_fe_[2] = {nullptr, nullptr};

@@ -187,17 +187,18 @@ class Qwen3TTSModel:
         ("token", id) / ("info", AudioGenerationInfo) / ("audio", ndarray) in the reference's order; with
         audio_chunk_frames > 0 also ("audio_chunk", (sample_offset, ndarray)) pieces of the final audio, in order,
         between the last token and info (the decoder's causal tail run chunk by chunk; same samples)."""
-        return self.generate_batch_end(self.generate_batch_begin(reqs, temperature, top_k, top_p, repetition_penalty, seed,
-                                                                 force_frames, on_event, audio_chunk_frames))
-
-    def generate_batch_begin(self, reqs: Sequence[GenerationRequest], temperature: float = 0.9, top_k: int = 50,
-                             top_p: float = 1.0, repetition_penalty: float = 1.05, seed: int = 0, force_frames: int = 0,
-                             on_event: Optional[Callable[[int, str, object], None]] = None, audio_chunk_frames: int = 0):
-        """First half of generate_batch (q3tts_generate_begin): returns a job once the AR loop has produced the codes and
-        their codec decode is queued. The next batch may be begun before this one is ended: its AR loop then overlaps
-        this batch's decode. At most two jobs may be outstanding."""
         arr, keep = self._marshal(reqs)
         s = self._sampling(temperature, top_k, top_p, repetition_penalty, seed, force_frames, audio_chunk_frames)
+        cb = self._event_cb(on_event)
+        res = (L.Result * len(reqs))()
+        st = self._lib.q3tts_generate(self._h, arr, len(reqs), C.byref(s), cb, None, res)
+        del keep
+        return self._collect(st, res, len(reqs))
+
+    @staticmethod
+    def _event_cb(on_event):
+        if not on_event:
+            return C.cast(None, L.EVENT_CB)
 
         def _cb(_user, evp):
             ev = evp.contents
@@ -214,16 +215,9 @@ class Qwen3TTSModel:
             else:
                 on_event(ev.request_index, "audio", np.ctypeslib.as_array(ev.pcm, shape=(ev.n_samples,)).copy())
 
-        cb = L.EVENT_CB(_cb) if on_event else C.cast(None, L.EVENT_CB)
-        job = C.c_void_p()
-        self._check(self._lib.q3tts_generate_begin(self._h, arr, len(reqs), C.byref(s), cb, None, C.byref(job)))
-        del keep  # request memory is only read during begin
-        return (job, len(reqs), cb)  # the callback object must outlive the job (INFO / AUDIO fire in end)
+        return L.EVENT_CB(_cb)
 
-    def generate_batch_end(self, job) -> List[GenerationResult]:
-        handle, n, _cb = job
-        res = (L.Result * n)()
-        st = self._lib.q3tts_generate_end(self._h, handle, res)
+    def _collect(self, st, res, n) -> List[GenerationResult]:
         try:
             self._check(st)
             out = []
@@ -242,6 +236,25 @@ class Qwen3TTSModel:
             return out
         finally:
             self._lib.q3tts_result_free(res, n)
+
+    def generate_batch_begin(self, reqs: Sequence[GenerationRequest], temperature: float = 0.9, top_k: int = 50,
+                             top_p: float = 1.0, repetition_penalty: float = 1.05, seed: int = 0, force_frames: int = 0,
+                             on_event: Optional[Callable[[int, str, object], None]] = None, audio_chunk_frames: int = 0):
+        """First half of generate_batch (q3tts_generate_begin): returns a job once the AR loop has produced the codes and
+        their codec decode is queued. The next batch may be begun before this one is ended: its AR loop then overlaps
+        this batch's decode. At most two jobs may be outstanding."""
+        arr, keep = self._marshal(reqs)
+        s = self._sampling(temperature, top_k, top_p, repetition_penalty, seed, force_frames, audio_chunk_frames)
+        cb = self._event_cb(on_event)
+        job = C.c_void_p()
+        self._check(self._lib.q3tts_generate_begin(self._h, arr, len(reqs), C.byref(s), cb, None, C.byref(job)))
+        del keep  # request memory is only read during begin
+        return (job, len(reqs), cb)  # the callback object must outlive the job (INFO / AUDIO fire in end)
+
+    def generate_batch_end(self, job) -> List[GenerationResult]:
+        handle, n, _cb = job
+        res = (L.Result * n)()
+        return self._collect(self._lib.q3tts_generate_end(self._h, handle, res), res, n)
 
     def _request_from_text(self, text, speaker, instruct, language, max_tokens, text_ids, instruct_ids,
                            target_token_count) -> GenerationRequest:
