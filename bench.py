@@ -264,9 +264,9 @@ def main():
             if trace:
                 print(f"[trace] {what} {1e3 * (time.perf_counter() - t):.1f} ms", file=sys.stderr)
             return r
-        job = timed("begin", model.generate_batch_begin, reqs, **gen_kw)
-        for _ in range(args.steps - 1):
-            nxt = timed("begin", model.generate_batch_begin, reqs, **gen_kw)
+        job = timed("begin", model.generate_batch_begin, reqs, more_follows=(args.steps > 1), **gen_kw)
+        for i in range(args.steps - 1):
+            nxt = timed("begin", model.generate_batch_begin, reqs, more_follows=(i + 2 < args.steps), **gen_kw)
             account(timed("end", model.generate_batch_end, job))
             job = nxt
         account(timed("end", model.generate_batch_end, job))

@@ -182,10 +182,14 @@ void q3tts_result_free(q3tts_result* results, int32_t n);
  *          releases the job.
  * A second begin may be issued before the first job's end: its AR loop (a latency-bound chain of small launches) then
  * overlaps the first job's decode (matrix-core work). At most 2 jobs may be outstanding per model handle; results do
- * not depend on the interleaving (the decode reads job-owned copies of the codes). q3tts_generate == begin + end. */
+ * not depend on the interleaving (the decode reads job-owned copies of the codes). q3tts_generate == begin + end.
+ * `more_follows` != 0 says that another begin will be issued before this job's end: the decode is then confined to part
+ * of the chip so that the next batch's launch chain keeps room (a decode that fills every CU stalls that chain and
+ * nothing is gained); 0 (the last batch of a queue) lets the decode use the whole chip. Results do not depend on it. */
 typedef struct q3tts_job q3tts_job;
 q3tts_status q3tts_generate_begin(q3tts_model* m, const q3tts_request* reqs, int32_t n_reqs,
-                                  const q3tts_sampling* sampling, q3tts_event_cb cb, void* user, q3tts_job** job);
+                                  const q3tts_sampling* sampling, q3tts_event_cb cb, void* user, int32_t more_follows,
+                                  q3tts_job** job);
 q3tts_status q3tts_generate_end(q3tts_model* m, q3tts_job* job, q3tts_result* results);
 
 /* Qwen3TTSSpeechTokenizer.decode (Models/SpeechTokenizer.swift:823-836): codes

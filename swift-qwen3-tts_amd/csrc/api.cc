@@ -153,7 +153,7 @@ struct q3tts_job {
 };
 
 q3tts_status q3tts_generate_begin(q3tts_model* m, const q3tts_request* reqs, int32_t n_reqs, const q3tts_sampling* sampling,
-                                  q3tts_event_cb cb, void* user, q3tts_job** job) {
+                                  q3tts_event_cb cb, void* user, int32_t more_follows, q3tts_job** job) {
     return guarded(m, [&] {
         Q3_CHECK(m && reqs && job, 3, "Invalid input: null argument");
         *job = nullptr;
@@ -161,7 +161,7 @@ q3tts_status q3tts_generate_begin(q3tts_model* m, const q3tts_request* reqs, int
         if (sampling) sp = *sampling;
         else q3tts_default_sampling(&sp);
         auto j = std::make_unique<q3tts_job>();
-        j->slot = m->eng->begin(reqs, n_reqs, sp, cb, user);
+        j->slot = m->eng->begin(reqs, n_reqs, sp, cb, user, more_follows != 0);
         j->n = n_reqs;
         *job = j.release();
     });

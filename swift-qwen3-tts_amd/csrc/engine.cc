@@ -266,7 +266,11 @@ void Engine::enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, 
     // with the row blocks per workgroup (0.8-1.3 us). Against a separate row-norm launch (4.5 us) it wins at both widths
     // since the norm-prologue kernels request x before the weight tiles, take at most two row blocks per workgroup and
     // the 6144-wide gate/up runs as one round of workgroups (gemm_decode.hip); wider stacks keep the row-norm kernel.
-    const bool prologue_qkv = H <= 2048, prologue_mlp = H <= 2048;
+    // Above 64 rows per launch (prefill chunks) the prologue is repeated by (column tiles x row-block groups) workgroups --
+    // 2048 of them for a 6144-wide gate/up at 256 rows, ~3 us of SIMD time each -- so the rows are normalised once by
+    // the row kernel instead, from the SAME per-tile partials in the same order (NormRowsArgs::ss_in): bit-identical.
+    const bool row_norm = M > 64;
+    const bool prologue_qkv = H <= 2048 && !row_norm, prologue_mlp = H <= 2048 && !row_norm;
     // The talker's layer weights and KV cache are read once per frame step out of gigabytes; the code predictor's
     // 0.22 GB are read fifteen times per step. Non-temporal loads on the former leave the Infinity Cache (256 MB) to the
     // latter: measured 3.53 -> 3.42 ms per 1.7B frame step with both (either one alone: < 1 %; on the predictor's
@@ -275,14 +279,15 @@ void Engine::enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, 
     const bool is_talker = &s == &m_->talker;
     const int ntw = is_talker && !nt_off ? 1 : 0;
     const int ntkv = ntw;
-    auto norm_into_xn = [&](const uint16_t* nw) {
+    auto norm_into_xn = [&](const uint16_t* nw, const float* ss, int ss_count) {
         NormRowsArgs n{};
         n.h = w.h; n.hMB = MBL; n.w = nw; n.eps = s.eps; n.out = w.xn; n.outMB = MBL; n.M = M; n.H = H;
+        if (row_norm && H <= 2048) { n.ss_in = ss; n.ss_count = ss_count; n.ss_ld = Mp_; }
         launch_norm_rows(n, st_);
     };
     for (size_t l = 0; l < s.layers.size(); ++l) {
         const LayerW& L = s.layers[l];
-        if (!prologue_qkv) norm_into_xn(L.ln1);
+        if (!prologue_qkv) norm_into_xn(L.ln1, w.ss_a, (l == 0) ? ss_count_in : tiles);
         GemmArgs q = gemm_args(L.qkv, prologue_qkv ? w.h : w.xn, M);
         q.epi = 0; q.y = w.qkv; q.ldy = w.ld_qkv; q.nt_weights = ntw;
         if (prologue_qkv) {
@@ -303,7 +308,7 @@ void Engine::enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, 
         GemmArgs o = gemm_args(L.o, w.ao, M);
         o.epi = 3; o.y = w.h; o.yMB = MBL; o.resid = 1; o.ss_out = w.ss_b; o.nt_weights = ntw;
         launch_gemm_skinny(o, st_);
-        if (!prologue_mlp) norm_into_xn(L.ln2);
+        if (!prologue_mlp) norm_into_xn(L.ln2, w.ss_b, tiles);
         GemmArgs g = gemm_args(L.gateup, prologue_mlp ? w.h : w.xn, M);
         g.epi = 2; g.y = w.act; g.yMB = MBL; g.nt_weights = ntw;
         if (prologue_mlp) {
@@ -1406,13 +1411,13 @@ EngineGroup::EngineGroup(std::unique_ptr<Model> model, const q3tts_load_opts& op
     speakers = lanes_[0]->speakers;
 }
 
-int EngineGroup::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3tts_event_cb cb, void* user) {
+int EngineGroup::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3tts_event_cb cb, void* user, bool more_follows) {
     Q3_CHECK(n >= 1 && n <= opts_.max_batch, 3, "Invalid input: batch size must be between 1 and max_batch");
     if (lanes_.size() == 1) {
         Engine& e = *lanes_[0];
         e.row_offset = 0;
         e.request_base = 0;
-        return e.begin(reqs, n, sp, cb, user, nullptr, true);
+        return e.begin(reqs, n, sp, cb, user, nullptr, more_follows);
     }
     int slot = -1;
     for (int i = 0; i < Engine::kJobSlots; ++i)

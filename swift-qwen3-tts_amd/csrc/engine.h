@@ -215,7 +215,7 @@ class EngineGroup {
     void generate(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3tts_event_cb cb, void* user,
                   q3tts_result* results, const DebugOpts* dbg);
     // Two-deep pipeline (Engine::begin / end). With more than one lane a job runs to completion inside begin.
-    int begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3tts_event_cb cb, void* user);
+    int begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3tts_event_cb cb, void* user, bool more_follows);
     void end(int job, q3tts_result* results);
     std::string last_error;
     q3tts_timing timing{};

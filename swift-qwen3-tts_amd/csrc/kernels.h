@@ -48,6 +48,10 @@ struct NormRowsArgs {
     int outMB;
     float* ss_out;      // [ss_ld]: sum(out^2) per row (first partial of the consumer's norm) or nullptr
     int M, H;
+    // optional: sum(h^2) per row from the producer's per-tile partials [ss_count][ss_ld], added up exactly as the GEMM's
+    // norm prologue adds them (gemm_body.inc), so that this kernel + a GEMM without prologue == the GEMM with it, bit for bit
+    const float* ss_in;
+    int ss_count, ss_ld;
 };
 void launch_norm_rows(const NormRowsArgs& a, hipStream_t st);
 

@@ -50,6 +50,14 @@ void launch_mb(const GemmArgs& a, int split, hipStream_t st) {
     const int tiles = EPI == 2 ? a.N / 8 : a.N / 16;  // EPI 2: eight columns per (gate | up) tile
 #define Q3_GEMM(NWv, CHv) \
     hipLaunchKernelGGL((gemm_skinny_kernel<MB, EPI, NWv, CHv, NORM, QUANT, 1, NTW>), dim3(tiles, split), dim3(NWv * 64), 0, st, a)
+    if constexpr (MB == 4 && !NORM && !NTW) {
+        // prefill chunks: four tiles per workgroup through the chunk-streaming form (CH = 0)
+        static const bool one_tile = std::getenv("Q3TTS_GEMM_ONE_PAIR") != nullptr;
+        if (!one_tile && nw == 8 && tiles >= 64) {
+            hipLaunchKernelGGL((gemm_skinny_kernel<4, EPI, 8, 0, false, QUANT, 4, false>), dim3((tiles + 3) / 4, split), dim3(512), 0, st, a);
+            return;
+        }
+    }
     if constexpr (EPI == 2 && MB <= 2) {
         // gate/up tiles are self-contained, so a workgroup takes as many as it needs for the launch to be ONE round of at
         // most 256 workgroups: 768 tiles (6144 columns) -> 3 each, 384 (3072) -> 2 each

@@ -20,6 +20,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {
 //   out <- bf16( bf16(h * rstd) * w )            MLXNN.RMSNorm, Talker.swift:520,573
 __global__ __launch_bounds__(256) void norm_rows_kernel(NormRowsArgs a) {
     __shared__ float sh[4];
+    __shared__ float parts[8];
     constexpr int kTrips = 2;  // H <= 4096
     const int m = blockIdx.x, tid = threadIdx.x;
     float v[kTrips][8];
@@ -40,7 +41,20 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(NormRowsArgs a) {
             }
         }
     }
-    const float tot = block_sum_256(ss, sh);
+    float tot;
+    if (a.ss_in) {  // the prologue's order: eight strided partial sums, then those eight in order
+        if (tid < 8) {
+            float s = 0.f;
+            for (int j = tid; j < a.ss_count; j += 8) s += a.ss_in[(size_t)j * a.ss_ld + m];
+            parts[tid] = s;
+        }
+        __syncthreads();
+        tot = 0.f;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) tot += parts[p];
+    } else {
+        tot = block_sum_256(ss, sh);
+    }
     const float rstd = 1.0f / sqrtf(tot / (float)a.H + a.eps);
     float so = 0.f;
 #pragma unroll

@@ -96,7 +96,7 @@ def lib() -> C.CDLL:
     L.q3tts_model_speaker_name.restype = C.c_char_p
     L.q3tts_generate.argtypes = [vp, C.POINTER(Request), C.c_int32, C.POINTER(Sampling), EVENT_CB, vp,
                                  C.POINTER(Result)]
-    L.q3tts_generate_begin.argtypes = [vp, C.POINTER(Request), C.c_int32, C.POINTER(Sampling), EVENT_CB, vp, C.POINTER(vp)]
+    L.q3tts_generate_begin.argtypes = [vp, C.POINTER(Request), C.c_int32, C.POINTER(Sampling), EVENT_CB, vp, C.c_int32, C.POINTER(vp)]
     L.q3tts_generate_end.argtypes = [vp, vp, C.POINTER(Result)]
     L.q3tts_pcm_to_int16.argtypes = [f32p, C.c_int64, C.POINTER(C.c_int16)]
     L.q3tts_pcm_to_int16.restype = None

@@ -239,15 +239,18 @@ class Qwen3TTSModel:
 
     def generate_batch_begin(self, reqs: Sequence[GenerationRequest], temperature: float = 0.9, top_k: int = 50,
                              top_p: float = 1.0, repetition_penalty: float = 1.05, seed: int = 0, force_frames: int = 0,
-                             on_event: Optional[Callable[[int, str, object], None]] = None, audio_chunk_frames: int = 0):
+                             on_event: Optional[Callable[[int, str, object], None]] = None, audio_chunk_frames: int = 0,
+                             more_follows: bool = True):
         """First half of generate_batch (q3tts_generate_begin): returns a job once the AR loop has produced the codes and
         their codec decode is queued. The next batch may be begun before this one is ended: its AR loop then overlaps
-        this batch's decode. At most two jobs may be outstanding."""
+        this batch's decode. At most two jobs may be outstanding. more_follows=False (the last batch of a queue) lets the
+        decode use the whole chip instead of leaving room for a next batch."""
         arr, keep = self._marshal(reqs)
         s = self._sampling(temperature, top_k, top_p, repetition_penalty, seed, force_frames, audio_chunk_frames)
         cb = self._event_cb(on_event)
         job = C.c_void_p()
-        self._check(self._lib.q3tts_generate_begin(self._h, arr, len(reqs), C.byref(s), cb, None, C.byref(job)))
+        self._check(self._lib.q3tts_generate_begin(self._h, arr, len(reqs), C.byref(s), cb, None, 1 if more_follows else 0,
+                                                   C.byref(job)))
         del keep  # request memory is only read during begin
         return (job, len(reqs), cb)  # the callback object must outlive the job (INFO / AUDIO fire in end)
 

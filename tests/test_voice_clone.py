@@ -498,3 +498,25 @@ def test_gpu_matches_voice_clone_golden(engine_base):
         assert (res.codes[:, 0] == g["clone_codes"][:, 0]).mean() >= 0.8
         if (res.codes == g["clone_codes"]).all():
             assert res.audio.shape == g["clone_pcm"].shape and np.abs(res.audio - g["clone_pcm"]).max() < 2e-4
+
+
+@pytest.mark.gpu
+def test_gpu_clone_audio_chunks_skip_the_reference_part(engine_base):
+    """Chunked delivery (q3tts_sampling.audio_chunk_frames) on voice-clone rows: the decoder runs over [reference ++
+    generated] frames (Qwen3.swift:1176-1186) and the reference's share of the samples is cut proportionally (:1195-1199);
+    the chunks must carry exactly the remaining audio, in order, and a mixed batch must work."""
+    from qwen3tts import GenerationRequest
+    reqs = []
+    for row, sec in ((0, 0.9), (1, 0.4)):
+        pr = clone_prompt(row, 7)
+        reqs.append(GenerationRequest(pr["text_ids"], pr["target_token_count"], None, None, "english",
+                                      ref_audio=ref_audio(row, sec), ref_text_ids=pr["ref_text_ids"]))
+    kw = dict(temperature=0.9, top_k=50, repetition_penalty=1.5, seed=4, force_frames=14)
+    want = engine_base.generate_batch(reqs, **kw)
+    pieces = {0: [], 1: []}
+    got = engine_base.generate_batch(reqs, audio_chunk_frames=6,
+                                     on_event=lambda i, k, p: pieces[i].append(p) if k == "audio_chunk" else None, **kw)
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert a.status == 0 and (a.codes == b.codes).all() and (a.audio == b.audio).all()
+        assert pieces[i][0][0] == 0 and (np.concatenate([p for _, p in pieces[i]]) == b.audio).all()
+        assert b.audio.size < (14 + 12) * 1920   # the reference's frames are not part of the result
