@@ -56,6 +56,9 @@ Engine::Engine(Model* model, const q3tts_load_opts& opts) : m_(model), opts_(opt
         cus = std::min(cus, prop.multiProcessorCount) / 8 * 8;
         if (cus > 0 && cus < prop.multiProcessorCount) {
             std::vector<uint32_t> mask(size_t(ceil_div(prop.multiProcessorCount, 32)), 0u);
+            // mask bit i = CU (i / 8) of XCD (i % 8), CUs of an XCD numbered round-robin over its shader engines: the first
+            // half of the bits is half of every shader engine of every XCD. (Every other CU instead -- whole shader
+            // engines -- left the AR chain's workgroups queueing on the busy engines: 1008 against 807 ms per step.)
             for (int i = 0; i < cus; ++i) mask[size_t(i / 32)] |= 1u << (i % 32);
             Q3_HIP(hipExtStreamCreateWithCUMask(&st_codec_part_, uint32_t(mask.size()), mask.data()));
         }
