@@ -23,6 +23,7 @@ namespace {
 
 template <int REP, int NTH, bool NTKV = false>
 __global__ __launch_bounds__(NTH) void attn_decode_kernel(AttnArgs a) {
+    __builtin_amdgcn_s_setprio(3);
     attn_decode_body<REP, NTH, NTKV>(a, blockIdx.x, blockIdx.y);
 }
 
@@ -34,6 +35,7 @@ __global__ __launch_bounds__(NTH) void attn_decode_kernel(AttnArgs a) {
 // would if the elements arrived one launch at a time, so the results do not depend on where a chunk boundary falls.
 template <int REP, int NTH, int CMAX>
 __global__ __launch_bounds__(NTH) void attn_chunk_kernel(AttnArgs a) {
+    __builtin_amdgcn_s_setprio(3);
     constexpr int NG = NTH / 16;
     constexpr int NWV = NTH / 64;
     __shared__ __attribute__((aligned(16))) float q_s[CMAX][REP][D];

@@ -39,6 +39,7 @@ namespace {
 
 template <int MB, int EPI, int NW, int CH, bool NORM, bool QUANT, int NP = 1, bool NTW = false>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
+    __builtin_amdgcn_s_setprio(3);  // the AR chain's waves go first where they share a CU with a codec decode (engine.cc)
     gemm_skinny_body<MB, EPI, NW, CH, NORM, QUANT, NP, NTW>(a, blockIdx.x, blockIdx.y * MB);
 }
 

@@ -154,6 +154,7 @@ __device__ Best block_argmax(Best x, Best* scratch) {
 }
 
 __global__ __launch_bounds__(kThreads) void sampler_kernel(SamplerArgs a) {
+    __builtin_amdgcn_s_setprio(3);
     __shared__ float vals[kMaxV];
     __shared__ uint32_t sortbuf[kMaxV];
     __shared__ float sval[kMaxV];   // surviving logits, compacted (indices in sortbuf)
