@@ -45,33 +45,64 @@ __device__ __forceinline__ float act_other(float v, int act) {
     }
 }
 
-// Four consecutive output channels n..n+3 of position t: + bias, activation, scale, + residual -> out; and, when the
+// Epilogue of a 64-position x CT*16-channel wave tile: + bias, activation, scale, + residual -> out; and, when the
 // consumer of this tensor is a conv behind a SnakeBeta (DecoderResidualUnit act1/act2, DecoderBlock snake:
-// SpeechTokenizer.swift:430-437, 474-475), the activated copy -> out2, so that each element goes through sinf once
-// here instead of once per output-channel tile (and halo overlap) in the consumer's staging loop.
-__device__ __forceinline__ void epilogue4(const ConvGemmArgs& a, int b, int t, int n, f32x4& accv) {
-    float v[4] = {accv[0], accv[1], accv[2], accv[3]};
-    if (a.bias) {
-        const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
-        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-    }
-    if (a.act == 1) {
+// SpeechTokenizer.swift:430-437, 474-475), the activated copy -> out2 (snake_pass), so that each element goes through
+// sinf once here instead of once per output-channel tile (and halo overlap) in the consumer's staging loop.
+// Lane: channels n..n+3 (rows of D), n = n_w + 16 c + 4 (lane >> 4), of positions t = t_w + 16 p + (lane & 15).
+// Written in phases -- every bias / scale / residual request first, arithmetic and stores after the last of them --
+// because out and res may alias as far as the compiler knows: per (p, c) block it had emitted load-wait-...-store, up to
+// 3 x 16 dependent memory round trips per thread, which was most of a K = 1 launch's time (ACT: activation code compiled in).
+template <int CT, bool ACT>
+__device__ __forceinline__ void epilogue_tile(const ConvGemmArgs& a, int b, int t_w, int n_w, int T, int lane, f32x4 (&acc)[4][CT]) {
+    const int nq = n_w + 4 * (lane >> 4);
+    float4 bv[CT], sv[CT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
-    } else if (a.act != 0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = act_other(v[j], a.act);
+    for (int c = 0; c < CT; ++c) {
+        const int n = nq + 16 * c;
+        bv[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        sv[c] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (a.bias && n < a.N) bv[c] = *reinterpret_cast<const float4*>(a.bias + n);
+        if (a.scale && n < a.N) sv[c] = *reinterpret_cast<const float4*>(a.scale + n);
     }
-    if (a.scale) {
-        const float4 sv = *reinterpret_cast<const float4*>(a.scale + n);
-        v[0] *= sv.x; v[1] *= sv.y; v[2] *= sv.z; v[3] *= sv.w;
-    }
+    float4 rv[4][CT];
     if (a.res) {
-        const float4 rv = *reinterpret_cast<const float4*>(a.res + (size_t)b * a.res_bstride + (size_t)t * a.ldr + n);
-        v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+        const float* rb = a.res + (size_t)b * a.res_bstride;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int t = t_w + 16 * p + (lane & 15);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const int n = nq + 16 * c;
+                rv[p][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t < T && n < a.N) rv[p][c] = *reinterpret_cast<const float4*>(rb + (size_t)t * a.ldr + n);
+            }
+        }
     }
-    if (a.out) *reinterpret_cast<float4*>(a.out + (size_t)b * a.out_bstride + (size_t)t * a.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
-    accv = f32x4{v[0], v[1], v[2], v[3]};  // kept for snake_pass
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int t = t_w + 16 * p + (lane & 15);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int n = nq + 16 * c;
+            float v[4] = {acc[p][c][0], acc[p][c][1], acc[p][c][2], acc[p][c][3]};
+            if (a.bias) { v[0] += bv[c].x; v[1] += bv[c].y; v[2] += bv[c].z; v[3] += bv[c].w; }
+            if constexpr (ACT) {
+                if (a.act == 1) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
+                } else if (a.act != 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = act_other(v[j], a.act);
+                }
+            }
+            if (a.scale) { v[0] *= sv[c].x; v[1] *= sv[c].y; v[2] *= sv[c].z; v[3] *= sv[c].w; }
+            if (a.res) { v[0] += rv[p][c].x; v[1] += rv[p][c].y; v[2] += rv[p][c].z; v[3] += rv[p][c].w; }
+            if (a.out && t < T && n < a.N)
+                *reinterpret_cast<float4*>(a.out + (size_t)b * a.out_bstride + (size_t)t * a.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+            acc[p][c] = f32x4{v[0], v[1], v[2], v[3]};  // kept for snake_pass
+        }
+    }
 }
 
 // Second output: SnakeBeta of the finished tile. The accumulators are parked in LDS (each lane its own slots, so no
@@ -266,18 +297,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
         }
     }
 
-    // epilogue: lane holds channels n..n+3 (rows of D) of position t (column of D)
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int t = t0 + wm * 64 + p * 16 + (lane & 15);
-        if (t >= T) continue;
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            const int n = n0 + wn * (BN / 2) + c * 16 + 4 * (lane >> 4);
-            if (n >= a.N) continue;
-            epilogue4(a, b, t, n, acc[p][c]);
-        }
-    }
+    epilogue_tile<CT, true>(a, b, t0 + wm * 64, n0 + wn * (BN / 2), T, lane, acc);
     if (a.out2) snake_pass<CT>(a, smem, b, t0, n0, wn, T, wave, lane, acc, wm);
 }
 
@@ -452,17 +472,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvGemmArgs a)
         }
     }
 
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int t = t0 + wm * 64 + p * 16 + (lane & 15);
-        if (t >= T) continue;
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            const int n = n0 + wn * (BN / 2) + c * 16 + 4 * (lane >> 4);
-            if (n >= a.N) continue;
-            epilogue4(a, b, t, n, acc[p][c]);
-        }
-    }
+    if (a.act != 0) epilogue_tile<CT, true>(a, b, t0 + wm * 64, n0 + wn * (BN / 2), T, lane, acc);
+    else epilogue_tile<CT, false>(a, b, t0 + wm * 64, n0 + wn * (BN / 2), T, lane, acc);
     if (a.out2) snake_pass<CT>(a, reinterpret_cast<float*>(smem3), b, t0, n0, wn, T, wave, lane, acc, wm);
 }
 
@@ -692,6 +703,20 @@ __global__ __launch_bounds__(256, 2) void resunit_split_kernel(ResUnitArgs a) {
     }
 
     // ---- + bias2 + y -> out; optionally the next block's SnakeBeta of the sum -> out2 ----
+    // (every residual request before the first store: out and y could alias as far as the compiler knows, and it had
+    // emitted one load-wait-store round trip per accumulator tile)
+    float4 rvs[2][CT2], bv2[CT2];
+#pragma unroll
+    for (int c = 0; c < CT2; ++c) bv2[c] = a.b2 ? *reinterpret_cast<const float4*>(a.b2 + 16 * c + q4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int t = t0 + 32 * wave + 16 * p + (lane & 15);
+#pragma unroll
+        for (int c = 0; c < CT2; ++c) {
+            rvs[p][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < T) rvs[p][c] = *reinterpret_cast<const float4*>(yb + (size_t)t * C + 16 * c + q4);
+        }
+    }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int t = t0 + 32 * wave + 16 * p + (lane & 15);
@@ -699,10 +724,10 @@ __global__ __launch_bounds__(256, 2) void resunit_split_kernel(ResUnitArgs a) {
 #pragma unroll
         for (int c = 0; c < CT2; ++c) {
             const int n = 16 * c + q4;
-            const float4 rv = *reinterpret_cast<const float4*>(yb + (size_t)t * C + n);
+            const float4 rv = rvs[p][c];
             float4 v = make_float4(acc2[p][c][0] + rv.x, acc2[p][c][1] + rv.y, acc2[p][c][2] + rv.z, acc2[p][c][3] + rv.w);
             if (a.b2) {
-                const float4 bv = *reinterpret_cast<const float4*>(a.b2 + n);
+                const float4 bv = bv2[c];
                 v = make_float4((acc2[p][c][0] + bv.x) + rv.x, (acc2[p][c][1] + bv.y) + rv.y, (acc2[p][c][2] + bv.z) + rv.z,
                                 (acc2[p][c][3] + bv.w) + rv.w);
             }

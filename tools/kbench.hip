@@ -34,7 +34,7 @@ int main(int argc, char** argv) {
         {"cp gateup+nrm", 3072, 1024, 2, 1}, {"cp down epi3 ", 1024, 3072, 3, 0}, {"cp head +norm", 2048, 1024, 0, 1},
         {"cp proj epi3 ", 1024, 2048, 3, 0}};
     const int Mp = (M + 15) / 16 * 16;
-    const int copies = 24;  // rotate weight copies so the Infinity Cache does not serve them
+    const int copies = argc > 3 ? atoi(argv[3]) : 24;  // rotate weight copies so the Infinity Cache does not serve them (1: warm)
     for (auto& s : shapes) {
         const int rows = (s.epi == 2 ? 2 * s.N : s.N);
         size_t welems = (size_t)rows * s.K;
