@@ -91,6 +91,18 @@ Engine::Engine(Model* model, const q3tts_load_opts& opts) : m_(model), opts_(opt
 }
 
 Engine::~Engine() {
+    if (stager_.joinable()) {
+        {
+            std::lock_guard<std::mutex> lk(stage_mu_);
+            stage_stop_ = true;
+        }
+        stage_cv_.notify_all();
+        stager_.join();
+    }
+    for (auto& J : jobs_) {  // rows staged for a job that was never ended
+        for (float* p : J.st_pcm) std::free(p);
+        for (int32_t* p : J.st_codes) std::free(p);
+    }
     for (auto& g : graphs_) (void)hipGraphExecDestroy(g.second);
     codec_.reset();
     fe_.reset();
@@ -1168,18 +1180,26 @@ int Engine::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3
     J.request_base = request_base;
     J.seq = job_seq_++;
     J.busy = true;
+    compute_cuts(J);
+    {
+        std::lock_guard<std::mutex> lk(stage_mu_);
+        J.stage_err.clear();
+        J.stage = (overlapped && J.decoded) ? 1 : 0;  // a pipelined job: its rows are copied out while the next batch runs
+        if (J.stage == 1) {
+            if (!stager_.joinable()) stager_ = std::thread([this] { staging_loop(); });
+            stage_cv_.notify_all();
+        }
+    }
     return slot;
 }
 
-void Engine::end(int job, q3tts_result* results) {
-    Q3_CHECK(job >= 0 && job < kJobSlots && jobs_[job].busy, 3, "Invalid input: no such outstanding job");
-    Job& J = jobs_[job];
-    Q3_HIP(hipSetDevice(m_->device));
-    const int n = J.n, up = J.up, Fdec = J.Fdec;
-    // samples [cut, cut + ns) of row b's decoded stream are its audio: audioLengths = count(code0 > 0) * 1920, trimmed
-    // when 0 < valid < len (SpeechTokenizer.swift:831-833, Qwen3.swift:954-959); clone rows lose the reference's share
-    // (Qwen3.swift:1195-1199, Float arithmetic)
-    std::vector<int64_t> row_cut((size_t)(n), 0), row_ns((size_t)(n), 0);
+// samples [cut, cut + ns) of row b's decoded stream are its audio: audioLengths = count(code0 > 0) * 1920, trimmed when
+// 0 < valid < len (SpeechTokenizer.swift:831-833, Qwen3.swift:954-959); clone rows lose the reference's share
+// (Qwen3.swift:1195-1199, Float arithmetic)
+void Engine::compute_cuts(Job& J) {
+    const int n = J.n, up = J.up;
+    J.row_cut.assign(size_t(n), 0);
+    J.row_ns.assign(size_t(n), 0);
     for (int b = 0; b < n; ++b) {
         const int F = J.frames[size_t(b)];
         if (F == 0 || !J.decoded) continue;
@@ -1196,9 +1216,62 @@ void Engine::end(int job, q3tts_result* results) {
             cut = int64_t(float(ref_T) / float(std::max(total_f, 1)) * float(ns));
             if (!(cut > 0 && cut < ns)) cut = 0;
         }
-        row_cut[size_t(b)] = cut;
-        row_ns[size_t(b)] = ns - cut;
+        J.row_cut[size_t(b)] = cut;
+        J.row_ns[size_t(b)] = ns - cut;
     }
+}
+
+void Engine::stage_rows(Job& J) {
+    Q3_HIP(hipSetDevice(m_->device));
+    Q3_HIP(hipEventSynchronize(J.ev_codec[1]));
+    const int n = J.n;
+    J.st_pcm.assign(size_t(n), nullptr);
+    J.st_codes.assign(size_t(n), nullptr);
+    for (int b = 0; b < n; ++b) {
+        const int F = J.frames[size_t(b)];
+        if (F == 0 || !J.decoded) continue;
+        const int64_t ns = J.row_ns[size_t(b)];
+        J.st_codes[size_t(b)] = static_cast<int32_t*>(std::malloc(size_t(F) * 16 * 4));
+        J.st_pcm[size_t(b)] = static_cast<float*>(std::malloc(std::max<size_t>(size_t(ns) * 4, 4)));
+        Q3_CHECK(J.st_codes[size_t(b)] && J.st_pcm[size_t(b)], 5, "out of host memory for the results");
+        std::memcpy(J.st_codes[size_t(b)], J.codes_host.data() + size_t(b) * Fcap_ * 16, size_t(F) * 16 * 4);
+        std::memcpy(J.st_pcm[size_t(b)], J.pcm_host + size_t(b) * J.Fdec * J.up + J.row_cut[size_t(b)], size_t(ns) * 4);
+    }
+}
+
+void Engine::staging_loop() {
+    std::unique_lock<std::mutex> lk(stage_mu_);
+    for (;;) {
+        Job* next = nullptr;
+        for (auto& J : jobs_)
+            if (J.stage == 1 && (!next || J.seq < next->seq)) next = &J;
+        if (!next) {
+            if (stage_stop_) return;
+            stage_cv_.wait(lk);
+            continue;
+        }
+        lk.unlock();
+        int state = 2;
+        std::string err;
+        try {
+            stage_rows(*next);
+        } catch (const std::exception& e) {
+            state = 3;
+            err = e.what();
+        }
+        lk.lock();
+        next->stage = state;
+        next->stage_err = err;
+        stage_cv_.notify_all();
+    }
+}
+
+void Engine::end(int job, q3tts_result* results) {
+    Q3_CHECK(job >= 0 && job < kJobSlots && jobs_[job].busy, 3, "Invalid input: no such outstanding job");
+    Job& J = jobs_[job];
+    Q3_HIP(hipSetDevice(m_->device));
+    const int n = J.n, up = J.up, Fdec = J.Fdec;
+    const std::vector<int64_t>&row_cut = J.row_cut, &row_ns = J.row_ns;
     if (J.n_chunks > 0 && J.cb) {  // AUDIO_CHUNK events as the tail of the decoder delivers them
         for (int k = 0; k < J.n_chunks; ++k) {
             Q3_HIP(hipEventSynchronize(J.chunk_done[size_t(k)]));
@@ -1218,8 +1291,27 @@ void Engine::end(int job, q3tts_result* results) {
             }
         }
     }
-    Q3_HIP(hipEventSynchronize(J.ev_codec[1]));
+    {
+        std::unique_lock<std::mutex> lk(stage_mu_);
+        stage_cv_.wait(lk, [&] { return J.stage != 1; });
+    }
+    if (J.stage == 0) {
+        try {
+            stage_rows(J);
+            J.stage = 2;
+        } catch (const std::exception& e) {
+            J.stage = 3;
+            J.stage_err = e.what();
+        }
+    }
     J.busy = false;
+    if (J.stage == 3) {
+        for (float* p : J.st_pcm) std::free(p);
+        for (int32_t* p : J.st_codes) std::free(p);
+        J.st_pcm.clear();
+        J.st_codes.clear();
+        throw Error(5, J.stage_err);
+    }
     float ms = 0;
     Q3_HIP(hipEventElapsedTime(&ms, J.ev_codec[0], J.ev_codec[1]));
     J.timing.codec_ms = ms;  // on the codec stream: includes whatever the next batch's AR loop took away from it
@@ -1242,14 +1334,13 @@ void Engine::end(int job, q3tts_result* results) {
             continue;
         }
         r.n_frames = F;
-        r.codes = static_cast<int32_t*>(std::malloc(size_t(F) * 16 * 4));
-        std::memcpy(r.codes, J.codes_host.data() + size_t(b) * Fcap_ * 16, size_t(F) * 16 * 4);
-        const int64_t ns = row_ns[size_t(b)], cut = row_cut[size_t(b)];
-        r.n_samples = ns;
-        r.pcm = static_cast<float*>(std::malloc(size_t(ns) * 4));
-        std::memcpy(r.pcm, J.pcm_host + size_t(b) * Fdec * up + cut, size_t(ns) * 4);
+        r.codes = J.st_codes[size_t(b)];  // ownership passes to the result (q3tts_result_free)
+        r.n_samples = row_ns[size_t(b)];
+        r.pcm = J.st_pcm[size_t(b)];
         r.status = Q3TTS_OK;
     }
+    J.st_pcm.clear();
+    J.st_codes.clear();
     if (J.cb) {
         std::unique_lock<std::mutex> lk;
         if (cb_mutex) lk = std::unique_lock<std::mutex>(*cb_mutex);

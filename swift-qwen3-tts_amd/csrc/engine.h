@@ -7,7 +7,9 @@
 #pragma once
 #include <map>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -155,7 +157,22 @@ class Engine {
         void* user = nullptr;
         int request_base = 0;
         bool decoded = false;
+        // results of the rows: cut computed when the codes are known; PCM and codes copied out of the job's buffers once
+        // the decode has finished -- by the staging thread for a pipelined job (so that end() hands over pointers while
+        // the next batch's frame loop keeps the device busy), inside end() otherwise
+        std::vector<int64_t> row_cut, row_ns;
+        std::vector<float*> st_pcm;
+        std::vector<int32_t*> st_codes;
+        int stage = 0;  // 0: not staged, 1: queued for the staging thread, 2: staged, 3: staging failed (stage_err)
+        std::string stage_err;
     } jobs_[kJobSlots];
+    void compute_cuts(Job& J);
+    void stage_rows(Job& J);   // waits for the decode, then copies; throws
+    void staging_loop();
+    std::thread stager_;
+    std::mutex stage_mu_;
+    std::condition_variable stage_cv_;
+    bool stage_stop_ = false;
     uint64_t job_seq_ = 0;
 
     unsigned long long* stamps_ = nullptr;  // Q3TTS_FRAME_STAMPS=1: [0] frame steps, [k] ticks of phase k, [63] last stamp
