@@ -2,7 +2,8 @@ import csv, collections, sys
 f=sys.argv[1]
 agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter()
 for r in csv.DictReader(open(f)):
-    k=(r["Kernel_Name"][:60], r.get("Grid_Size_X",""), r.get("Grid_Size_Y",""))
+    n=r["Kernel_Name"].replace("q3::(anonymous namespace)::","").replace("void ","")
+    k=(n.split("(")[0][:64],)  # keep the template arguments: they tell the K = 7 / K = 1 / fused variants apart
     agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); cnt[k]+=1
 rows=sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES",0))[:12]
 for k,v in rows:
