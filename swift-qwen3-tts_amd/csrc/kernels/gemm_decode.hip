@@ -55,7 +55,13 @@ void launch_mb(const GemmArgs& a, int split, hipStream_t st) {
         // prefill chunks: four tiles per workgroup through the chunk-streaming form (CH = 0)
         static const bool one_tile = std::getenv("Q3TTS_GEMM_ONE_PAIR") != nullptr;
         if (!one_tile && nw == 8 && tiles >= 64) {
-            hipLaunchKernelGGL((gemm_skinny_kernel<4, EPI, 8, 0, false, QUANT, 4, false>), dim3((tiles + 3) / 4, split), dim3(512), 0, st, a);
+            // four tiles per workgroup quarter the x traffic (every workgroup reads all K of its 64 rows), but a narrow layer
+            // (o_proj / down_proj: 128 tiles) is then 128 workgroups on 256 CUs: two tiles each there (prefill 17.0 -> 14.2 ms
+            // at 1.7B / batch 32; one tile each: 15.5)
+            if (((tiles + 3) / 4) * split <= 128)
+                hipLaunchKernelGGL((gemm_skinny_kernel<4, EPI, 8, 0, false, QUANT, 2, false>), dim3((tiles + 1) / 2, split), dim3(512), 0, st, a);
+            else
+                hipLaunchKernelGGL((gemm_skinny_kernel<4, EPI, 8, 0, false, QUANT, 4, false>), dim3((tiles + 3) / 4, split), dim3(512), 0, st, a);
             return;
         }
     }
