@@ -32,7 +32,9 @@ int main(int argc, char** argv) {
         {"tk head +norm", 3072, 2048, 0, 1},
         {"cp qkv  +norm", 4096, 1024, 0, 1}, {"cp qkv       ", 4096, 1024, 0, 0}, {"cp o    epi3 ", 1024, 2048, 3, 0},
         {"cp gateup+nrm", 3072, 1024, 2, 1}, {"cp down epi3 ", 1024, 3072, 3, 0}, {"cp head +norm", 2048, 1024, 0, 1},
-        {"cp proj epi3 ", 1024, 2048, 3, 0}};
+        {"cp proj epi3 ", 1024, 2048, 3, 0},
+        // half the bytes per workgroup at the same workgroup count: what an 8-column tile split of o_proj / down_proj could gain
+        {"cp o   K/2   ", 1024, 1024, 3, 0}, {"cp down K/2  ", 1024, 1536, 3, 0}};
     const int Mp = (M + 15) / 16 * 16;
     const int copies = argc > 3 ? atoi(argv[3]) : 24;  // rotate weight copies so the Infinity Cache does not serve them (1: warm)
     for (auto& s : shapes) {
