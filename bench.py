@@ -328,7 +328,10 @@ def main():
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": step_ms,
-                     "avg_launch_ms_alone": solo["frame_step"] if solo else None},
+                     "avg_launch_ms_alone": solo["frame_step"] if solo else None,
+                     # the same kernel with nothing beside it (last warm-up step): in the pipelined region the frame loop
+                     # shares the chip with the previous batch's codec decode, which is what `frac` above includes
+                     "frac_alone": (algo_bytes / (solo["frame_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if solo and solo["frame_step"] else None},
         "roofline_codec": {"bound": "mfma", "kernel": "codec decoder (conv_gemm_split / resunit_split: bf16 MFMA, six products per "
                            "fp32 product block)", "achieved": codec_flops_bf16 / (codec_solo_ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
                            "unit": "TFLOP/s", "frac": codec_flops_bf16 / (codec_solo_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
