@@ -115,5 +115,18 @@ def test_pipelined_jobs_equal_sequential_calls(ckpt_dirs):
         assert kinds == ["token"] * 20 + ["info", "audio"]  # TOKEN in begin, INFO / AUDIO in end, reference order
         tm = m.last_timing()
         assert tm.codec_ms > 0 and tm.decode_ms > 0 and tm.rows == 5
+        # results are views over buffers the library handed over (no copy in the mirror): they must survive later jobs in the
+        # same job slots, and the model itself
+        keep = [(x.audio, x.audio.copy(), x.codes, x.codes.copy()) for x in ra]
+        assert all(a.base is not None for a, _, _, _ in keep)
+        del ra
+        jd = m.generate_batch_begin(batches[1], **kws[1])
+        je = m.generate_batch_begin(batches[2], more_follows=False, **kws[2])
+        rd, re_ = m.generate_batch_end(jd), m.generate_batch_end(je)
+        for got, exp in zip((rd, re_), want[1:]):
+            for x, y in zip(got, exp):
+                assert (x.codes == y.codes).all() and (x.audio == y.audio).all()
     finally:
         m.close()
+    for a, a0, c, c0 in keep:
+        assert (a == a0).all() and (c == c0).all()
