@@ -150,8 +150,8 @@ def cpu_baseline(ckpt: str, preset: str, n_text: int, n_instruct: int, frames: i
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--preset", default="1.7b", choices=["1.7b", "0.6b", "0.6b-q4", "0.6b-base", "1.7b-base"],
                     help="*-base: voice clone (BASELINE configs[4]): 3 s reference clip per row, repetition penalty 1.5")
     ap.add_argument("--batch", type=int, default=0, help="utterances per GPU (default 32; 16 for *-base; 64 for 0.6b-q4)")
