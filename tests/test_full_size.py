@@ -56,6 +56,15 @@ def test_full_size_properties(full_dir):
             assert r.audio.shape[0] == F * 1920 and np.isfinite(r.audio).all() and np.abs(r.audio).max() <= 1.0
         tm = m.last_timing()
         assert tm.frame_steps == F and tm.rows == 3
+        # the two-deep pipeline at the real sizes: the second batch's frame loop runs beside the first batch's decode on
+        # the CU-masked stream, rows are staged by the background thread -- bit for bit the sequential results
+        ja = m.generate_batch_begin(reqs, more_follows=True, **kw)
+        jb = m.generate_batch_begin(reqs[:8], more_follows=False, **kw)
+        pa, pb = m.generate_batch_end(ja), m.generate_batch_end(jb)
+        for x, y in zip(pa, a):
+            assert x.status == 0 and (x.codes == y.codes).all() and (x.audio == y.audio).all()
+        for x, y in zip(pb, a[:8]):
+            assert (x.codes == y.codes).all() and np.abs(x.audio - y.audio).max() < 1e-6
     finally:
         m.close()
     e = Qwen3TTSModel.from_pretrained(full_dir, max_batch=32, max_frames=F + 8, max_prompt=128, use_graph=False)
