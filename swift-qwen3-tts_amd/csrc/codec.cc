@@ -19,6 +19,8 @@ CodecRunner::CodecRunner(const Model& m, hipStream_t st) : m_(m), st_(st) {
     Q3_CHECK(m.cfg.codec.head_dim == 64, 6, "codec transformer head_dim must be 64");
     const char* e = std::getenv("Q3TTS_CODEC_FP32");
     fp32_mfma_ = e && e[0] == '1';
+    const char* b3 = std::getenv("Q3TTS_CODEC_BF16X3");  // A/B switch: the six-product bf16 split instead of fp16x2
+    bf16x3_ = b3 && b3[0] == '1';
     const char* nf = std::getenv("Q3TTS_CODEC_NO_FUSE");
     no_fuse_ = nf && nf[0] == '1';
 }
@@ -101,7 +103,11 @@ void CodecRunner::conv(const Pass& ps, const ConvW& cw, const float* x, int Tmax
                        const float* res, int act, const SnakeW* post, float* out2) {
     ConvGemmArgs a{};
     a.x = x; a.ldx = cw.Cin; a.x_bstride = int64_t(Tmax) * cw.Cin;
-    a.w = cw.w; a.w3 = fp32_mfma_ ? nullptr : cw.w3; a.bias = cw.bias; a.scale = cw.scale;
+    a.w = cw.w; a.bias = cw.bias; a.scale = cw.scale;
+    if (!fp32_mfma_) {
+        if (bf16x3_) a.w3 = cw.w3;
+        else { a.wh = cw.wh; a.wsc = cw.wsc; }
+    }
     a.res = res; a.ldr = cw.N; a.res_bstride = int64_t(Tmax) * cw.N;
     a.out = out; a.ldo = cw.N; a.out_bstride = int64_t(Tmax) * cw.N;
     a.snake_ea = sn ? sn->ea : nullptr; a.snake_ib = sn ? sn->ib : nullptr;
@@ -196,7 +202,8 @@ void CodecRunner::run_tail(const Pass& ps, int Tframes, float* const* bufs, floa
         const SnakeW* after = i + 1 < nblk ? &w.blocks[i + 1].snake : nullptr;
         bool fused = !fp32_mfma_ && !no_fuse_ && resunit_supported(Bk.Cout, Bk.res[0].conv1.K, 9);
         for (int j = 0; j < 3; ++j)
-            fused = fused && Bk.res[j].conv1.w3 && Bk.res[j].conv2.w3p && Bk.res[j].conv1.N == Bk.Cout && Bk.res[j].conv2.K == 1 &&
+            fused = fused && Bk.res[j].conv1.w3 && Bk.res[j].conv2.w3p && Bk.res[j].conv1.wh && Bk.res[j].conv2.whp &&
+                    Bk.res[j].conv1.N == Bk.Cout && Bk.res[j].conv2.K == 1 &&
                     resunit_supported(Bk.Cout, Bk.res[j].conv1.K, Bk.res[j].conv1.dil);
         if (fused) {
             // narrow blocks: each residual unit is one launch, y ping-pongs between two buffers (codec_conv.hip)
@@ -208,7 +215,9 @@ void CodecRunner::run_tail(const Pass& ps, int Tframes, float* const* bufs, floa
                 ResUnitArgs r{};
                 r.y = yin; r.out = yout;
                 if (j == 2 && after) { r.out2 = hs; r.post_ea = after->ea; r.post_ib = after->ib; }
-                r.w1 = Bk.res[j].conv1.w3; r.b1 = Bk.res[j].conv1.bias; r.w2p = Bk.res[j].conv2.w3p; r.b2 = Bk.res[j].conv2.bias;
+                r.b1 = Bk.res[j].conv1.bias; r.b2 = Bk.res[j].conv2.bias;
+                if (bf16x3_) { r.w1 = Bk.res[j].conv1.w3; r.w2p = Bk.res[j].conv2.w3p; }
+                else { r.w1h = Bk.res[j].conv1.wh; r.w2ph = Bk.res[j].conv2.whp; r.wsc1 = Bk.res[j].conv1.wsc; r.wsc2 = Bk.res[j].conv2.wsc; }
                 r.ea1 = Bk.res[j].act1.ea; r.ib1 = Bk.res[j].act1.ib; r.ea2 = Bk.res[j].act2.ea; r.ib2 = Bk.res[j].act2.ib;
                 r.frames = fr; r.ppf = ppf; r.Tmax = T; r.B = nb; r.C = Bk.Cout; r.K = Bk.res[j].conv1.K; r.dil = Bk.res[j].conv1.dil;
                 launch_resunit(r, st_);

@@ -51,7 +51,8 @@ class CodecRunner {
     hipStream_t st_;
     int up_ = 1920;
     bool no_fuse_ = false;    // Q3TTS_CODEC_NO_FUSE=1: residual units of the narrow blocks as two launches each
-    bool fp32_mfma_ = false;  // Q3TTS_CODEC_FP32=1: contract on the fp32 matrix-core path instead of the bf16x3 one
+    bool fp32_mfma_ = false;  // Q3TTS_CODEC_FP32=1: contract on the fp32 matrix-core path instead of the split one
+    bool bf16x3_ = false;     // Q3TTS_CODEC_BF16X3=1: three bf16 planes / six products instead of two fp16 planes / three
     uint8_t* buf_ = nullptr;
     size_t buf_bytes_ = 0;
     int32_t* lens_dev_ = nullptr;

@@ -15,6 +15,8 @@ struct ConvGemmArgs {
     const float* w;      // [N][K][Cin]
     const uint16_t* w3;  // optional: w split into three bf16 planes (hi | mid | lo, exact), [K][ceil(Cin/32)][N][3][32];
                          // selects the bf16x3 kernel (six bf16 MFMAs per product block instead of eight fp32 ones)
+    const uint16_t* wh;  // optional: w * 2^s[n] split into two fp16 planes (hi | lo), [K][ceil(Cin/32)][N][2][32]; selects the
+    const float* wsc;    // fp16x2 kernel (three fp16 MFMAs per product block); wsc[n] = 2^-s[n] rescales the accumulators
     const float* bias;   // [N] or nullptr
     const float* scale;  // [N] or nullptr
     const float* res;    // residual or nullptr
@@ -56,6 +58,10 @@ struct ResUnitArgs {
     const float* b1;      // [C] or nullptr
     const uint16_t* w2p;  // conv2 split planes, permuted k order [C/32][C][3][32] (model.cc attach_split_perm)
     const float* b2;
+    const uint16_t* w1h;  // fp16x2 form of both (model.cc attach_h2 / attach_h2_perm): [K][C/32][C][2][32], [C/32][C][2][32];
+    const uint16_t* w2ph; // when set, the fp16x2 kernel runs and w1 / w2p are not read
+    const float* wsc1;    // [C] 2^-s of conv1's / conv2's rows
+    const float* wsc2;
     const float* ea1;     // act1: exp(alpha), 1/(exp(beta)+1e-9)
     const float* ib1;
     const float* ea2;     // act2

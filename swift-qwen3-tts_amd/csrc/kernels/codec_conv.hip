@@ -477,6 +477,221 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvGemmArgs a)
     if (a.out2) snake_pass<CT>(a, reinterpret_cast<float*>(smem3), b, t0, n0, wn, T, wave, lane, acc, wm);
 }
 
+// ---- fp16x2 variant ------------------------------------------------------------------------------------
+// Three matrix-core products per block instead of six. fp16 carries 11 significand bits, so two planes hold 22:
+//   activations  x = xh + 2^-11 xl'   xh = fp16(x) (round to nearest), xl' = fp16((x - xh) * 2^11)   -- split while staging;
+//                the 2^11 keeps xl' a NORMAL fp16 wherever x itself is one (|x| >= 2^-14), independent of denormal modes
+//   weights      w 2^s = A + C        A = fp16(w 2^s), C = fp16(w 2^s - A), s per output channel such that the row's
+//                largest |w 2^s| lies in [2^13, 2^14): C (~2^-12 of the element) is normal for every element within
+//                2^-15 of the row maximum and carries an absolute error below 2^-38 of that maximum otherwise (model.cc
+//                attach_h2). 2^-s is applied to the accumulators in the epilogue (exact).
+//   product      w x 2^s = A xh + C xh + (A 2^-11) xl'  [+ C xl' 2^-11, dropped: ~2^-24.8 of the product, r.m.s.]
+// A 2^-11 is formed in registers from the A fragment (v_pk_mul_f16, exact unless A < 2^-3, i.e. 2^-16 of the row maximum).
+// Each fp16 x fp16 product is exact in fp32; what is lost is the rounding of xl' and C (operand error ~0.6 x 2^-24
+// r.m.s., 2^-22 worst case) and the dropped term -- per-product noise at the level of ONE fp32 rounding, which adds up
+// as sqrt(K) while an fp32 fmaf chain's own rounding adds up as K: on a K = 5376 contraction the simulated error against
+// double is 0.3x the fmaf chain's (tools/split_sim.py). Range: |x| must stay below 65504 (fp16); a decoder activation
+// beyond that turns into inf/NaN and reaches the PCM as a non-finite sample, which out_conv reports (codec.cc re-runs the
+// decode on the fp32 matrix-core kernels then).
+// An LDS row holds the two planes of 32 input channels (2 x 64 B) + 32 B of padding = 10 sixteen-byte units (10 = 2 mod 4:
+// conflict-free ds_read_b128); weight tiles are double-buffered (one barrier per tap): (128 + halo + 2 BN) x 160 B <= 70 KiB.
+constexpr int ROWH = 40;  // dwords per LDS row
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split_h2(const float4& v, uint2& hi, uint2& lo) {
+    const f32x4v x = {v.x, v.y, v.z, v.w};
+    const f16x4 h = __builtin_convertvector(x, f16x4);
+    const f32x4v r = (x - __builtin_convertvector(h, f32x4v)) * 2048.0f;
+    const f16x4 l = __builtin_convertvector(r, f16x4);
+    __builtin_memcpy(&hi, &h, 8);
+    __builtin_memcpy(&lo, &l, 8);
+}
+
+__device__ __forceinline__ f32x4 mfma_f16(const uint4& a, const uint4& b, f32x4 c) {
+    f16x8 av, bv;
+    __builtin_memcpy(&av, &a, 16);
+    __builtin_memcpy(&bv, &b, 16);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ uint4 f16x8_scale_m11(const uint4& a) {  // every fp16 of the fragment times 2^-11
+    f16x8 v;
+    __builtin_memcpy(&v, &a, 16);
+    v = v * static_cast<_Float16>(0.00048828125f);
+    uint4 r;
+    __builtin_memcpy(&r, &v, 16);
+    return r;
+}
+
+template <int CT>
+__device__ __forceinline__ void scale_acc(const float* wsc, int N, int n_w, int lane, f32x4 (&acc)[4][CT]) {
+    const int nq = n_w + 4 * (lane >> 4);
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const int n = nq + 16 * c;
+        float4 s = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (n < N) s = *reinterpret_cast<const float4*>(wsc + n);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            acc[p][c][0] *= s.x; acc[p][c][1] *= s.y; acc[p][c][2] *= s.z; acc[p][c][3] *= s.w;
+        }
+    }
+}
+
+template <int BN, bool PRO>
+__global__ __launch_bounds__(256, 2) void conv_gemm_h2_kernel(ConvGemmArgs a) {
+    constexpr int CT = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem3[];
+    const int halo = (a.K - 1) * a.dil;
+    uint32_t* As = smem3;                        // [(BM + halo)][ROWH]
+    uint32_t* Ws = smem3 + (BM + halo) * ROWH;   // [2][BN][ROWH]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int b = blockIdx.z;
+    const int n0 = blockIdx.x * BN;
+    const int t0 = blockIdx.y * BM;
+    const int T = a.frames[b] * a.ppf;
+    if (t0 >= T) return;
+    const int rows = BM + halo;
+    const float* xb = a.x + (size_t)b * a.x_bstride;
+    const float* x2b = a.x2;
+    const int nchunks = (a.Cin + KC - 1) / KC;
+    const int steps = nchunks * a.K;
+
+    f32x4 acc[4][CT];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // weight tile of one (tap, chunk) step: BN x 8 sixteen-byte pieces, contiguous in global memory
+    constexpr int WV = BN * 8 / 256;
+    uint4 wreg[WV];
+    auto load_w = [&](int step) {
+        const int chunk = step / a.K, tap = step % a.K;
+        const uint4* src = reinterpret_cast<const uint4*>(a.wh + ((size_t)(tap * nchunks + chunk) * a.N + n0) * 64);
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int item = i * 256 + tid;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (n0 + (item >> 3) < a.N) v = src[item];
+            wreg[i] = v;
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int item = i * 256 + tid;
+            *reinterpret_cast<uint4*>(&Ws[(buf * BN + (item >> 3)) * ROWH + (item & 7) * 4]) = wreg[i];
+        }
+    };
+
+    constexpr int AV = ((BM + MAX_HALO) * 8 + 255) / 256;
+    float4 areg[AV];
+    auto load_a = [&](int chunk) {
+        const int c0 = chunk * KC;
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int item = i * 256 + tid;
+            const int r = item >> 3, c4 = (item & 7) * 4;
+            int t = t0 - halo + r;
+            if constexpr (PRO) {
+                t += a.shift;
+                if (a.reflect) t = t < 0 ? -t : (t >= T ? 2 * (T - 1) - t : t);
+            }
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < rows && t >= 0 && t < T && c0 + c4 < a.Cin) {
+                v = *reinterpret_cast<const float4*>(xb + (size_t)t * a.ldx + c0 + c4);
+                if constexpr (PRO) {
+                    if (x2b) {
+                        const float4 u = *reinterpret_cast<const float4*>(x2b + (size_t)t * a.ldx2 + c0 + c4);
+                        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                    }
+                    if (a.pre_act == 1) {
+                        v.x = v.x > 0.f ? v.x : expf(v.x) - 1.0f;
+                        v.y = v.y > 0.f ? v.y : expf(v.y) - 1.0f;
+                        v.z = v.z > 0.f ? v.z : expf(v.z) - 1.0f;
+                        v.w = v.w > 0.f ? v.w : expf(v.w) - 1.0f;
+                    }
+                    if (a.snake_ea) {
+                        const float4 ea = *reinterpret_cast<const float4*>(a.snake_ea + c0 + c4);
+                        const float4 ib = *reinterpret_cast<const float4*>(a.snake_ib + c0 + c4);
+                        float s;
+                        s = sinf(v.x * ea.x); v.x = v.x + ib.x * (s * s);
+                        s = sinf(v.y * ea.y); v.y = v.y + ib.y * (s * s);
+                        s = sinf(v.z * ea.z); v.z = v.z + ib.z * (s * s);
+                        s = sinf(v.w * ea.w); v.w = v.w + ib.w * (s * s);
+                    }
+                }
+            }
+            areg[i] = v;
+        }
+    };
+    auto store_a = [&]() {
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int item = i * 256 + tid;
+            const int r = item >> 3, c4 = (item & 7) * 4;
+            if (r >= rows) continue;
+            uint2 hi, lo;
+            split_h2(areg[i], hi, lo);
+            uint32_t* dst = &As[r * ROWH + (c4 >> 1)];
+            *reinterpret_cast<uint2*>(dst) = hi;
+            *reinterpret_cast<uint2*>(dst + 16) = lo;
+        }
+    };
+
+    load_w(0);
+    load_a(0);
+    int buf = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        __syncthreads();  // the previous chunk's MFMAs are done with As
+        store_a();
+        if (chunk + 1 < nchunks) load_a(chunk + 1);
+        for (int tap = 0; tap < a.K; ++tap) {
+            const int step = chunk * a.K + tap;
+            store_w(buf);     // the other buffer may still be read by a wave that is behind: double-buffered
+            __syncthreads();
+            if (step + 1 < steps) load_w(step + 1);
+            const uint32_t* arow = &As[(wm * 64 + tap * a.dil + (lane & 15)) * ROWH + 4 * (lane >> 4)];
+            const uint32_t* wrow = &Ws[(buf * BN + wn * (BN / 2) + (lane & 15)) * ROWH + 4 * (lane >> 4)];
+            uint4 xa[2][4], wa[2][CT], wb[CT];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) xa[pl][p] = *reinterpret_cast<const uint4*>(arow + p * 16 * ROWH + pl * 16);
+#pragma unroll
+                for (int c = 0; c < CT; ++c) wa[pl][c] = *reinterpret_cast<const uint4*>(wrow + c * 16 * ROWH + pl * 16);
+            }
+#pragma unroll
+            for (int c = 0; c < CT; ++c) wb[c] = f16x8_scale_m11(wa[0][c]);
+            // smallest products first: (A 2^-11) xl', C xh, A xh
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[p][c] = mfma_f16(wb[c], xa[1][p], acc[p][c]);
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[p][c] = mfma_f16(wa[1][c], xa[0][p], acc[p][c]);
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[p][c] = mfma_f16(wa[0][c], xa[0][p], acc[p][c]);
+            buf ^= 1;
+        }
+    }
+
+    scale_acc<CT>(a.wsc, a.N, n0 + wn * (BN / 2), lane, acc);
+    if (a.act != 0) epilogue_tile<CT, true>(a, b, t0 + wm * 64, n0 + wn * (BN / 2), T, lane, acc);
+    else epilogue_tile<CT, false>(a, b, t0 + wm * 64, n0 + wn * (BN / 2), T, lane, acc);
+    if (a.out2) snake_pass<CT>(a, reinterpret_cast<float*>(smem3), b, t0, n0, wn, T, wave, lane, acc, wm);
+}
+
 // ---- fused residual unit -------------------------------------------------------------------------------
 // out = y + conv2(act2(conv1(act1(y)))) (DecoderResidualUnit, SpeechTokenizer.swift:430-437) for the narrow, long blocks
 // (C <= 96 channels at up to 384 k positions per row), which are HBM-bound when every conv is its own launch: six
@@ -759,6 +974,292 @@ __global__ __launch_bounds__(256, 2) void resunit_split_kernel(ResUnitArgs a) {
     }
 }
 
+// ---- fused residual unit, fp16x2 --------------------------------------------------------------------------
+// resunit_split_kernel's structure with the two-plane fp16 split of conv_gemm_h2_kernel: three products per block, two
+// LDS planes, weight tiles double-buffered. conv1's accumulators (scaled by its 2^-s, + bias, SnakeBeta act2) are split in
+// registers into conv2's B fragments as before.
+template <int CT2>
+__global__ __launch_bounds__(256, 2) void resunit_h2_kernel(ResUnitArgs a) {
+    constexpr int C = 16 * CT2, NCH = CT2 / 2;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem3[];
+    const int halo = (a.K - 1) * a.dil;
+    uint32_t* As = smem3;                        // [(BM + halo)][ROWH]
+    uint32_t* Ws = smem3 + (BM + halo) * ROWH;   // [2][C][ROWH]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.y * BM;
+    const int T = a.frames[b] * a.ppf;
+    if (t0 >= T) return;
+    const int rows = BM + halo;
+    const size_t boff = (size_t)b * a.Tmax * C;
+    const float* yb = a.y + boff;
+    const int S1 = NCH * a.K;  // conv1 steps; conv2 adds NCH more
+
+    f32x4 acc1[2][CT2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int c = 0; c < CT2; ++c) acc1[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int WV = (C * 8 + 255) / 256;
+    uint4 wreg[WV];
+    auto load_w = [&](int step) {
+        const uint4* src;
+        if (step < S1) {
+            const int chunk = step / a.K, tap = step % a.K;
+            src = reinterpret_cast<const uint4*>(a.w1h + (size_t)(tap * NCH + chunk) * C * 64);
+        } else {
+            src = reinterpret_cast<const uint4*>(a.w2ph + (size_t)(step - S1) * C * 64);
+        }
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int item = i * 256 + tid;
+            wreg[i] = item < C * 8 ? src[item] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int item = i * 256 + tid;
+            if (item < C * 8) *reinterpret_cast<uint4*>(&Ws[(buf * C + (item >> 3)) * ROWH + (item & 7) * 4]) = wreg[i];
+        }
+    };
+
+    constexpr int AV = ((BM + MAX_HALO) * 8 + 255) / 256;
+    float4 areg[AV];
+    auto load_a = [&](int chunk) {
+        const int c0 = chunk * KC;
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int item = i * 256 + tid;
+            const int r = item >> 3, c4 = (item & 7) * 4;
+            const int t = t0 - halo + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < rows && t >= 0 && t < T) {
+                v = *reinterpret_cast<const float4*>(yb + (size_t)t * C + c0 + c4);
+                const float4 ea = *reinterpret_cast<const float4*>(a.ea1 + c0 + c4);
+                const float4 ib = *reinterpret_cast<const float4*>(a.ib1 + c0 + c4);
+                v.x = v.x + ib.x * snake_sin2(v.x * ea.x);
+                v.y = v.y + ib.y * snake_sin2(v.y * ea.y);
+                v.z = v.z + ib.z * snake_sin2(v.z * ea.z);
+                v.w = v.w + ib.w * snake_sin2(v.w * ea.w);
+            }
+            areg[i] = v;
+        }
+    };
+    auto store_a = [&]() {
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int item = i * 256 + tid;
+            const int r = item >> 3, c4 = (item & 7) * 4;
+            if (r >= rows) continue;
+            uint2 hi, lo;
+            split_h2(areg[i], hi, lo);
+            uint32_t* dst = &As[r * ROWH + (c4 >> 1)];
+            *reinterpret_cast<uint2*>(dst) = hi;
+            *reinterpret_cast<uint2*>(dst + 16) = lo;
+        }
+    };
+
+    // ---- conv1 ----
+    load_w(0);
+    load_a(0);
+    int buf = 0;
+    for (int chunk = 0; chunk < NCH; ++chunk) {
+        __syncthreads();
+        store_a();
+        if (chunk + 1 < NCH) load_a(chunk + 1);
+        for (int tap = 0; tap < a.K; ++tap) {
+            const int step = chunk * a.K + tap;
+            store_w(buf);
+            __syncthreads();
+            load_w(step + 1);  // the step after conv1's last one is conv2's first
+            const uint32_t* arow = &As[(32 * wave + tap * a.dil + (lane & 15)) * ROWH + 4 * (lane >> 4)];
+            const uint32_t* wrow = &Ws[(buf * C + (lane & 15)) * ROWH + 4 * (lane >> 4)];
+            uint4 xa[2][2], wa[2][CT2], wb[CT2];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) xa[pl][p] = *reinterpret_cast<const uint4*>(arow + p * 16 * ROWH + pl * 16);
+#pragma unroll
+                for (int c = 0; c < CT2; ++c) wa[pl][c] = *reinterpret_cast<const uint4*>(wrow + c * 16 * ROWH + pl * 16);
+            }
+#pragma unroll
+            for (int c = 0; c < CT2; ++c) wb[c] = f16x8_scale_m11(wa[0][c]);
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int c = 0; c < CT2; ++c) acc1[p][c] = mfma_f16(wb[c], xa[1][p], acc1[p][c]);
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int c = 0; c < CT2; ++c) acc1[p][c] = mfma_f16(wa[1][c], xa[0][p], acc1[p][c]);
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int c = 0; c < CT2; ++c) acc1[p][c] = mfma_f16(wa[0][c], xa[0][p], acc1[p][c]);
+            buf ^= 1;
+        }
+    }
+
+    // ---- 2^-s, + bias1, act2 in registers (lane: channels 16c + 4(lane >> 4) + j of its two position tiles) ----
+    const int q4 = 4 * (lane >> 4);
+    int big = 0;
+#pragma unroll
+    for (int c = 0; c < CT2; ++c) {
+        const float4 sv = *reinterpret_cast<const float4*>(a.wsc1 + 16 * c + q4);
+        const float4 bv = a.b1 ? *reinterpret_cast<const float4*>(a.b1 + 16 * c + q4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 ea = *reinterpret_cast<const float4*>(a.ea2 + 16 * c + q4);
+        const float e[4] = {ea.x, ea.y, ea.z, ea.w}, bb[4] = {bv.x, bv.y, bv.z, bv.w}, ss[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc1[p][c][j] = acc1[p][c][j] * ss[j] + bb[j];
+                big |= !(fabsf(acc1[p][c][j] * e[j]) < 1.0e6f);
+            }
+    }
+    // block-wide vote (also the barrier that retires conv1's reads of As): arguments beyond the polynomial's range are
+    // possible only in a diverged model; the whole workgroup then goes through the libm path, one tile at a time via LDS
+    if (__syncthreads_or(big)) {
+        float4* stash = reinterpret_cast<float4*>(As) + wave * (CT2 * 64);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int c = 0; c < CT2; ++c) stash[c * 64 + lane] = make_float4(acc1[p][c][0], acc1[p][c][1], acc1[p][c][2], acc1[p][c][3]);
+#pragma unroll 1
+            for (int c = 0; c < CT2; ++c) {
+                float4 v = stash[c * 64 + lane];
+                const float4 ea = *reinterpret_cast<const float4*>(a.ea2 + 16 * c + q4);
+                const float4 ib = *reinterpret_cast<const float4*>(a.ib2 + 16 * c + q4);
+                v.x = v.x + ib.x * snake_sin2(v.x * ea.x);
+                v.y = v.y + ib.y * snake_sin2(v.y * ea.y);
+                v.z = v.z + ib.z * snake_sin2(v.z * ea.z);
+                v.w = v.w + ib.w * snake_sin2(v.w * ea.w);
+                stash[c * 64 + lane] = v;
+            }
+#pragma unroll
+            for (int c = 0; c < CT2; ++c) {
+                const float4 v = stash[c * 64 + lane];
+                acc1[p][c] = f32x4{v.x, v.y, v.z, v.w};
+            }
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CT2; ++c) {
+            const float4 ea = *reinterpret_cast<const float4*>(a.ea2 + 16 * c + q4);
+            const float4 ib = *reinterpret_cast<const float4*>(a.ib2 + 16 * c + q4);
+            const float e[4] = {ea.x, ea.y, ea.z, ea.w}, ii[4] = {ib.x, ib.y, ib.z, ib.w};
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc1[p][c][j] = acc1[p][c][j] + ii[j] * snake_sin2_poly(acc1[p][c][j] * e[j]);
+        }
+    }
+
+    // ---- conv2: the B fragments come out of acc1 ----
+    f32x4 acc2[2][CT2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int c = 0; c < CT2; ++c) acc2[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < NCH; ++m) {
+        store_w(buf);
+        __syncthreads();
+        if (m + 1 < NCH) load_w(S1 + m + 1);
+        const uint32_t* wrow = &Ws[(buf * C + (lane & 15)) * ROWH + 4 * (lane >> 4)];
+        uint4 xb[2][2], wa[2][CT2], wb[CT2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const float4 v0 = make_float4(acc1[p][2 * m][0], acc1[p][2 * m][1], acc1[p][2 * m][2], acc1[p][2 * m][3]);
+            const float4 v1 = make_float4(acc1[p][2 * m + 1][0], acc1[p][2 * m + 1][1], acc1[p][2 * m + 1][2], acc1[p][2 * m + 1][3]);
+            uint2 h0, l0, h1, l1;
+            split_h2(v0, h0, l0);
+            split_h2(v1, h1, l1);
+            xb[0][p] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            xb[1][p] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        }
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int c = 0; c < CT2; ++c) wa[pl][c] = *reinterpret_cast<const uint4*>(wrow + c * 16 * ROWH + pl * 16);
+#pragma unroll
+        for (int c = 0; c < CT2; ++c) wb[c] = f16x8_scale_m11(wa[0][c]);
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int c = 0; c < CT2; ++c) acc2[p][c] = mfma_f16(wb[c], xb[1][p], acc2[p][c]);
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int c = 0; c < CT2; ++c) acc2[p][c] = mfma_f16(wa[1][c], xb[0][p], acc2[p][c]);
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int c = 0; c < CT2; ++c) acc2[p][c] = mfma_f16(wa[0][c], xb[0][p], acc2[p][c]);
+        buf ^= 1;
+    }
+
+    // ---- 2^-s, + bias2, + y -> out; optionally the next block's SnakeBeta of the sum -> out2 ----
+    float4 rvs[2][CT2], bv2[CT2], sv2[CT2];
+#pragma unroll
+    for (int c = 0; c < CT2; ++c) {
+        bv2[c] = a.b2 ? *reinterpret_cast<const float4*>(a.b2 + 16 * c + q4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        sv2[c] = *reinterpret_cast<const float4*>(a.wsc2 + 16 * c + q4);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int t = t0 + 32 * wave + 16 * p + (lane & 15);
+#pragma unroll
+        for (int c = 0; c < CT2; ++c) {
+            rvs[p][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < T) rvs[p][c] = *reinterpret_cast<const float4*>(yb + (size_t)t * C + 16 * c + q4);
+        }
+    }
+    __syncthreads();  // every wave is done with the weight tiles before As / Ws double as the stash below
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int t = t0 + 32 * wave + 16 * p + (lane & 15);
+        if (t >= T) continue;
+#pragma unroll
+        for (int c = 0; c < CT2; ++c) {
+            const int n = 16 * c + q4;
+            const float4 rv = rvs[p][c], bv = bv2[c], sv = sv2[c];
+            float4 v = make_float4(acc2[p][c][0] * sv.x + rv.x, acc2[p][c][1] * sv.y + rv.y, acc2[p][c][2] * sv.z + rv.z,
+                                   acc2[p][c][3] * sv.w + rv.w);
+            if (a.b2)
+                v = make_float4((acc2[p][c][0] * sv.x + bv.x) + rv.x, (acc2[p][c][1] * sv.y + bv.y) + rv.y,
+                                (acc2[p][c][2] * sv.z + bv.z) + rv.z, (acc2[p][c][3] * sv.w + bv.w) + rv.w);
+            *reinterpret_cast<float4*>(a.out + boff + (size_t)t * C + n) = v;
+            acc2[p][c] = f32x4{v.x, v.y, v.z, v.w};
+        }
+    }
+    if (a.out2) {  // As is free since the vote; every lane uses its own stash slots
+        float4* stash = reinterpret_cast<float4*>(As) + wave * (CT2 * 64);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int c = 0; c < CT2; ++c) stash[c * 64 + lane] = make_float4(acc2[p][c][0], acc2[p][c][1], acc2[p][c][2], acc2[p][c][3]);
+            const int t = t0 + 32 * wave + 16 * p + (lane & 15);
+            if (t >= T) continue;
+#pragma unroll 1
+            for (int c = 0; c < CT2; ++c) {
+                const int n = 16 * c + q4;
+                float4 v = stash[c * 64 + lane];
+                const float4 ea = *reinterpret_cast<const float4*>(a.post_ea + n);
+                const float4 ib = *reinterpret_cast<const float4*>(a.post_ib + n);
+                v.x = v.x + ib.x * snake_sin2(v.x * ea.x);
+                v.y = v.y + ib.y * snake_sin2(v.y * ea.y);
+                v.z = v.z + ib.z * snake_sin2(v.z * ea.z);
+                v.w = v.w + ib.w * snake_sin2(v.w * ea.w);
+                *reinterpret_cast<float4*>(a.out2 + boff + (size_t)t * C + n) = v;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 bool resunit_supported(int C, int K, int dil) { return (C == 32 || C == 64 || C == 96) && K >= 1 && (K - 1) * dil <= MAX_HALO; }
@@ -769,12 +1270,23 @@ void launch_resunit(const ResUnitArgs& a, hipStream_t st) {
     if (mt <= 0 || a.B <= 0) return;
     static bool attr_set = false;
     if (!attr_set) {
-        void (*ks[3])(ResUnitArgs) = {&resunit_split_kernel<2>, &resunit_split_kernel<4>, &resunit_split_kernel<6>};
+        void (*ks[6])(ResUnitArgs) = {&resunit_split_kernel<2>, &resunit_split_kernel<4>, &resunit_split_kernel<6>,
+                                      &resunit_h2_kernel<2>,    &resunit_h2_kernel<4>,    &resunit_h2_kernel<6>};
         for (auto k : ks)
             Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         attr_set = true;
     }
     dim3 grid(1, mt, a.B), block(256);
+    if (a.w1h) {
+        Q3_CHECK(a.w2ph && a.wsc1 && a.wsc2, 3, "resunit: incomplete fp16x2 weights");
+        const size_t smemh = size_t(BM + (a.K - 1) * a.dil + 2 * a.C) * ROWH * sizeof(uint32_t);
+        switch (a.C) {
+            case 32: hipLaunchKernelGGL(resunit_h2_kernel<2>, grid, block, smemh, st, a); break;
+            case 64: hipLaunchKernelGGL(resunit_h2_kernel<4>, grid, block, smemh, st, a); break;
+            default: hipLaunchKernelGGL(resunit_h2_kernel<6>, grid, block, smemh, st, a); break;
+        }
+        return;
+    }
     const size_t smem = size_t(BM + (a.K - 1) * a.dil + a.C) * ROW3 * sizeof(uint32_t);
     switch (a.C) {
         case 32: hipLaunchKernelGGL(resunit_split_kernel<2>, grid, block, smem, st, a); break;
@@ -805,7 +1317,24 @@ void launch_conv_gemm(const ConvGemmArgs& a, hipStream_t st) {
                                                    &conv_gemm_split_kernel<64, true>,  &conv_gemm_split_kernel<64, false>};
         for (auto k : split_kernels)
             Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        void (*h2_kernels[6])(ConvGemmArgs) = {&conv_gemm_h2_kernel<128, true>, &conv_gemm_h2_kernel<128, false>,
+                                                &conv_gemm_h2_kernel<96, true>,  &conv_gemm_h2_kernel<96, false>,
+                                                &conv_gemm_h2_kernel<64, true>,  &conv_gemm_h2_kernel<64, false>};
+        for (auto k : h2_kernels)
+            Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         attr_set = true;
+    }
+    if (a.wh) {
+        Q3_CHECK(a.wsc != nullptr, 3, "conv_gemm: fp16x2 weights without their row scales");
+        const size_t smemh = size_t(BM + (a.K - 1) * a.dil + 2 * BN) * ROWH * sizeof(uint32_t);
+        const bool pro = a.x2 || a.pre_act || a.snake_ea || a.shift || a.reflect;
+        auto go = [&](void (*kern)(ConvGemmArgs)) { hipLaunchKernelGGL(kern, grid, block, smemh, st, a); };
+        switch (BN) {
+            case 128: pro ? go(&conv_gemm_h2_kernel<128, true>) : go(&conv_gemm_h2_kernel<128, false>); break;
+            case 96: pro ? go(&conv_gemm_h2_kernel<96, true>) : go(&conv_gemm_h2_kernel<96, false>); break;
+            default: pro ? go(&conv_gemm_h2_kernel<64, true>) : go(&conv_gemm_h2_kernel<64, false>); break;
+        }
+        return;
     }
     if (a.w3) {
         const size_t smem3 = size_t(BM + (a.K - 1) * a.dil + BN) * ROW3 * sizeof(uint32_t);

@@ -587,6 +587,92 @@ void attach_split_perm(Builder& b, ConvW& c, const std::vector<float>& w) {
     c.w3p = b.put<uint16_t>(p.empty() ? nullptr : p.data(), n);
 }
 
+// ---- fp16x2 form (codec_conv.hip conv_gemm_h2_kernel) ----
+inline uint16_t f32_to_f16_bits(float x) {  // round to nearest even (the compiler's conversion; |x| < 65520 here)
+    const _Float16 h = static_cast<_Float16>(x);
+    uint16_t u;
+    std::memcpy(&u, &h, 2);
+    return u;
+}
+inline float f16_bits_to_f32(uint16_t u) {
+    _Float16 h;
+    std::memcpy(&h, &u, 2);
+    return static_cast<float>(h);
+}
+// 2^s[n] brings the largest |w| of output row n into [2^13, 2^14): hi = fp16(w 2^s) is then a normal number for every
+// element within 2^-27 of the row maximum, and lo = fp16(w 2^s - hi) (about 2^-12 of the element, no further scaling)
+// for every element within 2^-15 of it; smaller elements lose bits that sit 2^-38 below the row maximum.
+inline std::vector<int> row_shifts(const ConvW& c, const std::vector<float>& w) {
+    std::vector<int> s(size_t(c.N), 0);
+    const size_t per = size_t(c.K) * c.Cin;
+    for (int nn = 0; nn < c.N; ++nn) {
+        float mx = 0.f;
+        for (size_t i = 0; i < per; ++i) mx = std::max(mx, std::fabs(w[size_t(nn) * per + i]));
+        if (mx > 0.f && std::isfinite(mx)) {
+            int e;
+            std::frexp(mx, &e);  // mx = f 2^e, f in [0.5, 1)
+            s[size_t(nn)] = std::min(100, std::max(-100, 14 - e));
+        }
+    }
+    return s;
+}
+inline void split_h2(float w, int s, uint16_t& hi, uint16_t& lo) {
+    const float ws = std::ldexp(w, s);
+    hi = f32_to_f16_bits(ws);
+    lo = f32_to_f16_bits(ws - f16_bits_to_f32(hi));
+}
+void put_row_scales(Builder& b, ConvW& c, const std::vector<int>& s, bool have) {
+    std::vector<float> sc;
+    if (have) {
+        sc.resize(size_t(c.N));
+        for (int nn = 0; nn < c.N; ++nn) sc[size_t(nn)] = std::ldexp(1.0f, -s[size_t(nn)]);
+    }
+    c.wsc = b.put<float>(sc.empty() ? nullptr : sc.data(), size_t(c.N));
+}
+
+// w [N][K][Cin] fp32 -> [K][chunks of 32 input channels][N][2 planes][32] fp16 (zero beyond Cin) + 2^-s per row
+void attach_h2(Builder& b, ConvW& c, const std::vector<float>& w) {
+    if (!b.split3) return;
+    const int chunks = (c.Cin + 31) / 32;
+    const size_t n = size_t(c.K) * chunks * c.N * 64;
+    const bool have = !b.dry && b.fill && !w.empty();
+    std::vector<uint16_t> p;
+    std::vector<int> s;
+    if (have) {
+        s = row_shifts(c, w);
+        p.assign(n, 0);
+        for (int nn = 0; nn < c.N; ++nn)
+            for (int tap = 0; tap < c.K; ++tap)
+                for (int ci = 0; ci < c.Cin; ++ci) {
+                    uint16_t* d = &p[((size_t(tap) * chunks + ci / 32) * c.N + nn) * 64 + (ci % 32)];
+                    split_h2(w[(size_t(nn) * c.K + tap) * c.Cin + ci], s[size_t(nn)], d[0], d[32]);
+                }
+    }
+    c.wh = b.put<uint16_t>(p.empty() ? nullptr : p.data(), n);
+    put_row_scales(b, c, s, have);
+}
+
+// conv2 of a residual unit in the fused kernel's k order (see attach_split_perm); shares wsc with attach_h2's copy
+void attach_h2_perm(Builder& b, ConvW& c, const std::vector<float>& w) {
+    if (!b.split3 || c.K != 1 || c.Cin % 32 != 0) return;
+    const int chunks = c.Cin / 32;
+    const size_t n = size_t(chunks) * c.N * 64;
+    std::vector<uint16_t> p;
+    if (!b.dry && b.fill && !w.empty()) {
+        const std::vector<int> s = row_shifts(c, w);
+        p.assign(n, 0);
+        for (int nn = 0; nn < c.N; ++nn)
+            for (int m = 0; m < chunks; ++m)
+                for (int sl = 0; sl < 32; ++sl) {
+                    const int q = sl >> 3, e = (sl >> 2) & 1, j = sl & 3;
+                    const int ci = 32 * m + 16 * e + 4 * q + j;
+                    uint16_t* d = &p[(size_t(m) * c.N + nn) * 64 + sl];
+                    split_h2(w[size_t(nn) * c.Cin + ci], s[size_t(nn)], d[0], d[32]);
+                }
+    }
+    c.whp = b.put<uint16_t>(p.empty() ? nullptr : p.data(), n);
+}
+
 ConvW put_conv(Builder& b, const TMap& t, const std::string& name, int dil = 1) {
     const HostTensor& w = need(t, name + ".weight");
     ConvW c;
@@ -602,6 +688,7 @@ ConvW put_conv(Builder& b, const TMap& t, const std::string& name, int dil = 1) 
     c.dil = dil;
     c.w = b.put_f32(w);
     attach_split(b, c, w.data);
+    attach_h2(b, c, w.data);
     if (const HostTensor* bias = maybe(t, name + ".bias")) c.bias = b.put_f32(*bias);
     return c;
 }
@@ -629,6 +716,7 @@ ConvW put_linear_concat(Builder& b, const TMap& t, const std::vector<std::string
     c.Cin = K;
     c.w = b.put_f32(cat);
     attach_split(b, c, cat.data);
+    attach_h2(b, c, cat.data);
     return c;
 }
 
@@ -660,6 +748,7 @@ ConvW put_tconv(Builder& b, const TMap& t, const std::string& name, int stride) 
     c.dil = 1;
     c.w = b.put_f32(p);
     attach_split(b, c, p.data);
+    attach_h2(b, c, p.data);
     if (const HostTensor* bias = maybe(t, name + ".bias")) {
         HostTensor bb;
         bb.shape = {int64_t(stride) * Cout};
@@ -722,6 +811,7 @@ void build_codec(Builder& b, const TMap& t, const CodecDecoderConfig& dc, CodecW
         c.rvq_out.Cin = 2 * in;
         c.rvq_out.w = b.put_f32(f);
         attach_split(b, c.rvq_out, f.data);
+        attach_h2(b, c.rvq_out, f.data);
     }
     c.pre_conv = put_conv(b, t, "decoder.pre_conv.conv");
     const std::string pt = "decoder.pre_transformer";
@@ -774,6 +864,7 @@ void build_codec(Builder& b, const TMap& t, const CodecDecoderConfig& dc, CodecW
             B.res[j].act2 = put_snake(b, t, rp + ".act2");
             B.res[j].conv2 = put_conv(b, t, rp + ".conv2.conv");
             attach_split_perm(b, B.res[j].conv2, need(t, rp + ".conv2.conv.weight").data);
+            attach_h2_perm(b, B.res[j].conv2, need(t, rp + ".conv2.conv.weight").data);
         }
     }
     c.out_snake = put_snake(b, t, "decoder.decoder.outSnake");
