@@ -296,10 +296,12 @@ def main():
     algo_bytes = model.info.weight_bytes + kv_bytes / max(frame_steps, 1)
     achieved = algo_bytes / (step_ms * 1e-3) / 1e9
     pipelined = not args.no_pipeline and args.steps > 1
-    # codec decoder: 2.484 GMAC per frame; every fp32 product block is six bf16 MFMA products
+    # codec decoder: 2.484 GMAC per frame; every fp32 product block is executed as THREE fp16 MFMA products
+    # (two-plane split, codec_conv.hip) -- `achieved` counts exactly those, `fp32_equivalent_tflops` the useful work
     n_frames_step = B * args.frames
     codec_solo_ms = solo["codec_decode"] if solo else codec_ms / args.steps
-    codec_flops_bf16 = 6 * 2 * 2.484e9 * n_frames_step
+    codec_products = 6 if os.environ.get("Q3TTS_CODEC_BF16X3") == "1" else 3
+    codec_flops_bf16 = codec_products * 2 * 2.484e9 * n_frames_step
     latency_ms = (solo["voice_frontend"] + solo["prefill"] + solo["ar_decode"] + solo["codec_decode"]) if solo else None
     out = {
         "metric": "codec_tokens_per_s", "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -309,7 +311,7 @@ def main():
                                f"{args.n_text} text + {n_instruct} instruct tokens, T={temp} top-k 50, "
                                + ("voice clone: 3.0 s reference clip per row -> codec encoder + speaker encoder + ICL prompt, "
                                   if clone else "")
-                               + "prompt assembly + prefill + hipGraph AR decode + fp32-equivalent (bf16x3 split) codec decode -> 24 kHz PCM"
+                               + "prompt assembly + prefill + hipGraph AR decode + fp32-equivalent (two-plane fp16 split) codec decode -> 24 kHz PCM"
                                + ("; steps pipelined two deep (a step's codec decode overlaps the next step's AR loop)" if pipelined else ""),
                    "batch_per_gpu": B, "frames_per_utterance": args.frames, "parallelism": f"batch-shard x{world}"},
         "rtf_audio_s_per_wall_s": value * FRAME_SECONDS, "rtf_wall_s_per_audio_s": 1.0 / (value * FRAME_SECONDS),
@@ -332,8 +334,8 @@ def main():
                      # the same kernel with nothing beside it (last warm-up step): in the pipelined region the frame loop
                      # shares the chip with the previous batch's codec decode, which is what `frac` above includes
                      "frac_alone": (algo_bytes / (solo["frame_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if solo and solo["frame_step"] else None},
-        "roofline_codec": {"bound": "mfma", "kernel": "codec decoder (conv_gemm_split / resunit_split: bf16 MFMA, six products per "
-                           "fp32 product block)", "achieved": codec_flops_bf16 / (codec_solo_ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
+        "roofline_codec": {"bound": "mfma", "kernel": "codec decoder (conv_gemm_h2 / resunit_h2: fp16 MFMA, %d executed products per "
+                           "fp32 product block)" % codec_products, "executed_products_per_fp32_product": codec_products, "achieved": codec_flops_bf16 / (codec_solo_ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
                            "unit": "TFLOP/s", "frac": codec_flops_bf16 / (codec_solo_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                            "fp32_equivalent_tflops": 2 * 2.484e9 * n_frames_step / (codec_solo_ms * 1e-3) / 1e12,
                            "algorithmic_gmac_per_frame": 2.484, "frames_per_launch_sequence": n_frames_step,

@@ -28,6 +28,7 @@ CodecRunner::CodecRunner(const Model& m, hipStream_t st) : m_(m), st_(st) {
 CodecRunner::~CodecRunner() {
     if (buf_) (void)hipFree(buf_);
     if (lens_dev_) (void)hipFree(lens_dev_);
+    if (lens_host_) (void)hipHostFree(lens_host_);
 }
 
 void CodecRunner::ensure(size_t bytes) {

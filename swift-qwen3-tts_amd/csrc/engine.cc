@@ -919,8 +919,11 @@ int Engine::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3
     Q3_HIP(hipSetDevice(m_->device));  // lanes run on their own host threads
     Q3_CHECK(n >= 1 && n <= Bm_, 3, "Invalid input: batch size must be between 1 and max_batch");
     Q3_CHECK(groups == 16, 3, "Invalid input: num_code_groups must be 16");
-    Q3_CHECK(!jobs_[job_seq_ % kJobSlots].busy, 3,
-             "Invalid input: two jobs are already outstanding (q3tts_generate_end must be called first)");
+    Q3_CHECK(sp.audio_chunk_frames >= 0, 3, "Invalid input: audio_chunk_frames must not be negative");
+    int slot = -1;  // any free slot: jobs may be ended in any order
+    for (int i = 0; i < kJobSlots; ++i)
+        if (!jobs_[i].busy && slot < 0) slot = i;
+    Q3_CHECK(slot >= 0, 3, "Invalid input: two jobs are already outstanding (q3tts_generate_end must be called first)");
     const double t_start = now_s();
     std::vector<ResolvedRequest> rr;
     for (int i = 0; i < n; ++i) rr.push_back(resolve(reqs[i], sp));
@@ -1084,9 +1087,7 @@ int Engine::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3
     }
 
     // ---- hand the codes to the codec decoder (Qwen3.swift:943-961) on its own stream ----
-    const int slot = int(job_seq_ % kJobSlots);
     Job& J = jobs_[slot];
-    Q3_CHECK(!J.busy, 3, "Invalid input: two jobs are already outstanding (q3tts_generate_end must be called first)");
     J.n = n;
     J.up = codec_->upsample();
     J.frames.assign(size_t(n), 0);
@@ -1175,6 +1176,7 @@ int Engine::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3
         J.timing.kv_bytes_read = kvb;
     }
     J.t_start = t_start;
+    J.t_done = 0;
     J.cb = cb;
     J.user = user;
     J.request_base = request_base;
@@ -1224,6 +1226,8 @@ void Engine::compute_cuts(Job& J) {
 void Engine::stage_rows(Job& J) {
     Q3_HIP(hipSetDevice(m_->device));
     Q3_HIP(hipEventSynchronize(J.ev_codec[1]));
+    J.t_done = now_s();  // the job's own completion, not the moment end() happens to be called (a pipelined job's end()
+                         // comes after the NEXT batch's whole frame loop)
     const int n = J.n;
     J.st_pcm.assign(size_t(n), nullptr);
     J.st_codes.assign(size_t(n), nullptr);
@@ -1269,6 +1273,26 @@ void Engine::staging_loop() {
 void Engine::end(int job, q3tts_result* results) {
     Q3_CHECK(job >= 0 && job < kJobSlots && jobs_[job].busy, 3, "Invalid input: no such outstanding job");
     Job& J = jobs_[job];
+    // Whatever happens below, the slot is released and rows staged for it are freed: a failure inside end() must not
+    // leave the handle with a job nobody can end (q3tts_generate_end has already dropped the caller's handle by then).
+    struct Release {
+        Engine* e;
+        Job* j;
+        bool handed_over = false;
+        ~Release() {
+            if (!handed_over) {
+                {   // a staging thread may still be copying into the vectors
+                    std::unique_lock<std::mutex> lk(e->stage_mu_);
+                    e->stage_cv_.wait(lk, [&] { return j->stage != 1; });
+                }
+                for (float* p : j->st_pcm) std::free(p);
+                for (int32_t* p : j->st_codes) std::free(p);
+            }
+            j->st_pcm.clear();
+            j->st_codes.clear();
+            j->busy = false;
+        }
+    } release{this, &J};
     Q3_HIP(hipSetDevice(m_->device));
     const int n = J.n, up = J.up, Fdec = J.Fdec;
     const std::vector<int64_t>&row_cut = J.row_cut, &row_ns = J.row_ns;
@@ -1304,19 +1328,12 @@ void Engine::end(int job, q3tts_result* results) {
             J.stage_err = e.what();
         }
     }
-    J.busy = false;
-    if (J.stage == 3) {
-        for (float* p : J.st_pcm) std::free(p);
-        for (int32_t* p : J.st_codes) std::free(p);
-        J.st_pcm.clear();
-        J.st_codes.clear();
-        throw Error(5, J.stage_err);
-    }
+    if (J.stage == 3) throw Error(5, J.stage_err);
     float ms = 0;
     Q3_HIP(hipEventElapsedTime(&ms, J.ev_codec[0], J.ev_codec[1]));
     J.timing.codec_ms = ms;  // on the codec stream: includes whatever the next batch's AR loop took away from it
     timing = J.timing;
-    const double total = now_s() - J.t_start;
+    const double total = (J.t_done > 0 ? J.t_done : now_s()) - J.t_start;
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     for (int b = 0; b < n; ++b) {
@@ -1339,8 +1356,7 @@ void Engine::end(int job, q3tts_result* results) {
         r.pcm = J.st_pcm[size_t(b)];
         r.status = Q3TTS_OK;
     }
-    J.st_pcm.clear();
-    J.st_codes.clear();
+    release.handed_over = true;
     if (J.cb) {
         std::unique_lock<std::mutex> lk;
         if (cb_mutex) lk = std::unique_lock<std::mutex>(*cb_mutex);

@@ -62,7 +62,7 @@ class Engine {
     // generate() in two halves (q3tts_generate_begin / _end): begin returns once the AR loop has finished and the codec
     // decode of its codes is queued on the codec stream; end waits for the PCM and fills the results. A second begin()
     // may run between the two: its AR loop (a latency-bound chain that leaves the matrix cores idle) then overlaps the
-    // first job's decode (matrix-core bound). Jobs end in begin order; at most kJobSlots are outstanding.
+    // first job's decode (matrix-core bound). Jobs may end in any order; at most kJobSlots are outstanding.
     static constexpr int kJobSlots = 2;
     int begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3tts_event_cb cb, void* user, const DebugOpts* dbg,
               bool overlapped);  // overlapped: another batch's AR loop is expected to run beside this one's decode
@@ -152,7 +152,7 @@ class Engine {
         std::vector<hipEvent_t> chunk_done;  // chunked decode (audio_chunk_frames > 0): one per chunk, behind its copy
         int n_chunks = 0, chunk_frames = 0;
         q3tts_timing timing{};
-        double t_start = 0;
+        double t_start = 0, t_done = 0;  // begin() entered / PCM on the host (stage_rows)
         q3tts_event_cb cb = nullptr;
         void* user = nullptr;
         int request_base = 0;

@@ -35,6 +35,15 @@ class AudioGenerationInfo:  # GenerationTypes.swift:15-21
     tokens_per_second: float
     peak_memory_usage: float
 
+    @property
+    def summary(self) -> str:
+        """AudioGenerationInfo.summary (GenerationTypes.swift:39-45): the same three lines and number formats."""
+        return ("Prompt:     %d tokens, %.2f tokens/s, %.3fs\n"
+                "Generation: %d tokens, %.2f tokens/s, %.3fs\n"
+                "Peak Memory Usage: %s GB" % (self.prompt_token_count, self.prompt_token_count / max(self.prefill_time, 0.001),
+                                              self.prefill_time, self.generation_token_count, self.tokens_per_second,
+                                              self.generate_time, repr(float(self.peak_memory_usage))))
+
 
 @dataclass
 class GenerationRequest:

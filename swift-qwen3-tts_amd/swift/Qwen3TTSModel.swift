@@ -41,6 +41,16 @@ public struct AudioGenerationInfo: Sendable {   // GenerationTypes.swift:15-21
     public let promptTokenCount: Int, generationTokenCount: Int
     public let prefillTime: TimeInterval, generateTime: TimeInterval
     public let tokensPerSecond: Double, peakMemoryUsage: Double
+
+    /// GenerationTypes.swift:39-45 (same three lines, same number formats)
+    public var summary: String {
+        let promptRate = String(format: "%.2f", Double(promptTokenCount) / max(prefillTime, 0.001))
+        return """
+        Prompt:     \(promptTokenCount) tokens, \(promptRate) tokens/s, \(String(format: "%.3f", prefillTime))s
+        Generation: \(generationTokenCount) tokens, \(String(format: "%.2f", tokensPerSecond)) tokens/s, \(String(format: "%.3f", generateTime))s
+        Peak Memory Usage: \(peakMemoryUsage) GB
+        """
+    }
 }
 
 public enum AudioGeneration: Sendable {   // GenerationTypes.swift:51-58
@@ -160,8 +170,14 @@ public final class Qwen3TTSModel {
         let instructIds = (instruct?.isEmpty == false)
             ? tokenizer.encode(text: "<|im_start|>user\n\(instruct!)<|im_end|>\n").map(Int32.init) : []
         let targetCount = Int32(tokenizer.encode(text: text).count)
-        var sampling = q3tts_sampling(temperature: temperature, top_k: Int32(topK), top_p: topP,
-                                      repetition_penalty: repetitionPenalty, seed: seed, force_frames: 0)
+        // defaults first, then the fields this call sets: fields added to the C struct later keep their defaults here
+        var sampling = q3tts_sampling()
+        q3tts_default_sampling(&sampling)
+        sampling.temperature = temperature
+        sampling.top_k = Int32(topK)
+        sampling.top_p = topP
+        sampling.repetition_penalty = repetitionPenalty
+        sampling.seed = seed
         var result = q3tts_result()
         let box = Unmanaged.passRetained(EventBox(onEvent))
         defer { box.release(); q3tts_result_free(&result, 1) }
@@ -201,7 +217,8 @@ private let eventTrampoline: q3tts_event_cb = { user, evp in
         box.f?(.info(AudioGenerationInfo(promptTokenCount: Int(i.prompt_token_count), generationTokenCount: Int(i.generation_token_count),
                                          prefillTime: i.prefill_time, generateTime: i.generate_time,
                                          tokensPerSecond: i.tokens_per_second, peakMemoryUsage: i.peak_memory_usage)))
-    default: box.f?(.audio(Array(UnsafeBufferPointer(start: ev.pcm, count: Int(ev.n_samples)))))
+    case Q3TTS_EVENT_AUDIO: box.f?(.audio(Array(UnsafeBufferPointer(start: ev.pcm, count: Int(ev.n_samples)))))
+    default: break   // AUDIO_CHUNK pieces (only with audio_chunk_frames > 0, which this wrapper never sets) are not part of the reference's enum
     }
 }
 
