@@ -163,6 +163,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (profiling)")
     ap.add_argument("--streams", type=int, default=0, help="lanes per GPU (0 = engine default)")
     ap.add_argument("--no-pipeline", action="store_true", help="one batch at a time (no codec / AR overlap between steps)")
+    ap.add_argument("--codec-cus", type=int, default=0, help="q3tts_load_opts.codec_overlap_cus (0 = engine default, -1 = no mask)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -193,7 +194,7 @@ def main():
     rep = 1.5 if clone else 1.05  # generateVoiceClone's default (Qwen3.swift:1017)
     # rank 0 reads the checkpoint; replicas receive the weight arena by one RCCL broadcast over xGMI
     model = Qwen3TTSModel.from_pretrained(ckpt, device=local, max_batch=B, max_frames=args.frames + 8, max_prompt=192 if clone else 128,
-                                          use_graph=not args.no_graph, n_streams=args.streams,
+                                          use_graph=not args.no_graph, n_streams=args.streams, codec_overlap_cus=args.codec_cus,
                                           weights_from_broadcast=(world > 1 and rank != 0))
     if world > 1:
         import torch

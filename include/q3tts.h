@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define Q3TTS_ABI_VERSION 2
+#define Q3TTS_ABI_VERSION 3
 
 typedef struct q3tts_model q3tts_model;
 
@@ -50,7 +50,12 @@ typedef struct {
                                        disk; the caller fills it (RCCL broadcast from rank 0) via
                                        q3tts_model_arena before the first generate */
     int32_t n_streams;  /* lanes the batch is split over (own HIP stream + hipGraph + host thread each);
-                           0 = default (1). Results do not depend on it (rows are independent) */
+                           0 = default (1). Results do not depend on it (rows are independent). With more than one
+                           lane q3tts_generate_begin runs its job to completion (TOKEN, INFO and AUDIO events fire inside
+                           begin) and q3tts_generate_end only hands the results over: nothing overlaps */
+    int32_t codec_overlap_cus; /* compute units a codec decode is confined to while the NEXT batch's frame loop runs beside it
+                           (q3tts_generate_begin with more_follows != 0); multiple of 8; 0 = default (tuned for a 1.7B
+                           talker at batch 32), -1 = never confine. Results do not depend on it */
 } q3tts_load_opts;
 
 void q3tts_default_load_opts(q3tts_load_opts* o);
@@ -125,6 +130,15 @@ typedef struct {
     int32_t audio_chunk_frames; /* new (the reference decodes one-shot, README.md:140): > 0 delivers the waveform in pieces of
                                    this many codec frames through AUDIO_CHUNK events as the causal tail of the decoder
                                    produces them, before INFO / AUDIO; the samples are bit-identical to the one-shot decode */
+    int32_t audio_window_frames; /* 0 (default): the chunks above are cut after the last token, from the exact decode.
+                                   > 0 (with audio_chunk_frames > 0): audio leaves WHILE tokens are still being generated. The
+                                   decoder's pre-transformer is bidirectional over the whole utterance (SpeechTokenizer.swift:763),
+                                   so a chunk is then computed from the frames that exist: this many frames of left context and
+                                   audio_lookahead_frames to the right; everything behind the pre-transformer is causal and
+                                   carries its state from chunk to chunk (exact). The waveform differs from the one-shot decode
+                                   by a bounded amount (tests/test_streaming.py); AUDIO then carries the
+                                   concatenation of the chunks. Not combined with voice-clone rows (those fall back to 0) */
+    int32_t audio_lookahead_frames; /* frames to the right of a chunk that must exist before it is decoded (default 4) */
 } q3tts_sampling;
 void q3tts_default_sampling(q3tts_sampling* s);
 
@@ -198,6 +212,13 @@ q3tts_status q3tts_generate_end(q3tts_model* m, q3tts_job* job, q3tts_result* re
 q3tts_status q3tts_codec_decode(q3tts_model* m, const int32_t* codes, const int32_t* n_frames,
                                 int32_t batch, int32_t max_frames, float* pcm, int64_t* audio_lengths);
 
+/* The same decode the way a stream produces it (q3tts_sampling.audio_window_frames): chunks of `chunk_frames` frames, the causal
+ * tail carrying its state between them, the pre-transformer over [chunk start - window, chunk end + lookahead) -- or, with
+ * window < 0, once over all frames, which makes the result bit-identical to q3tts_codec_decode. For tests and for callers that
+ * hold a code sequence and want the bounded-latency arithmetic. */
+q3tts_status q3tts_codec_decode_streamed(q3tts_model* m, const int32_t* codes, const int32_t* n_frames, int32_t batch,
+                                         int32_t max_frames, int32_t chunk_frames, int32_t window, int32_t lookahead, float* pcm);
+
 /* Qwen3TTSSpeechTokenizer.encode (Models/SpeechTokenizer.swift:841-846 -> SpeechTokenizerEncoder.swift:1031-1056):
  * 24 kHz mono float32 waveform -> codes [16][*n_frames] int32 (code row major, as the reference returns
  * [1, 16, time]); cap_frames = capacity of `codes` in frames (q3tts_codec_encoded_frames gives the exact count). */
@@ -237,6 +258,7 @@ typedef struct {
     int32_t rows;
     int64_t kv_bytes_read;  /* algorithmic KV bytes read over all frame steps */
     double frontend_ms;     /* voice clone: codec encoder + speaker encoder over all rows of the call */
+    double first_audio_ms;  /* streamed decode: request in -> first AUDIO_CHUNK samples on the host (0 when nothing streamed) */
 } q3tts_timing;
 q3tts_status q3tts_last_timing(const q3tts_model* m, q3tts_timing* out);
 

@@ -48,6 +48,7 @@ void q3tts_default_load_opts(q3tts_load_opts* o) {
     o->use_graph = 1;
     o->weights_from_broadcast = 0;
     o->n_streams = 0;
+    o->codec_overlap_cus = 0;
 }
 
 void q3tts_default_sampling(q3tts_sampling* s) {  // Qwen3.swift:1296-1299
@@ -58,6 +59,8 @@ void q3tts_default_sampling(q3tts_sampling* s) {  // Qwen3.swift:1296-1299
     s->seed = 0;
     s->force_frames = 0;
     s->audio_chunk_frames = 0;
+    s->audio_window_frames = 0;
+    s->audio_lookahead_frames = 4;
 }
 
 q3tts_status q3tts_model_load(const char* model_dir, const q3tts_load_opts* opts, q3tts_model** out) {
@@ -332,6 +335,14 @@ q3tts_status q3tts_debug_linear(q3tts_model* m, const uint16_t* x, const uint16_
     return guarded(m, [&] {
         Q3_CHECK(m && x && W && y, 3, "Invalid input: null argument");
         m->eng->lane0().debug_linear(x, W, bias, M, K, N, y);
+    });
+}
+
+q3tts_status q3tts_codec_decode_streamed(q3tts_model* m, const int32_t* codes, const int32_t* n_frames, int32_t batch, int32_t max_frames,
+                                         int32_t chunk_frames, int32_t window, int32_t lookahead, float* pcm) {
+    return guarded(m, [&] {
+        Q3_CHECK(m && codes && n_frames && pcm, 3, "Invalid input: null argument");
+        m->eng->lane0().codec_decode_streamed(codes, n_frames, batch, max_frames, chunk_frames, window, lookahead, pcm);
     });
 }
 

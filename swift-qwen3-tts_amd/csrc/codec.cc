@@ -29,6 +29,9 @@ CodecRunner::~CodecRunner() {
     if (buf_) (void)hipFree(buf_);
     if (lens_dev_) (void)hipFree(lens_dev_);
     if (lens_host_) (void)hipHostFree(lens_host_);
+    if (stream_.arena) (void)hipFree(stream_.arena);
+    if (stream_.lens_host) (void)hipHostFree(stream_.lens_host);
+    if (stream_.lens_dev) (void)hipFree(stream_.lens_dev);
 }
 
 void CodecRunner::ensure(size_t bytes) {
@@ -102,7 +105,15 @@ void CodecRunner::upload_lens(const int32_t* lens, int n) {
 // `post`: also (or, with out == nullptr, only) write SnakeBeta_post(result) to out2 for the next conv
 void CodecRunner::conv(const Pass& ps, const ConvW& cw, const float* x, int Tmax, int ppf, float* out, const SnakeW* sn,
                        const float* res, int act, const SnakeW* post, float* out2) {
+    if (stream_.dry) return;
     ConvGemmArgs a{};
+    // streamed decode: Tmax counts the allocation's rows (history margin + chunk); row 0 of the chunk sits behind the margin
+    const int64_t m_in = int64_t(ps.hist_frames) * ppf * cw.Cin, m_out = int64_t(ps.hist_frames) * ppf * cw.N;
+    x += m_in;
+    if (out) out += m_out;
+    if (res) res += m_out;
+    if (out2) out2 += m_out;
+    a.hist = ps.hist_frames * ppf;
     a.x = x; a.ldx = cw.Cin; a.x_bstride = int64_t(Tmax) * cw.Cin;
     a.w = cw.w; a.bias = cw.bias; a.scale = cw.scale;
     if (!fp32_mfma_) {
@@ -336,6 +347,312 @@ int CodecRunner::decode_chunked(const int32_t* codes_dev, int code_stride_frames
         Q3_HIP(hipEventRecord(chunk_done[size_t(k)], st_));
     }
     return n_chunks;
+}
+
+}  // namespace q3
+
+// ---------------------------------------------------------------------------------------------------------------------
+// streamed decode (row f1)
+// ---------------------------------------------------------------------------------------------------------------------
+namespace q3 {
+
+// Frames of history a tail tensor must carry so that every causal conv finds its halo in it: (K - 1) * dilation rows at the
+// tensor's rate, rounded up to whole frames (SpeechTokenizer.swift:298-301: left padding only).
+int CodecRunner::hist_frames() const {
+    const CodecDecoderConfig& dc = m_.cfg.codec;
+    int need = 1, ppf = 1;
+    for (int r : dc.upsampling_ratios) {
+        ppf *= r;
+        need = std::max(need, ceil_div(6, ppf));  // ConvNeXt depthwise k7
+    }
+    need = std::max(need, ceil_div(6, ppf));      // initConv k7
+    for (int r : dc.upsample_rates) {
+        need = std::max(need, 1);                 // transposed conv: one earlier input row
+        ppf *= r;
+        need = std::max(need, ceil_div(6 * 9, ppf));  // residual units, k7 with dilation up to 9
+    }
+    need = std::max(need, ceil_div(6, ppf));      // outConv k7
+    return need;
+}
+
+float* CodecRunner::sbuf(size_t frame_floats, bool keeps_history) {
+    Stream& S = stream_;
+    S.off = align_up(S.off, 256);
+    float* p = S.dry ? nullptr : reinterpret_cast<float*>(S.arena + S.off);
+    S.off += size_t(S.cfg.rows) * S.Tal * frame_floats * sizeof(float);
+    if (keeps_history && !S.dry) S.rolls.emplace_back(p, frame_floats);
+    return p;
+}
+
+void CodecRunner::stream_open(const StreamCfg& cfg) {
+    Stream& S = stream_;
+    Q3_CHECK(!S.open, 3, "Invalid input: a streamed decode is already open on this model");
+    const CodecDecoderConfig& dc = m_.cfg.codec;
+    S.cfg = cfg;
+    S.hist = hist_frames();
+    Q3_CHECK(cfg.rows >= 1 && cfg.max_frames >= 1 && cfg.lookahead >= 0, 3, "Invalid input: streamed decode geometry");
+    Q3_CHECK(cfg.chunk_frames >= S.hist, 3, "Invalid input: audio_chunk_frames of a streamed decode must be at least " + std::to_string(S.hist));
+    S.Tal = S.hist + cfg.chunk_frames;
+    S.next_chunk = 0;
+    S.front_done = false;
+    S.lens_used = 0;
+    const int n_chunks = ceil_div(cfg.max_frames, cfg.chunk_frames);
+    // front scratch: the widest front tensor over the longest window
+    const int Fwin = cfg.window < 0 ? cfg.max_frames : std::min(cfg.max_frames, cfg.window + cfg.chunk_frames + cfg.lookahead);
+    size_t front_pf = std::max<size_t>(size_t(2) * m_.codec.inner, size_t(dc.codebook_dim));
+    front_pf = std::max(front_pf, size_t(3) * dc.num_attention_heads * 64);
+    front_pf = std::max(front_pf, size_t(2) * dc.intermediate_size);
+    front_pf = std::max(front_pf, size_t(dc.latent_dim));
+    S.fbuf_floats = size_t(cfg.rows) * Fwin * front_pf;
+    // layout pass (no launches: the walk below and run_tail_stream only count), then one allocation
+    auto take = [&](size_t floats) {
+        S.off = align_up(S.off, 256);
+        float* p = S.arena ? reinterpret_cast<float*>(S.arena + S.off) : nullptr;
+        S.off += floats * sizeof(float);
+        return p;
+    };
+    S.dry = true;
+    S.off = 0;
+    for (int i = 0; i < 4; ++i) (void)take(S.fbuf_floats);
+    if (cfg.window < 0) (void)take(size_t(cfg.rows) * cfg.max_frames * dc.latent_dim);
+    (void)sbuf(size_t(dc.latent_dim), false);
+    (void)sbuf(size_t(up_), false);
+    {
+        Pass ps{};
+        ps.nb = cfg.rows;
+        ps.hist_frames = S.hist;
+        run_tail_stream(ps, nullptr, nullptr);
+    }
+    const size_t need = align_up(S.off, 256);
+    if (need > S.arena_bytes) {
+        Q3_HIP(hipStreamSynchronize(st_));
+        if (S.arena) Q3_HIP(hipFree(S.arena));
+        S.arena = nullptr;
+        S.arena_bytes = 0;
+        Q3_HIP(hipMalloc(reinterpret_cast<void**>(&S.arena), need));
+        S.arena_bytes = need;
+    }
+    S.dry = false;
+    S.off = 0;
+    S.rolls.clear();
+    for (auto& f : S.fbufs) f = take(S.fbuf_floats);
+    S.x_all = cfg.window < 0 ? take(size_t(cfg.rows) * cfg.max_frames * dc.latent_dim) : nullptr;
+    S.lat = sbuf(size_t(dc.latent_dim), false);
+    S.pcm = sbuf(size_t(up_), false);
+    S.dry = false;
+    // history margins start as zeros: the causal left padding of the first chunk
+    Q3_HIP(hipMemsetAsync(S.arena, 0, need, st_));
+    const size_t slots = size_t(2) * n_chunks + 2;
+    if (slots * cfg.rows > S.lens_slots) {
+        if (S.lens_host) Q3_HIP(hipHostFree(S.lens_host));
+        if (S.lens_dev) Q3_HIP(hipFree(S.lens_dev));
+        S.lens_host = nullptr;
+        S.lens_dev = nullptr;
+        Q3_HIP(hipHostMalloc(reinterpret_cast<void**>(&S.lens_host), slots * cfg.rows * 4, hipHostMallocDefault));
+        Q3_HIP(hipMalloc(reinterpret_cast<void**>(&S.lens_dev), slots * cfg.rows * 4));
+        S.lens_slots = slots * cfg.rows;
+    }
+    S.open = true;
+}
+
+void CodecRunner::stream_close() {
+    stream_.open = false;  // the arena stays for the next stream of the same shape
+}
+
+int CodecRunner::stream_push(const int32_t* codes_dev, int code_stride_frames, const int* avail, const uint8_t* final_rows, float* pcm_host,
+                             size_t pcm_row_stride, std::vector<hipEvent_t>& chunk_done) {
+    Stream& S = stream_;
+    Q3_CHECK(S.open, 3, "Invalid input: no streamed decode is open");
+    const CodecDecoderConfig& dc = m_.cfg.codec;
+    const int B = S.cfg.rows, C = S.cfg.chunk_frames, W = S.cfg.window, L = S.cfg.lookahead;
+    const size_t lat = size_t(dc.latent_dim);
+    auto lens_slot = [&](const std::vector<int32_t>& v) {
+        Q3_CHECK((S.lens_used + 1) * B <= S.lens_slots, 7, "internal error: streamed decode ran out of length slots");
+        int32_t* h = S.lens_host + S.lens_used * B;
+        int32_t* d = S.lens_dev + S.lens_used * B;
+        std::memcpy(h, v.data(), size_t(B) * 4);
+        Q3_HIP(hipMemcpyAsync(d, h, size_t(B) * 4, hipMemcpyHostToDevice, st_));
+        ++S.lens_used;
+        return d;
+    };
+    const std::string none;
+    for (;;) {
+        const int k = S.next_chunk, f0 = k * C, f1 = f0 + C;
+        if (f0 >= S.cfg.max_frames) break;
+        // decodable: every row either has its frames up to f1 + lookahead or will get no more; at least one row has a frame in it
+        bool ready = true, any = false, all_final = true;
+        int have = 0;
+        for (int b = 0; b < B; ++b) {
+            const bool fin = final_rows && final_rows[b];
+            all_final = all_final && fin;
+            if (!fin && avail[b] < std::min(S.cfg.max_frames, f1 + (W < 0 ? S.cfg.max_frames : L))) ready = false;
+            any = any || avail[b] > f0;
+            have = std::max(have, avail[b]);
+        }
+        if (!ready) break;
+        if (!any) {
+            if (all_final) break;  // nothing left anywhere
+            break;
+        }
+        std::vector<int32_t> v((size_t)(B));
+        Pass ps{};
+        ps.nb = B;
+        ps.stage = &none;
+        // ---- pre-transformer over the window (or, window < 0, once over everything) ----
+        int w0 = 0;
+        if (W < 0) {
+            if (!S.front_done) {
+                for (int b = 0; b < B; ++b) v[size_t(b)] = avail[b];
+                ps.fr = lens_slot(v);
+                run_front(ps, codes_dev, code_stride_frames, S.cfg.max_frames, S.fbufs);
+                Q3_HIP(hipMemcpyAsync(S.x_all, S.fbufs[0], size_t(B) * S.cfg.max_frames * lat * 4, hipMemcpyDeviceToDevice, st_));
+                S.front_done = true;
+            }
+            Q3_HIP(hipMemcpy2DAsync(S.lat + size_t(S.hist) * lat, size_t(S.Tal) * lat * 4, S.x_all + size_t(f0) * lat,
+                                    size_t(S.cfg.max_frames) * lat * 4, size_t(std::min(C, S.cfg.max_frames - f0)) * lat * 4, size_t(B),
+                                    hipMemcpyDeviceToDevice, st_));
+        } else {
+            w0 = std::max(0, f0 - W);
+            const int w1 = std::min(have, f1 + L), Fw = w1 - w0;
+            for (int b = 0; b < B; ++b) v[size_t(b)] = std::max(0, std::min(avail[b], w1) - w0);
+            ps.fr = lens_slot(v);
+            run_front(ps, codes_dev + size_t(w0) * 16, code_stride_frames, Fw, S.fbufs);
+            Q3_HIP(hipMemcpy2DAsync(S.lat + size_t(S.hist) * lat, size_t(S.Tal) * lat * 4, S.fbufs[0] + size_t(f0 - w0) * lat,
+                                    size_t(Fw) * lat * 4, size_t(std::min(C, w1 - f0)) * lat * 4, size_t(B), hipMemcpyDeviceToDevice, st_));
+        }
+        // ---- the causal tail over the chunk, state carried in the tensors' margins ----
+        for (int b = 0; b < B; ++b) v[size_t(b)] = std::max(0, std::min(avail[b], f1) - f0);
+        ps.fr = lens_slot(v);
+        ps.hist_frames = S.hist;
+        S.off = 0;       // the same walk over the arena as in stream_open
+        S.rolls.clear();
+        {
+            auto skip = [&](size_t floats) {
+                S.off = align_up(S.off, 256);
+                S.off += floats * sizeof(float);
+            };
+            for (int i = 0; i < 4; ++i) skip(S.fbuf_floats);
+            if (W < 0) skip(size_t(B) * S.cfg.max_frames * lat);
+            (void)sbuf(lat, false);
+            (void)sbuf(size_t(up_), false);
+        }
+        Q3_HIP(hipMemsetAsync(S.pcm, 0, size_t(B) * S.Tal * up_ * 4, st_));
+        run_tail_stream(ps, S.lat, S.pcm);
+        for (auto& r : S.rolls)
+            launch_roll_history(r.first + size_t(S.hist) * r.second, int64_t(S.Tal) * int64_t(r.second), int64_t(S.hist) * int64_t(r.second),
+                                int64_t(C) * int64_t(r.second), B, st_);
+        Q3_HIP(hipMemcpy2DAsync(pcm_host + size_t(f0) * up_, pcm_row_stride * sizeof(float), S.pcm + size_t(S.hist) * up_,
+                                size_t(S.Tal) * up_ * sizeof(float), size_t(std::min(C, S.cfg.max_frames - f0)) * up_ * sizeof(float), size_t(B),
+                                hipMemcpyDeviceToHost, st_));
+        while (int(chunk_done.size()) <= k) {
+            hipEvent_t e = nullptr;
+            Q3_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            chunk_done.push_back(e);
+        }
+        Q3_HIP(hipEventRecord(chunk_done[size_t(k)], st_));
+        ++S.next_chunk;
+    }
+    return S.next_chunk;
+}
+
+// run_tail (steps 5-7, SpeechTokenizer.swift:767-781) over one chunk of a stream. The launches and their arguments are
+// run_tail's; what differs is where the tensors live: each in its own persistent buffer of Tal = hist + chunk frames per row
+// whose first `hist` frames are the previous chunk's last ones (rolled in by stream_push), so a conv's causal halo comes
+// from memory instead of being zero (first chunk: the margins are zero, i.e. exactly the reference's left padding).
+void CodecRunner::run_tail_stream(const Pass& ps, float* lat, float* pcm) {
+    const CodecDecoderConfig& dc = m_.cfg.codec;
+    const CodecW& w = m_.codec;
+    const Stream& S = stream_;
+    const int nb = ps.nb;
+    const int32_t* fr = ps.fr;
+    const int H = ps.hist_frames;
+    int T = S.Tal, ppf = 1;  // T: rows of an allocation at the current rate
+    float* h = lat;
+    // 5. upsample stages
+    for (size_t i = 0; i < w.ups.size(); ++i) {
+        const auto& U = w.ups[i];
+        const int C = U.tconv.N / U.stride;
+        const size_t ff = size_t(ppf) * U.stride * C;  // floats per frame behind the transposed conv
+        float* y = sbuf(ff, true);                     // dwconv reads six rows back
+        float* t1 = sbuf(ff, false);
+        float* t2 = sbuf(size_t(ppf) * U.stride * U.pw1.N, false);
+        const bool last = i + 1 == w.ups.size();
+        float* yo = sbuf(ff, last);                    // the last stage feeds initConv (k7)
+        conv(ps, U.tconv, h, T, ppf, y, nullptr, nullptr, 0);
+        T *= U.stride;
+        ppf *= U.stride;
+        if (!S.dry)
+            launch_dwconv_ln(y + size_t(H) * ff, U.dw_w, U.dw_b, U.ln_w, U.ln_b, 1e-6f, C, fr, ppf, T, nb, t1 + size_t(H) * ff, st_, H * ppf);
+        conv(ps, U.pw1, t1, T, ppf, t2, nullptr, nullptr, 1);
+        conv(ps, U.pw2, t2, T, ppf, yo, nullptr, y, 0);  // out of place: y keeps the values dwconv needs as history
+        h = yo;
+    }
+    // 6. MainDecoder
+    const size_t nblk = w.blocks.size();
+    float* ys = nullptr;  // SnakeBeta of the previous stage's output = the next transposed conv's input
+    {
+        const size_t ff = size_t(ppf) * w.init_conv.N;
+        float* y = sbuf(ff, nblk == 0);
+        ys = nblk ? sbuf(ff, true) : nullptr;  // transposed conv: one row back
+        conv(ps, w.init_conv, h, T, ppf, y, nullptr, nullptr, 0, nblk ? &w.blocks[0].snake : nullptr, ys);
+        h = y;
+    }
+    for (size_t i = 0; i < nblk; ++i) {
+        const auto& Bk = w.blocks[i];
+        const SnakeW* after = i + 1 < nblk ? &w.blocks[i + 1].snake : nullptr;
+        const bool lastb = i + 1 == nblk;
+        bool fused = !fp32_mfma_ && !no_fuse_ && resunit_supported(Bk.Cout, Bk.res[0].conv1.K, 9);
+        for (int j = 0; j < 3; ++j)
+            fused = fused && Bk.res[j].conv1.w3 && Bk.res[j].conv2.w3p && Bk.res[j].conv1.wh && Bk.res[j].conv2.whp &&
+                    Bk.res[j].conv1.N == Bk.Cout && Bk.res[j].conv2.K == 1 &&
+                    resunit_supported(Bk.Cout, Bk.res[j].conv1.K, Bk.res[j].conv1.dil);
+        const size_t ff = size_t(ppf) * Bk.stride * Bk.Cout;
+        float* hs_next = after ? sbuf(ff, true) : nullptr;
+        if (fused) {
+            float* yb[4];
+            for (int j = 0; j < 3; ++j) yb[j] = sbuf(ff, true);   // inputs of the three units (k7, dilated)
+            yb[3] = sbuf(ff, lastb);                               // block output; the last one feeds outConv (k7)
+            conv(ps, Bk.tconv, ys, T, ppf, yb[0], nullptr, nullptr, 0);
+            T *= Bk.stride;
+            ppf *= Bk.stride;
+            for (int j = 0; j < 3; ++j) {
+                ResUnitArgs r{};
+                r.y = yb[j] + size_t(H) * ff; r.out = yb[j + 1] + size_t(H) * ff;
+                if (j == 2 && after) { r.out2 = hs_next + size_t(H) * ff; r.post_ea = after->ea; r.post_ib = after->ib; }
+                r.b1 = Bk.res[j].conv1.bias; r.b2 = Bk.res[j].conv2.bias;
+                if (bf16x3_) { r.w1 = Bk.res[j].conv1.w3; r.w2p = Bk.res[j].conv2.w3p; }
+                else { r.w1h = Bk.res[j].conv1.wh; r.w2ph = Bk.res[j].conv2.whp; r.wsc1 = Bk.res[j].conv1.wsc; r.wsc2 = Bk.res[j].conv2.wsc; }
+                r.ea1 = Bk.res[j].act1.ea; r.ib1 = Bk.res[j].act1.ib; r.ea2 = Bk.res[j].act2.ea; r.ib2 = Bk.res[j].act2.ib;
+                r.frames = fr; r.ppf = ppf; r.Tmax = T; r.B = nb; r.C = Bk.Cout; r.K = Bk.res[j].conv1.K; r.dil = Bk.res[j].conv1.dil;
+                r.hist = H * ppf;
+                if (!S.dry) launch_resunit(r, st_);
+            }
+            h = yb[3];
+        } else {
+            float* y = sbuf(ff, lastb);
+            float* ya[3];
+            for (int j = 0; j < 3; ++j) ya[j] = sbuf(ff, true);  // act1_j(y): conv1_j's input (k7, dilated)
+            float* t1 = sbuf(ff, false);
+            conv(ps, Bk.tconv, ys, T, ppf, y, nullptr, nullptr, 0, &Bk.res[0].act1, ya[0]);
+            T *= Bk.stride;
+            ppf *= Bk.stride;
+            for (int j = 0; j < 3; ++j) {
+                conv(ps, Bk.res[j].conv1, ya[j], T, ppf, nullptr, nullptr, nullptr, 0, &Bk.res[j].act2, t1);
+                const SnakeW* next = j < 2 ? &Bk.res[j + 1].act1 : after;
+                conv(ps, Bk.res[j].conv2, t1, T, ppf, y, nullptr, y, 0, next, j < 2 ? ya[j + 1] : hs_next);
+            }
+            h = y;
+        }
+        ys = hs_next;
+    }
+    // 7. outSnake -> outConv -> clip
+    if (!S.dry) {
+        const size_t ff = size_t(ppf) * w.out_C;
+        launch_out_conv(h + size_t(H) * ff, w.out_C, w.out_snake.ea, w.out_snake.ib, w.out_w, w.out_b, fr, ppf, T, nb,
+                        pcm + size_t(H) * ppf, st_, H * ppf);
+    }
+    Q3_CHECK(ppf == up_, 7, "internal error: codec upsampling mismatch");
+    (void)dc;
 }
 
 }  // namespace q3

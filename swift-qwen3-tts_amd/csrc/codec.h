@@ -26,6 +26,28 @@ class CodecRunner {
     int decode_chunked(const int32_t* codes_dev, int code_stride_frames, const std::vector<int>& frames, int chunk_frames,
                        float* pcm_host, std::vector<hipEvent_t>& chunk_done);
     int tail_context_frames() const;
+
+    // ---- streamed decode (row f1: audio while tokens are still being generated) -------------------------------------
+    // The causal tail keeps its own state between chunks: every tensor a causal conv reads lives in a persistent buffer
+    // with `hist_frames()` frames of margin in front, into which the last frames of a chunk are rolled, so chunk k + 1
+    // reads exactly the rows the one-shot decode would -- nothing is recomputed and the tail is bit-identical to decode().
+    // The pre-transformer is bidirectional over the whole utterance in the reference (SpeechTokenizer.swift:763); a stream
+    // cannot wait for the end, so chunk [f0, f1) is computed from a window of frames [f0 - window, f1 + lookahead) (what
+    // exists of it): an approximation whose distance from the one-shot decode tests/test_streaming.py measures and bounds.
+    // window < 0: the pre-transformer runs ONCE over all frames (needs every code up front; exact, for tests and offline use).
+    struct StreamCfg {
+        int rows = 0, chunk_frames = 0, window = 0, lookahead = 0, max_frames = 0;
+    };
+    void stream_open(const StreamCfg& cfg);
+    // Rows have avail[b] frames so far (final[b]: the row will get no more). Decodes every chunk that has become decodable;
+    // chunk k's samples go to pcm_host + b * pcm_row_stride + k * chunk_frames * upsample() and chunk_done[k] is recorded
+    // behind the copy (events are created as needed). Returns the number of chunks issued so far. codes: device
+    // [rows][code_stride_frames][16], frames below avail[b] final. No host synchronisation.
+    int stream_push(const int32_t* codes_dev, int code_stride_frames, const int* avail, const uint8_t* final_rows, float* pcm_host,
+                    size_t pcm_row_stride, std::vector<hipEvent_t>& chunk_done);
+    void stream_close();
+    bool streaming() const { return stream_.open; }
+    int hist_frames() const;
     int upsample() const { return up_; }
     hipStream_t stream() const { return st_; }
     void set_stream(hipStream_t st) { st_ = st; }  // the caller drains the old stream first (shared scratch)
@@ -33,6 +55,7 @@ class CodecRunner {
   private:
     struct Pass {  // one pass of kernels over `nb` rows
         int nb = 0;
+        int hist_frames = 0;  // streamed decode: tensors carry this many frames of history in front of their first row
         const int32_t* fr = nullptr;  // device: valid frames per row
         const std::string* stage = nullptr;
         std::vector<float>* stage_out = nullptr;
@@ -44,6 +67,25 @@ class CodecRunner {
     void capture(const Pass& ps, const char* name, const float* t, int T, int C);
     void run_front(const Pass& ps, const int32_t* codes, int code_stride_frames, int Fmax, float* const* bufs);
     void run_tail(const Pass& ps, int Tframes, float* const* bufs, float* pcm);
+    // the tail over one chunk of a stream: `lat` = the chunk's pre-transformer frames (stream layout), pcm out (stream layout)
+    void run_tail_stream(const Pass& ps, float* lat, float* pcm);
+    float* sbuf(size_t frame_floats, bool keeps_history);  // next persistent tensor of the stream (same order every chunk)
+    struct Stream {
+        bool open = false, dry = false;
+        StreamCfg cfg;
+        int hist = 0, Tal = 0;       // margin frames, frames per allocation (hist + chunk)
+        int next_chunk = 0;
+        bool front_done = false;     // window < 0: the pre-transformer ran over all frames
+        uint8_t* arena = nullptr;
+        size_t arena_bytes = 0, off = 0;
+        std::vector<std::pair<float*, size_t>> rolls;  // (allocation base, frame floats) of the tensors with history
+        float *lat = nullptr, *pcm = nullptr, *x_all = nullptr;
+        float* fbufs[4] = {nullptr, nullptr, nullptr, nullptr};
+        size_t fbuf_floats = 0;
+        int32_t* lens_host = nullptr;  // pinned, one slot per (chunk, kind): never reused inside a stream
+        int32_t* lens_dev = nullptr;
+        size_t lens_slots = 0, lens_used = 0;
+    } stream_;
     size_t floats_per_frame() const;
     void upload_lens(const int32_t* lens, int n);
     int32_t* lens_host_ = nullptr;

@@ -42,6 +42,7 @@ struct ConvGemmArgs {
     int ldx2;
     int shift;              // input row = t - (K-1)*dil + shift + tap*dil: "same" convs use shift = (K-1)*dil/2
     int reflect;            // 1: rows outside [0,T) are mirrored (reflectPad1d, SpeakerEncoder.swift:26-40), else zero
+    int hist;               // streamed decode: rows -hist .. -1 in front of x are the previous chunk's last rows (else zero padding)
 };
 void launch_conv_gemm(const ConvGemmArgs& a, hipStream_t st);
 
@@ -68,6 +69,7 @@ struct ResUnitArgs {
     const float* ib2;
     const int32_t* frames;
     int ppf, Tmax, B, C, K, dil;
+    int hist;             // as ConvGemmArgs::hist, for y
 };
 bool resunit_supported(int C, int K, int dil);
 void launch_resunit(const ResUnitArgs& a, hipStream_t st);
@@ -81,7 +83,7 @@ void launch_rmsnorm_f32(const float* x, const float* w, float eps, int C, const 
                         int B, float* out, hipStream_t st);
 // depthwise causal conv k7 + LayerNorm (ConvNeXtBlock, SpeechTokenizer.swift:389-393)
 void launch_dwconv_ln(const float* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
-                      float eps, int C, const int32_t* frames, int ppf, int Tmax, int B, float* out, hipStream_t st);
+                      float eps, int C, const int32_t* frames, int ppf, int Tmax, int B, float* out, hipStream_t st, int hist = 0);
 // out[t][i] = silu(gu[t][i]) * gu[t][I+i] (DecoderMLP, SpeechTokenizer.swift:560-562)
 void launch_silu_mul_f32(const float* gu, int I, const int32_t* frames, int ppf, int Tmax, int B, float* out,
                          hipStream_t st);
@@ -91,7 +93,9 @@ void launch_attn_full_f32(const float* qkv, int heads, const int32_t* frames, in
                           hipStream_t st);
 // SnakeBeta -> k7 conv C->1 -> clip(-1,1) (MainDecoder tail, SpeechTokenizer.swift:687-688,781)
 void launch_out_conv(const float* x, int C, const float* ea, const float* ib, const float* w, const float* bias,
-                     const int32_t* frames, int ppf, int Tmax, int B, float* pcm, hipStream_t st);
+                     const int32_t* frames, int ppf, int Tmax, int B, float* pcm, hipStream_t st, int hist = 0);
+// streamed decode: rows [chunk_rows - keep_rows, chunk_rows) of every batch row move to [-keep_rows, 0) (history of the next chunk)
+void launch_roll_history(float* cur, int64_t bstride, int64_t keep_floats, int64_t chunk_floats, int B, hipStream_t st);
 
 // ---- voice-clone front end (kernels/voice_frontend.hip) ------------------------------------------
 // first SEANet conv: 1 -> C channels, causal k taps (SpeechTokenizerEncoder.swift:404-414). w [C][K], out [S][C]

@@ -44,7 +44,7 @@ Engine::Engine(Model* model, const q3tts_load_opts& opts) : m_(model), opts_(opt
         // AR chain's workgroups then queue behind them (prefill 23 -> 165 ms, nothing gained). Confined to half of the CUs
         // (mask bits interleave over the XCDs) the decode takes 1.7x as long but leaves the chain room: 879 -> 826 ms
         // per pipelined step at 1.7B / batch 32 (96 CUs: 841, 160: 841, 192: 856). A decode that nothing overlaps
-        // (generate(), codec_decode) uses the unmasked stream. Q3TTS_CODEC_CUS overrides the CU count (0: never mask).
+        // (generate(), codec_decode) uses the unmasked stream. q3tts_load_opts.codec_overlap_cus overrides the CU count.
         int least = 0, greatest = 0;
         Q3_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
         Q3_HIP(hipStreamCreateWithPriority(&st_, hipStreamNonBlocking, greatest));
@@ -52,7 +52,8 @@ Engine::Engine(Model* model, const q3tts_load_opts& opts) : m_(model), opts_(opt
         hipDeviceProp_t prop{};
         Q3_HIP(hipGetDeviceProperties(&prop, m_->device));
         int cus = prop.multiProcessorCount / 2;
-        if (const char* e = std::getenv("Q3TTS_CODEC_CUS")) cus = std::atoi(e);
+        if (opts.codec_overlap_cus > 0) cus = opts.codec_overlap_cus;   // q3tts_load_opts: the caller's own tuning
+        else if (opts.codec_overlap_cus < 0) cus = 0;
         cus = std::min(cus, prop.multiProcessorCount) / 8 * 8;
         if (cus > 0 && cus < prop.multiProcessorCount) {
             std::vector<uint32_t> mask(size_t(ceil_div(prop.multiProcessorCount, 32)), 0u);
@@ -63,8 +64,11 @@ Engine::Engine(Model* model, const q3tts_load_opts& opts) : m_(model), opts_(opt
             Q3_HIP(hipExtStreamCreateWithCUMask(&st_codec_part_, uint32_t(mask.size()), mask.data()));
         }
     }
-    for (auto& J : jobs_)
+    for (auto& J : jobs_) {
         for (auto& e : J.ev_codec) Q3_HIP(hipEventCreate(&e));
+        Q3_HIP(hipEventCreate(&J.ev_begin));
+        Q3_HIP(hipEventCreate(&J.ev_first_audio));
+    }
     for (auto& e : ev_) Q3_HIP(hipEventCreate(&e));
     for (auto& e : burst_ev_) Q3_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto& e : ev_fe_) Q3_HIP(hipEventCreate(&e));
@@ -121,6 +125,8 @@ Engine::~Engine() {
         if (J.pcm_host) (void)hipHostFree(J.pcm_host);
         for (auto& e : J.ev_codec)
             if (e) (void)hipEventDestroy(e);
+        if (J.ev_begin) (void)hipEventDestroy(J.ev_begin);
+        if (J.ev_first_audio) (void)hipEventDestroy(J.ev_first_audio);
     }
     if (ws_) (void)hipFree(ws_);
     for (void* p : {(void*)forced_dev_, (void*)sampled_dev_, (void*)tl_dump_, (void*)cl_dump_})
@@ -925,6 +931,7 @@ int Engine::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3
         if (!jobs_[i].busy && slot < 0) slot = i;
     Q3_CHECK(slot >= 0, 3, "Invalid input: two jobs are already outstanding (q3tts_generate_end must be called first)");
     const double t_start = now_s();
+    Q3_HIP(hipEventRecord(jobs_[slot].ev_begin, st_));
     std::vector<ResolvedRequest> rr;
     for (int i = 0; i < n; ++i) rr.push_back(resolve(reqs[i], sp));
     if (dbg)
@@ -1020,6 +1027,68 @@ int Engine::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3
     }
     Q3_HIP(hipEventRecord(ev_[1], st_));
 
+    // ---- streamed decode (row f1): chunks of the waveform leave while the loop below is still producing tokens ----
+    Job& J = jobs_[slot];
+    const bool streamed = sp.audio_chunk_frames > 0 && sp.audio_window_frames > 0 && !any_clone && !dbg && m_->has_codec;
+    hipStream_t sst = nullptr;
+    std::vector<int> s_avail((size_t)(n), 0);
+    std::vector<uint8_t> s_final((size_t)(n), 0);
+    J.streamed = false;
+    J.chunks_fired = 0;
+    J.t_first_audio = 0;
+    J.n_chunks = 0;
+    if (streamed) {
+        J.n = n;
+        J.up = codec_->upsample();
+        J.Fdec = Fcap_;  // row stride of the job's code and PCM buffers: the final lengths are not known yet
+        J.chunk_frames = sp.audio_chunk_frames;
+        J.cb = cb;
+        J.user = user;
+        J.request_base = request_base;
+        const size_t need = size_t(n) * Fcap_ * 16, floats = size_t(n) * Fcap_ * J.up;
+        if (need > J.dec_codes_cap) {
+            if (J.dec_codes) Q3_HIP(hipFree(J.dec_codes));
+            J.dec_codes = nullptr;
+            Q3_HIP(hipMalloc(reinterpret_cast<void**>(&J.dec_codes), need * 4));
+            J.dec_codes_cap = need;
+        }
+        if (floats > J.pcm_host_cap) {
+            if (J.pcm_host) Q3_HIP(hipHostFree(J.pcm_host));
+            J.pcm_host = nullptr;
+            Q3_HIP(hipHostMalloc(reinterpret_cast<void**>(&J.pcm_host), floats * 4, hipHostMallocDefault));
+            J.pcm_host_cap = floats;
+        }
+        // the decode runs beside this batch's own frame loop: the confined stream, like a decode beside the next batch's
+        sst = codec_stream(true);
+        CodecRunner::StreamCfg cfg;
+        cfg.rows = n; cfg.chunk_frames = sp.audio_chunk_frames; cfg.window = sp.audio_window_frames;
+        cfg.lookahead = std::max(0, sp.audio_lookahead_frames); cfg.max_frames = Fcap_;
+        Q3_HIP(hipEventRecord(J.ev_codec[0], sst));
+        codec_->stream_open(cfg);
+        J.streamed = true;
+    }
+    struct StreamGuard {  // an exception below must not leave the runner's stream open
+        CodecRunner* c;
+        bool on;
+        ~StreamGuard() { if (on && c->streaming()) c->stream_close(); }
+    } stream_guard{codec_.get(), streamed};
+    // frames [0, upto) of every row exist on the device once the copy below has run: hand them to the decoder, which
+    // issues every chunk that s_avail / s_final now allow
+    int s_copied = 0;
+    auto stream_feed = [&](int upto) {
+        if (!streamed) return;
+        if (upto > s_copied) {
+            Q3_HIP(hipMemcpy2DAsync(J.dec_codes + size_t(s_copied) * 16, size_t(Fcap_) * 64, codes_ + size_t(s_copied) * 16,
+                                    size_t(Fcap_) * 64, size_t(upto - s_copied) * 64, size_t(n), hipMemcpyDeviceToDevice, st_));
+            s_copied = upto;
+            Q3_HIP(hipEventRecord(ev_[3], st_));
+            Q3_HIP(hipStreamWaitEvent(sst, ev_[3], 0));
+        }
+        const int before = J.n_chunks;
+        J.n_chunks = codec_->stream_push(J.dec_codes, Fcap_, s_avail.data(), s_final.data(), J.pcm_host, size_t(Fcap_) * J.up, J.chunk_done);
+        if (before == 0 && J.n_chunks > 0) Q3_HIP(hipEventRecord(J.ev_first_audio, sst));  // behind chunk 0's copy to the host
+    };
+
     // ---- frame loop ----
     const bool use_graph = opts_.use_graph && !dbg;
     // the tables are cut from the weights, which may arrive after load (weights_from_broadcast): first use, not load
@@ -1051,10 +1120,24 @@ int Engine::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3
         }
         Q3_HIP(hipEventRecord(ring[bursts & 1], st_));
         ++bursts;
-        if (fixed_len && !cb) continue;
+        if (fixed_len && !cb) {
+            if (streamed) {  // every row has exactly `launched` frames (nothing ends early)
+                for (int b = 0; b < n; ++b) s_avail[size_t(b)] = std::min(launched, maxf[size_t(b)]);
+                stream_feed(launched);
+            }
+            continue;
+        }
         Q3_HIP(hipEventSynchronize(ring[(bursts - 1) & 1]));
         done = true;
         for (int b = 0; b < n; ++b) done = done && h_fin[size_t(b)];
+        if (streamed) {
+            for (int b = 0; b < n; ++b) {
+                s_avail[size_t(b)] = h_nframes[size_t(b)];
+                s_final[size_t(b)] = h_fin[size_t(b)];
+            }
+            stream_feed(launched);
+            fire_chunks(J, J.n_chunks, &s_avail, false);  // what has already landed on the host, without waiting
+        }
         if (cb) {  // .token events in generation order (Qwen3+Streaming.swift:24-27)
             for (int b = 0; b < n; ++b) {
                 const int nf = h_nframes[size_t(b)];
@@ -1087,7 +1170,6 @@ int Engine::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3
     }
 
     // ---- hand the codes to the codec decoder (Qwen3.swift:943-961) on its own stream ----
-    Job& J = jobs_[slot];
     J.n = n;
     J.up = codec_->upsample();
     J.frames.assign(size_t(n), 0);
@@ -1104,10 +1186,20 @@ int Engine::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3
         dframes[size_t(b)] = F > 0 ? F + J.ref_T[size_t(b)] : 0;
         Fdec = std::max(Fdec, dframes[size_t(b)]);
     }
-    J.Fdec = Fdec;
+    J.Fdec = streamed ? Fcap_ : Fdec;
     J.codes_host.resize(size_t(n) * Fcap_ * 16);
     Q3_HIP(hipMemcpyAsync(J.codes_host.data(), codes_, J.codes_host.size() * 4, hipMemcpyDeviceToHost, st_));
-    if (Fdec > 0) {
+    if (streamed) {  // the remaining chunks: every row is final now
+        for (int b = 0; b < n; ++b) {
+            s_avail[size_t(b)] = J.frames[size_t(b)];
+            s_final[size_t(b)] = 1;
+        }
+        stream_feed(launched);
+        codec_->stream_close();
+        Q3_HIP(hipStreamSynchronize(st_));
+        Q3_HIP(hipEventRecord(J.ev_codec[1], sst));
+        J.decoded = Fdec > 0;
+    } else if (Fdec > 0) {
         // The decoder reads a copy owned by the job: the next begin() overwrites codes_ while this decode may still run.
         const size_t need = size_t(n) * Fdec * 16;
         if (need > J.dec_codes_cap) {
@@ -1133,6 +1225,7 @@ int Engine::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3
                                     hipMemcpyDeviceToDevice, st_));
         }
     }
+    if (!streamed) {
     Q3_HIP(hipStreamSynchronize(st_));  // everything of this call on st_ is done; only the decode is still to come
     hipStream_t cst = codec_stream(overlapped);
     Q3_HIP(hipEventRecord(J.ev_codec[0], cst));
@@ -1158,6 +1251,7 @@ int Engine::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3
         J.decoded = true;
     }
     Q3_HIP(hipEventRecord(J.ev_codec[1], cst));
+    }
     J.timing = q3tts_timing{};
     float ms = 0;
     Q3_HIP(hipEventElapsedTime(&ms, ev_[0], ev_[1]));
@@ -1220,6 +1314,40 @@ void Engine::compute_cuts(Job& J) {
         }
         J.row_cut[size_t(b)] = cut;
         J.row_ns[size_t(b)] = ns - cut;
+    }
+}
+
+// AUDIO_CHUNK events of chunks [J.chunks_fired, upto). known == nullptr: the rows' final cuts (compute_cuts) bound the pieces;
+// otherwise row b has known[b] frames so far and nothing is cut in front (a streamed job, still inside its frame loop).
+// wait = false delivers only what has already landed on the host.
+void Engine::fire_chunks(Job& J, int upto, const std::vector<int>* known, bool wait) {
+    const int n = J.n, up = J.up;
+    for (int k = J.chunks_fired; k < upto; ++k) {
+        if (wait) {
+            Q3_HIP(hipEventSynchronize(J.chunk_done[size_t(k)]));
+        } else {
+            const hipError_t q = hipEventQuery(J.chunk_done[size_t(k)]);
+            if (q == hipErrorNotReady) return;
+            Q3_HIP(q);
+        }
+        J.chunks_fired = k + 1;
+        if (!J.cb) continue;
+        const int64_t c0 = int64_t(k) * J.chunk_frames * up, c1 = std::min<int64_t>(int64_t(J.Fdec), int64_t(k + 1) * J.chunk_frames) * up;
+        std::unique_lock<std::mutex> lk;
+        if (cb_mutex) lk = std::unique_lock<std::mutex>(*cb_mutex);
+        for (int b = 0; b < n; ++b) {
+            const int64_t cut = known ? 0 : J.row_cut[size_t(b)];
+            const int64_t len = known ? int64_t((*known)[size_t(b)]) * up : J.row_ns[size_t(b)];
+            const int64_t lo = std::max(c0, cut), hi = std::min(c1, cut + len);
+            if (hi <= lo) continue;
+            q3tts_event ev{};
+            ev.kind = Q3TTS_EVENT_AUDIO_CHUNK;
+            ev.request_index = J.request_base + b;
+            ev.pcm = J.pcm_host + size_t(b) * J.Fdec * up + lo;
+            ev.n_samples = hi - lo;
+            ev.sample_offset = lo - cut;
+            J.cb(J.user, &ev);
+        }
     }
 }
 
@@ -1294,27 +1422,9 @@ void Engine::end(int job, q3tts_result* results) {
         }
     } release{this, &J};
     Q3_HIP(hipSetDevice(m_->device));
-    const int n = J.n, up = J.up, Fdec = J.Fdec;
-    const std::vector<int64_t>&row_cut = J.row_cut, &row_ns = J.row_ns;
-    if (J.n_chunks > 0 && J.cb) {  // AUDIO_CHUNK events as the tail of the decoder delivers them
-        for (int k = 0; k < J.n_chunks; ++k) {
-            Q3_HIP(hipEventSynchronize(J.chunk_done[size_t(k)]));
-            const int64_t c0 = int64_t(k) * J.chunk_frames * up, c1 = std::min<int64_t>(int64_t(Fdec), int64_t(k + 1) * J.chunk_frames) * up;
-            std::unique_lock<std::mutex> lk;
-            if (cb_mutex) lk = std::unique_lock<std::mutex>(*cb_mutex);
-            for (int b = 0; b < n; ++b) {
-                const int64_t lo = std::max(c0, row_cut[size_t(b)]), hi = std::min(c1, row_cut[size_t(b)] + row_ns[size_t(b)]);
-                if (hi <= lo) continue;
-                q3tts_event ev{};
-                ev.kind = Q3TTS_EVENT_AUDIO_CHUNK;
-                ev.request_index = J.request_base + b;
-                ev.pcm = J.pcm_host + size_t(b) * Fdec * up + lo;
-                ev.n_samples = hi - lo;
-                ev.sample_offset = lo - row_cut[size_t(b)];
-                J.cb(J.user, &ev);
-            }
-        }
-    }
+    const int n = J.n;
+    const std::vector<int64_t>& row_ns = J.row_ns;
+    if (J.n_chunks > 0) fire_chunks(J, J.n_chunks, nullptr, true);  // AUDIO_CHUNK events not delivered inside the loop
     {
         std::unique_lock<std::mutex> lk(stage_mu_);
         stage_cv_.wait(lk, [&] { return J.stage != 1; });
@@ -1332,6 +1442,10 @@ void Engine::end(int job, q3tts_result* results) {
     float ms = 0;
     Q3_HIP(hipEventElapsedTime(&ms, J.ev_codec[0], J.ev_codec[1]));
     J.timing.codec_ms = ms;  // on the codec stream: includes whatever the next batch's AR loop took away from it
+    if (J.streamed && J.n_chunks > 0) {
+        Q3_HIP(hipEventElapsedTime(&ms, J.ev_begin, J.ev_first_audio));
+        J.timing.first_audio_ms = ms;
+    }
     timing = J.timing;
     const double total = (J.t_done > 0 ? J.t_done : now_s()) - J.t_start;
     size_t free_b = 0, total_b = 0;
@@ -1481,6 +1595,65 @@ void Engine::codec_decode(const int32_t* codes, const int32_t* n_frames, int bat
     (void)hipFree(dcodes);
 }
 
+void Engine::codec_decode_streamed(const int32_t* codes, const int32_t* n_frames, int batch, int max_frames, int chunk_frames, int window,
+                                   int lookahead, float* pcm) {
+    Q3_CHECK(m_->has_codec, 1, "Model not initialized: Speech tokenizer not loaded");
+    Q3_CHECK(batch >= 1 && max_frames >= 1 && chunk_frames >= 1, 3, "Invalid input: empty codec batch");
+    const int up = codec_->upsample();
+    int32_t* dcodes = nullptr;
+    float* hpcm = nullptr;
+    std::vector<hipEvent_t> done;
+    auto cleanup = [&] {
+        for (auto e : done) (void)hipEventDestroy(e);
+        if (dcodes) (void)hipFree(dcodes);
+        if (hpcm) (void)hipHostFree(hpcm);
+    };
+    try {
+        Q3_HIP(hipMalloc(reinterpret_cast<void**>(&dcodes), size_t(batch) * max_frames * 16 * 4));
+        Q3_HIP(hipMemcpy(dcodes, codes, size_t(batch) * max_frames * 16 * 4, hipMemcpyHostToDevice));
+        Q3_HIP(hipHostMalloc(reinterpret_cast<void**>(&hpcm), size_t(batch) * max_frames * up * 4, hipHostMallocDefault));
+        std::memset(hpcm, 0, size_t(batch) * max_frames * up * 4);
+        std::vector<int> avail((size_t)(batch));
+        std::vector<uint8_t> fin((size_t)(batch), 1);
+        int Fmax = 0;
+        for (int b = 0; b < batch; ++b) {
+            Q3_CHECK(n_frames[b] >= 0 && n_frames[b] <= max_frames, 3, "Invalid input: n_frames out of range");
+            avail[size_t(b)] = n_frames[b];
+            Fmax = std::max(Fmax, n_frames[b]);
+        }
+        hipStream_t cst = codec_stream(false);
+        CodecRunner::StreamCfg cfg;
+        cfg.rows = batch; cfg.chunk_frames = chunk_frames; cfg.window = window; cfg.lookahead = lookahead; cfg.max_frames = std::max(Fmax, 1);
+        codec_->stream_open(cfg);
+        try {
+            // as a stream would deliver them: frames become available chunk by chunk (window >= 0); all at once otherwise
+            if (window >= 0) {
+                std::vector<uint8_t> notyet((size_t)(batch), 0);
+                for (int have = chunk_frames; have < Fmax + chunk_frames + lookahead; have += chunk_frames) {
+                    std::vector<int> a((size_t)(batch));
+                    for (int b = 0; b < batch; ++b) {
+                        a[size_t(b)] = std::min(avail[size_t(b)], have);
+                        notyet[size_t(b)] = a[size_t(b)] == avail[size_t(b)] ? 1 : 0;
+                    }
+                    codec_->stream_push(dcodes, max_frames, a.data(), notyet.data(), hpcm, size_t(max_frames) * up, done);
+                }
+            }
+            codec_->stream_push(dcodes, max_frames, avail.data(), fin.data(), hpcm, size_t(max_frames) * up, done);
+        } catch (...) {
+            codec_->stream_close();
+            throw;
+        }
+        codec_->stream_close();
+        Q3_HIP(hipStreamSynchronize(cst));
+        for (int b = 0; b < batch; ++b)
+            std::memcpy(pcm + size_t(b) * max_frames * up, hpcm + size_t(b) * max_frames * up, size_t(n_frames[b]) * up * 4);
+    } catch (...) {
+        cleanup();
+        throw;
+    }
+    cleanup();
+}
+
 void Engine::debug_codec_stage(const int32_t* codes, int n_frames, const char* stage, float* out, int64_t cap, int* T, int* C) {
     Q3_CHECK(m_->has_codec, 1, "Model not initialized: Speech tokenizer not loaded");
     int32_t* dcodes = nullptr;
@@ -1610,6 +1783,7 @@ void EngineGroup::generate(const q3tts_request* reqs, int n, const q3tts_samplin
         timing.decode_ms = std::max(timing.decode_ms, t.decode_ms);
         timing.codec_ms = std::max(timing.codec_ms, t.codec_ms);
         timing.frontend_ms = std::max(timing.frontend_ms, t.frontend_ms);
+        timing.first_audio_ms = std::max(timing.first_audio_ms, t.first_audio_ms);
         timing.frame_steps = std::max(timing.frame_steps, t.frame_steps);
         timing.rows += t.rows;
         timing.kv_bytes_read += t.kv_bytes_read;

@@ -74,6 +74,8 @@ class Engine {
     void debug_linear(const uint16_t* x, const uint16_t* W, const uint16_t* bias, int M, int K, int N, uint16_t* y);
     void codec_decode(const int32_t* codes, const int32_t* n_frames, int batch, int max_frames, float* pcm,
                       int64_t* audio_lengths);
+    void codec_decode_streamed(const int32_t* codes, const int32_t* n_frames, int batch, int max_frames, int chunk_frames, int window,
+                               int lookahead, float* pcm);
     void debug_codec_stage(const int32_t* codes, int n_frames, const char* stage, float* out, int64_t cap, int* T, int* C);
     // voice-clone front end (SpeechTokenizer.swift:841-846; Qwen3.swift:222-249); host buffers in and out
     int codec_encode(const float* audio, int64_t n_samples, int32_t* codes, int cap_frames);
@@ -149,8 +151,12 @@ class Engine {
         float* pcm_host = nullptr;        // pinned [n][Fdec * up]
         size_t pcm_host_cap = 0;
         hipEvent_t ev_codec[2] = {nullptr, nullptr};
+        hipEvent_t ev_begin = nullptr, ev_first_audio = nullptr;  // request in / first streamed chunk on the host
         std::vector<hipEvent_t> chunk_done;  // chunked decode (audio_chunk_frames > 0): one per chunk, behind its copy
         int n_chunks = 0, chunk_frames = 0;
+        bool streamed = false;   // audio_window_frames > 0: chunks were decoded (and partly delivered) inside the frame loop
+        int chunks_fired = 0;    // AUDIO_CHUNK events already delivered for chunks [0, chunks_fired)
+        double t_first_audio = 0;
         q3tts_timing timing{};
         double t_start = 0, t_done = 0;  // begin() entered / PCM on the host (stage_rows)
         q3tts_event_cb cb = nullptr;
@@ -167,6 +173,8 @@ class Engine {
         std::string stage_err;
     } jobs_[kJobSlots];
     void compute_cuts(Job& J);
+    // AUDIO_CHUNK events of chunks [J.chunks_fired, upto); rows are clipped to known[b] frames (their final length when known)
+    void fire_chunks(Job& J, int upto, const std::vector<int>* known, bool wait);
     void stage_rows(Job& J);   // waits for the decode, then copies; throws
     void staging_loop();
     std::thread stager_;

@@ -33,6 +33,10 @@ constexpr int KC = 32;         // input channels per chunk
 constexpr int LDS_LD = 40;     // padded row (floats)
 constexpr int MAX_HALO = 56;   // (K-1)*dil <= 54 in the decoder (k7, dil 9)
 
+// 16-byte tensor store. (Written through to memory -- `sc0 sc1`, with or without `nt` -- the decode's stores leave no
+// dirty lines in the XCD L2s; measured beside a frame loop that changes nothing: 775-778 ms per pipelined step either way.)
+__device__ __forceinline__ void st16(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
 // geluApprox (SpeechTokenizerEncoder.swift:1080-1082), relu / sigmoid / tanh(relu) (SpeakerEncoder.swift:68, 151, 255-256)
@@ -99,7 +103,7 @@ __device__ __forceinline__ void epilogue_tile(const ConvGemmArgs& a, int b, int 
             if (a.scale) { v[0] *= sv[c].x; v[1] *= sv[c].y; v[2] *= sv[c].z; v[3] *= sv[c].w; }
             if (a.res) { v[0] += rv[p][c].x; v[1] += rv[p][c].y; v[2] += rv[p][c].z; v[3] += rv[p][c].w; }
             if (a.out && t < T && n < a.N)
-                *reinterpret_cast<float4*>(a.out + (size_t)b * a.out_bstride + (size_t)t * a.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+                st16(a.out + (size_t)b * a.out_bstride + (size_t)t * a.ldo + n, make_float4(v[0], v[1], v[2], v[3]));
             acc[p][c] = f32x4{v[0], v[1], v[2], v[3]};  // kept for snake_pass
         }
     }
@@ -142,7 +146,7 @@ __device__ __forceinline__ void snake_pass(const ConvGemmArgs& a, float* smem_ba
             v.y = v.y + ib.y * snake_sin2(v.y * ea.y);
             v.z = v.z + ib.z * snake_sin2(v.z * ea.z);
             v.w = v.w + ib.w * snake_sin2(v.w * ea.w);
-            *reinterpret_cast<float4*>(dst + nl) = v;
+            st16(dst + nl, v);
         }
     }
 }
@@ -213,10 +217,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
             int t = t0 - halo + a.shift + r;
             if (a.reflect) t = t < 0 ? -t : (t >= T ? 2 * (T - 1) - t : t);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < rows && t >= 0 && t < T && c0 + c4 < a.Cin) {
-                v = *reinterpret_cast<const float4*>(xb + (size_t)t * a.ldx + c0 + c4);
+            if (r < rows && t >= -a.hist && t < T && c0 + c4 < a.Cin) {
+                v = *reinterpret_cast<const float4*>(xb + (int64_t)t * a.ldx + c0 + c4);
                 if (x2b) {
-                    const float4 u = *reinterpret_cast<const float4*>(x2b + (size_t)t * a.ldx2 + c0 + c4);
+                    const float4 u = *reinterpret_cast<const float4*>(x2b + (int64_t)t * a.ldx2 + c0 + c4);
                     v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
                 }
                 if (a.pre_act == 1) {  // ELU, alpha 1 (SpeechTokenizerEncoder.swift:1075-1077)
@@ -393,11 +397,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvGemmArgs a)
                 if (a.reflect) t = t < 0 ? -t : (t >= T ? 2 * (T - 1) - t : t);
             }
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < rows && t >= 0 && t < T && c0 + c4 < a.Cin) {
-                v = *reinterpret_cast<const float4*>(xb + (size_t)t * a.ldx + c0 + c4);
+            if (r < rows && t >= -a.hist && t < T && c0 + c4 < a.Cin) {
+                v = *reinterpret_cast<const float4*>(xb + (int64_t)t * a.ldx + c0 + c4);
                 if constexpr (PRO) {
                     if (x2b) {
-                        const float4 u = *reinterpret_cast<const float4*>(x2b + (size_t)t * a.ldx2 + c0 + c4);
+                        const float4 u = *reinterpret_cast<const float4*>(x2b + (int64_t)t * a.ldx2 + c0 + c4);
                         v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
                     }
                     if (a.pre_act == 1) {
@@ -604,11 +608,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_h2_kernel(ConvGemmArgs a) {
                 if (a.reflect) t = t < 0 ? -t : (t >= T ? 2 * (T - 1) - t : t);
             }
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < rows && t >= 0 && t < T && c0 + c4 < a.Cin) {
-                v = *reinterpret_cast<const float4*>(xb + (size_t)t * a.ldx + c0 + c4);
+            if (r < rows && t >= -a.hist && t < T && c0 + c4 < a.Cin) {
+                v = *reinterpret_cast<const float4*>(xb + (int64_t)t * a.ldx + c0 + c4);
                 if constexpr (PRO) {
                     if (x2b) {
-                        const float4 u = *reinterpret_cast<const float4*>(x2b + (size_t)t * a.ldx2 + c0 + c4);
+                        const float4 u = *reinterpret_cast<const float4*>(x2b + (int64_t)t * a.ldx2 + c0 + c4);
                         v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
                     }
                     if (a.pre_act == 1) {
@@ -763,8 +767,8 @@ __global__ __launch_bounds__(256, 2) void resunit_split_kernel(ResUnitArgs a) {
             const int r = item >> 3, c4 = (item & 7) * 4;
             const int t = t0 - halo + r;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < rows && t >= 0 && t < T) {
-                v = *reinterpret_cast<const float4*>(yb + (size_t)t * C + c0 + c4);
+            if (r < rows && t >= -a.hist && t < T) {
+                v = *reinterpret_cast<const float4*>(yb + (int64_t)t * C + c0 + c4);
                 const float4 ea = *reinterpret_cast<const float4*>(a.ea1 + c0 + c4);
                 const float4 ib = *reinterpret_cast<const float4*>(a.ib1 + c0 + c4);
                 v.x = v.x + ib.x * snake_sin2(v.x * ea.x);
@@ -946,7 +950,7 @@ __global__ __launch_bounds__(256, 2) void resunit_split_kernel(ResUnitArgs a) {
                 v = make_float4((acc2[p][c][0] + bv.x) + rv.x, (acc2[p][c][1] + bv.y) + rv.y, (acc2[p][c][2] + bv.z) + rv.z,
                                 (acc2[p][c][3] + bv.w) + rv.w);
             }
-            *reinterpret_cast<float4*>(a.out + boff + (size_t)t * C + n) = v;
+            st16(a.out + boff + (size_t)t * C + n, v);
             acc2[p][c] = f32x4{v.x, v.y, v.z, v.w};
         }
     }
@@ -968,7 +972,7 @@ __global__ __launch_bounds__(256, 2) void resunit_split_kernel(ResUnitArgs a) {
                 v.y = v.y + ib.y * snake_sin2(v.y * ea.y);
                 v.z = v.z + ib.z * snake_sin2(v.z * ea.z);
                 v.w = v.w + ib.w * snake_sin2(v.w * ea.w);
-                *reinterpret_cast<float4*>(a.out2 + boff + (size_t)t * C + n) = v;
+                st16(a.out2 + boff + (size_t)t * C + n, v);
             }
         }
     }
@@ -1036,8 +1040,8 @@ __global__ __launch_bounds__(256, 2) void resunit_h2_kernel(ResUnitArgs a) {
             const int r = item >> 3, c4 = (item & 7) * 4;
             const int t = t0 - halo + r;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < rows && t >= 0 && t < T) {
-                v = *reinterpret_cast<const float4*>(yb + (size_t)t * C + c0 + c4);
+            if (r < rows && t >= -a.hist && t < T) {
+                v = *reinterpret_cast<const float4*>(yb + (int64_t)t * C + c0 + c4);
                 const float4 ea = *reinterpret_cast<const float4*>(a.ea1 + c0 + c4);
                 const float4 ib = *reinterpret_cast<const float4*>(a.ib1 + c0 + c4);
                 v.x = v.x + ib.x * snake_sin2(v.x * ea.x);
@@ -1232,7 +1236,7 @@ __global__ __launch_bounds__(256, 2) void resunit_h2_kernel(ResUnitArgs a) {
             if (a.b2)
                 v = make_float4((acc2[p][c][0] * sv.x + bv.x) + rv.x, (acc2[p][c][1] * sv.y + bv.y) + rv.y,
                                 (acc2[p][c][2] * sv.z + bv.z) + rv.z, (acc2[p][c][3] * sv.w + bv.w) + rv.w);
-            *reinterpret_cast<float4*>(a.out + boff + (size_t)t * C + n) = v;
+            st16(a.out + boff + (size_t)t * C + n, v);
             acc2[p][c] = f32x4{v.x, v.y, v.z, v.w};
         }
     }
@@ -1254,7 +1258,7 @@ __global__ __launch_bounds__(256, 2) void resunit_h2_kernel(ResUnitArgs a) {
                 v.y = v.y + ib.y * snake_sin2(v.y * ea.y);
                 v.z = v.z + ib.z * snake_sin2(v.z * ea.z);
                 v.w = v.w + ib.w * snake_sin2(v.w * ea.w);
-                *reinterpret_cast<float4*>(a.out2 + boff + (size_t)t * C + n) = v;
+                st16(a.out2 + boff + (size_t)t * C + n, v);
             }
         }
     }

@@ -2,6 +2,8 @@
 // (/root/reference/Sources/Qwen3TTS/Models/SpeechTokenizer.swift): Split-RVQ gather, fp32 RMSNorm,
 // depthwise conv + LayerNorm, SwiGLU gating, full attention of the 8-layer pre-transformer and the
 // Snake -> conv(C->1) -> clip tail. All are HBM/L2 bound row kernels over channels-last tensors.
+#include <algorithm>
+
 #include "../common.h"
 #include "snake.h"
 #include "../codec_kernels.h"
@@ -50,7 +52,7 @@ __global__ __launch_bounds__(256) void rmsnorm_f32_kernel(const float* x, const 
 // ConvNeXt front half: y = dwconv_k7_causal(x) + b ; out = LayerNorm(y) (eps 1e-6)
 __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* x, const float* dw_w, const float* dw_b,
                                                         const float* ln_w, const float* ln_b, float eps, int C,
-                                                        const int32_t* frames, int ppf, int Tmax, float* out) {
+                                                        const int32_t* frames, int ppf, int Tmax, float* out, int hist) {
     __shared__ float sh[4];
     constexpr int kMaxPer = 16;  // C <= 4096
     const int t = blockIdx.x, b = blockIdx.y;
@@ -64,7 +66,7 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* x, const fl
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
             const int ti = t - 6 + k;
-            if (ti >= 0) acc += xb[(size_t)ti * C + c] * dw_w[c * 7 + k];
+            if (ti >= -hist) acc += xb[(int64_t)ti * C + c] * dw_w[c * 7 + k];
         }
         acc += dw_b[c];
         y[cnt] = acc;
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(64) void attn_full_f32_kernel(const float* qkv, int
 // the banks) and the 7 x C taps sit in LDS; a lane owns every fourth 4-channel group of its position.
 __global__ __launch_bounds__(256) void out_conv_kernel(const float* x, int C, const float* ea, const float* ib,
                                                        const float* w, const float* bias, const int32_t* frames, int ppf,
-                                                       int Tmax, float* pcm) {
+                                                       int Tmax, float* pcm, int hist) {
     extern __shared__ __attribute__((aligned(16))) float xs[];  // [(64+6)][C + 4] snake(x), then [7][C] taps
     const int ld = C + 4, C4 = C >> 2;
     float* ws = xs + 70 * ld;
@@ -168,8 +170,8 @@ __global__ __launch_bounds__(256) void out_conv_kernel(const float* x, int C, co
         while (r < 70) {
             const int t = t0 - 6 + r;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t >= 0 && t < T) {
-                v = *reinterpret_cast<const float4*>(xb + (size_t)t * C + 4 * c4);
+            if (t >= -hist && t < T) {
+                v = *reinterpret_cast<const float4*>(xb + (int64_t)t * C + 4 * c4);
                 const float4 e = *reinterpret_cast<const float4*>(ea + 4 * c4), q = *reinterpret_cast<const float4*>(ib + 4 * c4);
                 v.x = v.x + q.x * snake_sin2(v.x * e.x);
                 v.y = v.y + q.y * snake_sin2(v.y * e.y);
@@ -208,7 +210,22 @@ __global__ __launch_bounds__(256) void out_conv_kernel(const float* x, int C, co
     }
 }
 
+// streamed decode: the last `keep` floats of a chunk's valid region become the history in front of the next chunk
+__global__ __launch_bounds__(256) void roll_history_kernel(float* cur, int64_t bstride, int64_t keep, int64_t chunk) {
+    float* row = cur + (int64_t)blockIdx.y * bstride;
+    const float4* src = reinterpret_cast<const float4*>(row + chunk - keep);
+    float4* dst = reinterpret_cast<float4*>(row - keep);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < keep / 4; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+
 }  // namespace
+
+void launch_roll_history(float* cur, int64_t bstride, int64_t keep_floats, int64_t chunk_floats, int B, hipStream_t st) {
+    Q3_CHECK(keep_floats % 4 == 0 && chunk_floats >= keep_floats, 3, "roll_history: chunk shorter than the history");
+    if (keep_floats == 0 || B <= 0) return;
+    const int gx = int(std::min<int64_t>(64, (keep_floats / 4 + 255) / 256));
+    hipLaunchKernelGGL(roll_history_kernel, dim3(gx, B), dim3(256), 0, st, cur, bstride, keep_floats, chunk_floats);
+}
 
 void launch_rvq_gather(const int32_t* codes, int code_stride_frames, const float* cb_first, const float* const* cb_rest,
                        int n_rest, int inner, const int32_t* frames, int Fmax, int B, float* out, hipStream_t st) {
@@ -220,10 +237,10 @@ void launch_rmsnorm_f32(const float* x, const float* w, float eps, int C, const 
     hipLaunchKernelGGL(rmsnorm_f32_kernel, dim3(Tmax, B), dim3(256), 0, st, x, w, eps, C, frames, ppf, Tmax, out);
 }
 void launch_dwconv_ln(const float* x, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
-                      float eps, int C, const int32_t* frames, int ppf, int Tmax, int B, float* out, hipStream_t st) {
+                      float eps, int C, const int32_t* frames, int ppf, int Tmax, int B, float* out, hipStream_t st, int hist) {
     Q3_CHECK(C <= 4096, 3, "dwconv_ln: more than 4096 channels");
     hipLaunchKernelGGL(dwconv_ln_kernel, dim3(Tmax, B), dim3(256), 0, st, x, dw_w, dw_b, ln_w, ln_b, eps, C, frames, ppf,
-                       Tmax, out);
+                       Tmax, out, hist);
 }
 void launch_silu_mul_f32(const float* gu, int I, const int32_t* frames, int ppf, int Tmax, int B, float* out,
                          hipStream_t st) {
@@ -235,11 +252,11 @@ void launch_attn_full_f32(const float* qkv, int heads, const int32_t* frames, in
                        out);
 }
 void launch_out_conv(const float* x, int C, const float* ea, const float* ib, const float* w, const float* bias,
-                     const int32_t* frames, int ppf, int Tmax, int B, float* pcm, hipStream_t st) {
+                     const int32_t* frames, int ppf, int Tmax, int B, float* pcm, hipStream_t st, int hist) {
     const size_t smem = (size_t(70) * (C + 4) + size_t(7) * C) * sizeof(float);
     Q3_CHECK(smem <= 64 * 1024 && C % 4 == 0 && C >= 4 && C <= 1024, 3, "out_conv: unsupported channel count");
     hipLaunchKernelGGL(out_conv_kernel, dim3((Tmax + 63) / 64, B), dim3(256), smem, st, x, C, ea, ib, w, bias, frames, ppf,
-                       Tmax, pcm);
+                       Tmax, pcm, hist);
 }
 
 }  // namespace q3

@@ -18,7 +18,7 @@ u8p = C.POINTER(C.c_uint8)
 class LoadOpts(C.Structure):
     _fields_ = [("device", C.c_int32), ("max_batch", C.c_int32), ("max_frames", C.c_int32),
                 ("max_prompt", C.c_int32), ("use_graph", C.c_int32), ("weights_from_broadcast", C.c_int32),
-                ("n_streams", C.c_int32)]
+                ("n_streams", C.c_int32), ("codec_overlap_cus", C.c_int32)]
 
 
 class ModelInfo(C.Structure):
@@ -41,7 +41,8 @@ class Request(C.Structure):
 
 class Sampling(C.Structure):
     _fields_ = [("temperature", C.c_float), ("top_k", C.c_int32), ("top_p", C.c_float),
-                ("repetition_penalty", C.c_float), ("seed", C.c_uint64), ("force_frames", C.c_int32), ("audio_chunk_frames", C.c_int32)]
+                ("repetition_penalty", C.c_float), ("seed", C.c_uint64), ("force_frames", C.c_int32), ("audio_chunk_frames", C.c_int32),
+                ("audio_window_frames", C.c_int32), ("audio_lookahead_frames", C.c_int32)]
 
 
 class GenInfo(C.Structure):
@@ -66,7 +67,7 @@ class Result(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("prefill_ms", C.c_double), ("decode_ms", C.c_double), ("codec_ms", C.c_double),
                 ("frame_steps", C.c_int32), ("rows", C.c_int32), ("kv_bytes_read", C.c_int64),
-                ("frontend_ms", C.c_double)]
+                ("frontend_ms", C.c_double), ("first_audio_ms", C.c_double)]
 
 
 _lib = None
@@ -104,6 +105,7 @@ def lib() -> C.CDLL:
     L.q3tts_result_free.argtypes = [C.POINTER(Result), C.c_int32]
     L.q3tts_result_free.restype = None
     L.q3tts_codec_decode.argtypes = [vp, i32p, i32p, C.c_int32, C.c_int32, f32p, C.POINTER(C.c_int64)]
+    L.q3tts_codec_decode_streamed.argtypes = [vp, i32p, i32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, f32p]
     L.q3tts_last_timing.argtypes = [vp, C.POINTER(Timing)]
     L.q3tts_codec_encode.argtypes = [vp, f32p, C.c_int64, i32p, C.c_int32, i32p]
     L.q3tts_codec_encoded_frames.argtypes = [vp, C.c_int64]

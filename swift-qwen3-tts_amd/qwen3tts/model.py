@@ -112,7 +112,8 @@ class Qwen3TTSModel:
     @classmethod
     def from_pretrained(cls, model_path: str, device: int = 0, max_batch: int = 1, max_frames: int = 2048,
                         max_prompt: int = 512, use_graph: bool = True,
-                        weights_from_broadcast: bool = False, n_streams: int = 0) -> "Qwen3TTSModel":
+                        weights_from_broadcast: bool = False, n_streams: int = 0,
+                        codec_overlap_cus: int = 0) -> "Qwen3TTSModel":
         lib = L.lib()
         o = L.LoadOpts()
         lib.q3tts_default_load_opts(C.byref(o))
@@ -120,6 +121,7 @@ class Qwen3TTSModel:
         o.use_graph = 1 if use_graph else 0
         o.weights_from_broadcast = 1 if weights_from_broadcast else 0
         o.n_streams = n_streams
+        o.codec_overlap_cus = codec_overlap_cus
         h = C.c_void_p()
         st = lib.q3tts_model_load(model_path.encode(), C.byref(o), C.byref(h))
         if st != 0:
@@ -202,23 +204,29 @@ class Qwen3TTSModel:
         return arr, keep
 
     @staticmethod
-    def _sampling(temperature, top_k, top_p, repetition_penalty, seed, force_frames, audio_chunk_frames=0) -> L.Sampling:
+    def _sampling(temperature, top_k, top_p, repetition_penalty, seed, force_frames, audio_chunk_frames=0,
+                  audio_window_frames=0, audio_lookahead_frames=4) -> L.Sampling:
         s = L.Sampling()
         s.temperature, s.top_k, s.top_p = temperature, top_k, top_p
         s.repetition_penalty, s.seed, s.force_frames = repetition_penalty, seed, force_frames
         s.audio_chunk_frames = audio_chunk_frames
+        s.audio_window_frames, s.audio_lookahead_frames = audio_window_frames, audio_lookahead_frames
         return s
 
     def generate_batch(self, reqs: Sequence[GenerationRequest], temperature: float = 0.9, top_k: int = 50,
                        top_p: float = 1.0, repetition_penalty: float = 1.05, seed: int = 0, force_frames: int = 0,
                        on_event: Optional[Callable[[int, str, object], None]] = None,
-                       audio_chunk_frames: int = 0) -> List[GenerationResult]:
+                       audio_chunk_frames: int = 0, audio_window_frames: int = 0,
+                       audio_lookahead_frames: int = 4) -> List[GenerationResult]:
         """n utterances in one call (row-independent). `on_event(request_index, kind, payload)` receives
         ("token", id) / ("info", AudioGenerationInfo) / ("audio", ndarray) in the reference's order; with
         audio_chunk_frames > 0 also ("audio_chunk", (sample_offset, ndarray)) pieces of the final audio, in order,
-        between the last token and info (the decoder's causal tail run chunk by chunk; same samples)."""
+        between the last token and info (the decoder's causal tail run chunk by chunk; same samples). With
+        audio_window_frames > 0 as well the pieces leave while tokens are still being generated (q3tts.h: the
+        pre-transformer then sees a sliding window; the waveform is within a stated tolerance of the one-shot decode)."""
         arr, keep = self._marshal(reqs)
-        s = self._sampling(temperature, top_k, top_p, repetition_penalty, seed, force_frames, audio_chunk_frames)
+        s = self._sampling(temperature, top_k, top_p, repetition_penalty, seed, force_frames, audio_chunk_frames,
+                           audio_window_frames, audio_lookahead_frames)
         cb = self._event_cb(on_event)
         res = (L.Result * len(reqs))()
         st = self._lib.q3tts_generate(self._h, arr, len(reqs), C.byref(s), cb, None, res)
@@ -417,6 +425,20 @@ class Qwen3TTSModel:
         return pcm, lens
 
     # -- test hooks -------------------------------------------------------------------------------
+    def codec_decode_streamed(self, codes: np.ndarray, chunk_frames: int, window: int, lookahead: int = 4,
+                              n_frames: Optional[Sequence[int]] = None) -> np.ndarray:
+        """The decode the way a stream produces it (q3tts_codec_decode_streamed): window < 0 = pre-transformer over all
+        frames (bit-identical to codec_decode); otherwise a sliding window. Returns pcm [batch][max_frames * 1920]."""
+        codes = np.ascontiguousarray(codes, np.int32)
+        if codes.ndim == 2:
+            codes = codes[None]
+        B, F, G = codes.shape
+        nf = np.asarray(n_frames if n_frames is not None else [F] * B, np.int32)
+        pcm = np.zeros((B, F * self.info.samples_per_frame), np.float32)
+        self._check(self._lib.q3tts_codec_decode_streamed(self._h, codes.ctypes.data_as(L.i32p), nf.ctypes.data_as(L.i32p), B, F,
+                                                          chunk_frames, window, lookahead, pcm.ctypes.data_as(L.f32p)))
+        return pcm
+
     def debug_prepare_inputs(self, req: GenerationRequest):
         arr, keep = self._marshal([req])
         H = self.info.hidden_size

@@ -94,3 +94,119 @@ def test_chunked_tail_at_the_real_layer_widths(tmp_path_factory):
             assert np.abs(b.audio).max() > 1e-3
     finally:
         m.close()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# streamed decode: audio while tokens are still being generated (q3tts_sampling.audio_window_frames > 0)
+# ---------------------------------------------------------------------------------------------------------
+def _full_codec_dir(tmp_path_factory, name):
+    import json
+    import os
+    from qwen3tts import synth
+    d = str(tmp_path_factory.mktemp(name))
+    p = synth.preset("tiny-a")
+    p["speech_tokenizer"]["decoder_config"] = synth._codec_cfg(False)
+    p["config"]["talker_config"]["code_predictor_config"]["vocab_size"] = 2048
+    os.makedirs(os.path.join(d, "speech_tokenizer"), exist_ok=True)
+    g = synth._Gen(1234, False)
+    json.dump(p["config"], open(os.path.join(d, "config.json"), "w"))
+    json.dump(p["speech_tokenizer"], open(os.path.join(d, "speech_tokenizer", "config.json"), "w"))
+    synth.save_safetensors(os.path.join(d, "model.safetensors"), synth.talker_tensors(p["config"], g))
+    synth.save_safetensors(os.path.join(d, "speech_tokenizer", "model.safetensors"),
+                           synth.codec_tensors(p["speech_tokenizer"]["decoder_config"], g, out_wstd=synth.FULL_WIDTH_OUT_WSTD))
+    return d
+
+
+@pytest.fixture(scope="module")
+def full_codec_model(tmp_path_factory):
+    from qwen3tts import Qwen3TTSModel
+    m = Qwen3TTSModel.from_pretrained(_full_codec_dir(tmp_path_factory, "full_codec_streamed"), max_batch=4, max_frames=96, max_prompt=64)
+    yield m
+    m.close()
+
+
+@pytest.mark.parametrize("chunk", [3, 7, 16, 200])
+def test_carried_state_tail_is_bit_identical(ckpt_dirs, full_codec_model, chunk):
+    """The causal tail with its conv state carried from chunk to chunk (no left context recomputed): with the pre-transformer
+    run once over all frames (window < 0) the streamed decode IS the one-shot decode, bit for bit -- tiny and real layer
+    widths (fused residual units in the last block, two-launch units in the others), ragged rows."""
+    from qwen3tts import Qwen3TTSModel
+    rng = np.random.default_rng(chunk)
+    for m, own in ((Qwen3TTSModel.from_pretrained(ckpt_dirs["tiny-b"], max_batch=4, max_frames=96, max_prompt=64), True),
+                   (full_codec_model, False)):
+        try:
+            F = [37, 5, 22]
+            vc = m.info.cp_vocab_size
+            codes = np.zeros((3, 37, 16), np.int32)
+            for b, f in enumerate(F):
+                codes[b, :f] = rng.integers(1, min(vc, 2048), size=(f, 16))
+            want, lens = m.codec_decode(codes, n_frames=F)
+            got = m.codec_decode_streamed(codes, chunk, -1, n_frames=F)
+            for b, f in enumerate(F):
+                assert lens[b] == f * 1920
+                assert (got[b, :f * 1920] == want[b, :f * 1920]).all(), (chunk, b)
+        finally:
+            if own:
+                m.close()
+
+
+def test_sliding_window_distance_from_the_one_shot_decode(full_codec_model):
+    """What a stream gives up: the pre-transformer is bidirectional over the whole utterance (SpeechTokenizer.swift:763); a
+    chunk decoded while later tokens do not exist yet sees `window` frames to the left and `lookahead` to the right. The
+    distance from the one-shot decode is measured at the real layer widths over a (window, lookahead) grid and bounded.
+    (Synthetic weights: LayerScale 0.01 as in the shipped initialisation, so the attention's share of the residual stream --
+    and with it this distance -- is what the checkpoint writer makes it; the numbers are a property of this checkpoint.)"""
+    m = full_codec_model
+    rng = np.random.default_rng(21)
+    F = 72
+    codes = rng.integers(1, 2048, size=(2, F, 16)).astype(np.int32)
+    want, _ = m.codec_decode(codes)
+    rms = float(np.sqrt(np.mean(want ** 2)))
+    assert np.abs(want).max() < 0.999 and rms > 1e-3
+    table = {}
+    for W, L in ((4, 0), (16, 0), (16, 4), (32, 4), (64, 8), (F, F)):
+        got = m.codec_decode_streamed(codes, 8, W, L)
+        err = np.abs(got - want)
+        table[(W, L)] = (float(err.max()), float(np.sqrt(np.mean(err ** 2))))
+    print("window, lookahead -> max |pcm - one-shot|, rms (signal rms %.3f):" % rms)
+    for k, v in table.items():
+        print("  W=%3d L=%3d   max %.3e   rms %.3e" % (k + v))
+    assert table[(F, F)][0] <= 1e-6                 # a window that covers everything: the one-shot decode again
+    assert table[(32, 4)][0] <= 2e-2 and table[(32, 4)][1] <= 0.05 * rms   # the default streaming geometry (stated tolerance)
+    assert table[(64, 8)][1] <= table[(4, 0)][1] + 1e-9
+
+
+def test_audio_leaves_before_the_last_token(ckpt_dirs):
+    """generate with audio_window_frames > 0: AUDIO_CHUNK events arrive while TOKEN events are still coming, the pieces
+    concatenate to the final audio, and that audio is exactly the streamed decode of the final codes."""
+    from qwen3tts import Qwen3TTSModel
+    m = Qwen3TTSModel.from_pretrained(ckpt_dirs["tiny-b"], max_batch=4, max_frames=96, max_prompt=96)
+    try:
+        reqs = [_req(row=i, n_text=5 + 3 * i) for i in range(3)]
+        kw = dict(temperature=0.9, top_k=40, repetition_penalty=1.05, seed=11, force_frames=64)
+        base = m.generate_batch(reqs, **kw)
+        order, pieces = [], {i: [] for i in range(3)}
+
+        def on_event(i, kind, payload):
+            order.append((i, kind))
+            if kind == "audio_chunk":
+                pieces[i].append(payload)
+
+        got = m.generate_batch(reqs, on_event=on_event, audio_chunk_frames=8, audio_window_frames=16, audio_lookahead_frames=2, **kw)
+        tm = m.last_timing()
+        codes = np.stack([r.codes for r in got])
+        ref = m.codec_decode_streamed(codes, 8, 16, 2)
+        for i, (a, b) in enumerate(zip(got, base)):
+            assert (a.codes == b.codes).all() and a.audio.size == b.audio.size == 64 * 1920
+            kinds = [k for j, k in order if j == i]
+            first_chunk, last_token = kinds.index("audio_chunk"), len(kinds) - 1 - kinds[::-1].index("token")
+            assert first_chunk < last_token, "no audio left before the last token"
+            assert kinds[-2:] == ["info", "audio"] and kinds.count("audio_chunk") == 8
+            offs = [o for o, _ in pieces[i]]
+            assert offs == [k * 8 * 1920 for k in range(8)]
+            cat = np.concatenate([p for _, p in pieces[i]])
+            assert (cat == a.audio).all() and (a.audio == ref[i]).all()
+            assert np.abs(a.audio - b.audio).max() <= 2e-2          # the window's price on this checkpoint
+        assert 0 < tm.first_audio_ms < tm.prefill_ms + tm.decode_ms, (tm.first_audio_ms, tm.decode_ms)
+    finally:
+        m.close()
