@@ -56,6 +56,10 @@ typedef struct {
     int32_t codec_overlap_cus; /* compute units a codec decode is confined to while the NEXT batch's frame loop runs beside it
                            (q3tts_generate_begin with more_follows != 0); multiple of 8; 0 = default (tuned for a 1.7B
                            talker at batch 32), -1 = never confine. Results do not depend on it */
+    int32_t codec_fp32;  /* 1: the codec decoder's convolutions on the fp32 matrix cores (the reference's arithmetic range, 2.4x the
+                           time) instead of fp16 matrix cores with every fp32 operand split into two fp16 planes (same accuracy,
+                           activations limited to |x| < 65504: a decode that leaves that range reports
+                           Q3TTS_ERR_AUDIO_DECODING_FAILED for the row instead of a waveform). Default 0 */
 } q3tts_load_opts;
 
 void q3tts_default_load_opts(q3tts_load_opts* o);
@@ -139,6 +143,9 @@ typedef struct {
                                    by a bounded amount (tests/test_streaming.py); AUDIO then carries the
                                    concatenation of the chunks. Not combined with voice-clone rows (those fall back to 0) */
     int32_t audio_lookahead_frames; /* frames to the right of a chunk that must exist before it is decoded (default 4) */
+    uint32_t row_base;    /* new: global index of reqs[0] in a job whose rows are sharded over several processes (one
+                             replica per GPU). A row's random stream is keyed by (seed, row_base + row index), so a sharded
+                             job draws what the same rows would draw in one call. Default 0 */
 } q3tts_sampling;
 void q3tts_default_sampling(q3tts_sampling* s);
 

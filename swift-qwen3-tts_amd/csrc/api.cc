@@ -49,6 +49,7 @@ void q3tts_default_load_opts(q3tts_load_opts* o) {
     o->weights_from_broadcast = 0;
     o->n_streams = 0;
     o->codec_overlap_cus = 0;
+    o->codec_fp32 = 0;
 }
 
 void q3tts_default_sampling(q3tts_sampling* s) {  // Qwen3.swift:1296-1299
@@ -61,6 +62,7 @@ void q3tts_default_sampling(q3tts_sampling* s) {  // Qwen3.swift:1296-1299
     s->audio_chunk_frames = 0;
     s->audio_window_frames = 0;
     s->audio_lookahead_frames = 4;
+    s->row_base = 0;
 }
 
 q3tts_status q3tts_model_load(const char* model_dir, const q3tts_load_opts* opts, q3tts_model** out) {

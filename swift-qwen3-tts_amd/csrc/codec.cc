@@ -14,13 +14,13 @@ namespace {
 constexpr size_t kScratchBudget = size_t(24) << 30;  // activation scratch per chunk of rows (of 288 GB HBM)
 }
 
-CodecRunner::CodecRunner(const Model& m, hipStream_t st) : m_(m), st_(st) {
+CodecRunner::CodecRunner(const Model& m, hipStream_t st, bool fp32_convs) : m_(m), st_(st) {
     up_ = m.cfg.codec.total_upsample();
     Q3_CHECK(m.cfg.codec.head_dim == 64, 6, "codec transformer head_dim must be 64");
-    const char* e = std::getenv("Q3TTS_CODEC_FP32");
-    fp32_mfma_ = e && e[0] == '1';
-    const char* b3 = std::getenv("Q3TTS_CODEC_BF16X3");  // A/B switch: the six-product bf16 split instead of fp16x2
-    bf16x3_ = b3 && b3[0] == '1';
+    const char* e = std::getenv("Q3TTS_CODEC_FP32");  // tests switch per model load without touching the load options
+    fp32_mfma_ = fp32_convs || (e && e[0] == '1');
+    Q3_HIP(hipMalloc(reinterpret_cast<void**>(&nf_dev_), size_t(kMaxRows) * 4));
+    Q3_HIP(hipMemset(nf_dev_, 0, size_t(kMaxRows) * 4));
     const char* nf = std::getenv("Q3TTS_CODEC_NO_FUSE");
     no_fuse_ = nf && nf[0] == '1';
 }
@@ -29,6 +29,7 @@ CodecRunner::~CodecRunner() {
     if (buf_) (void)hipFree(buf_);
     if (lens_dev_) (void)hipFree(lens_dev_);
     if (lens_host_) (void)hipHostFree(lens_host_);
+    if (nf_dev_) (void)hipFree(nf_dev_);
     if (stream_.arena) (void)hipFree(stream_.arena);
     if (stream_.lens_host) (void)hipHostFree(stream_.lens_host);
     if (stream_.lens_dev) (void)hipFree(stream_.lens_dev);
@@ -116,10 +117,7 @@ void CodecRunner::conv(const Pass& ps, const ConvW& cw, const float* x, int Tmax
     a.hist = ps.hist_frames * ppf;
     a.x = x; a.ldx = cw.Cin; a.x_bstride = int64_t(Tmax) * cw.Cin;
     a.w = cw.w; a.bias = cw.bias; a.scale = cw.scale;
-    if (!fp32_mfma_) {
-        if (bf16x3_) a.w3 = cw.w3;
-        else { a.wh = cw.wh; a.wsc = cw.wsc; }
-    }
+    if (!fp32_mfma_) { a.wh = cw.wh; a.wsc = cw.wsc; }
     a.res = res; a.ldr = cw.N; a.res_bstride = int64_t(Tmax) * cw.N;
     a.out = out; a.ldo = cw.N; a.out_bstride = int64_t(Tmax) * cw.N;
     a.snake_ea = sn ? sn->ea : nullptr; a.snake_ib = sn ? sn->ib : nullptr;
@@ -214,7 +212,7 @@ void CodecRunner::run_tail(const Pass& ps, int Tframes, float* const* bufs, floa
         const SnakeW* after = i + 1 < nblk ? &w.blocks[i + 1].snake : nullptr;
         bool fused = !fp32_mfma_ && !no_fuse_ && resunit_supported(Bk.Cout, Bk.res[0].conv1.K, 9);
         for (int j = 0; j < 3; ++j)
-            fused = fused && Bk.res[j].conv1.w3 && Bk.res[j].conv2.w3p && Bk.res[j].conv1.wh && Bk.res[j].conv2.whp &&
+            fused = fused && Bk.res[j].conv1.wh && Bk.res[j].conv2.whp &&
                     Bk.res[j].conv1.N == Bk.Cout && Bk.res[j].conv2.K == 1 &&
                     resunit_supported(Bk.Cout, Bk.res[j].conv1.K, Bk.res[j].conv1.dil);
         if (fused) {
@@ -228,8 +226,7 @@ void CodecRunner::run_tail(const Pass& ps, int Tframes, float* const* bufs, floa
                 r.y = yin; r.out = yout;
                 if (j == 2 && after) { r.out2 = hs; r.post_ea = after->ea; r.post_ib = after->ib; }
                 r.b1 = Bk.res[j].conv1.bias; r.b2 = Bk.res[j].conv2.bias;
-                if (bf16x3_) { r.w1 = Bk.res[j].conv1.w3; r.w2p = Bk.res[j].conv2.w3p; }
-                else { r.w1h = Bk.res[j].conv1.wh; r.w2ph = Bk.res[j].conv2.whp; r.wsc1 = Bk.res[j].conv1.wsc; r.wsc2 = Bk.res[j].conv2.wsc; }
+                r.w1h = Bk.res[j].conv1.wh; r.w2ph = Bk.res[j].conv2.whp; r.wsc1 = Bk.res[j].conv1.wsc; r.wsc2 = Bk.res[j].conv2.wsc;
                 r.ea1 = Bk.res[j].act1.ea; r.ib1 = Bk.res[j].act1.ib; r.ea2 = Bk.res[j].act2.ea; r.ib2 = Bk.res[j].act2.ib;
                 r.frames = fr; r.ppf = ppf; r.Tmax = T; r.B = nb; r.C = Bk.Cout; r.K = Bk.res[j].conv1.K; r.dil = Bk.res[j].conv1.dil;
                 launch_resunit(r, st_);
@@ -252,14 +249,16 @@ void CodecRunner::run_tail(const Pass& ps, int Tframes, float* const* bufs, floa
     }
     // 7. outSnake -> outConv -> clip (:687-688, :781)
     launch_out_conv(bufs[cur], w.out_C, w.out_snake.ea, w.out_snake.ib, w.out_w, w.out_b, fr, ppf, T, nb,
-                    pcm, st_);
+                    pcm, st_, 0, nf_dev_ + ps.row0);
     Q3_CHECK(T == Tframes * up_, 7, "internal error: codec upsampling mismatch");
     (void)dc;
 }
 
 int CodecRunner::decode(const int32_t* codes_dev, int code_stride_frames, const std::vector<int>& frames, float** pcm_dev,
-                        const std::string& stage, std::vector<float>* stage_out, int* stage_T, int* stage_C) {
+                        const std::string& stage, std::vector<float>* stage_out, int* stage_T, int* stage_C, int32_t* nonfinite_host) {
     const int B = int(frames.size());
+    Q3_CHECK(B <= kMaxRows, 3, "Invalid input: too many rows in one codec decode");
+    Q3_HIP(hipMemsetAsync(nf_dev_, 0, size_t(B) * 4, st_));
     int Fmax = 0;
     for (int f : frames) Fmax = std::max(Fmax, f);
     Q3_CHECK(Fmax > 0, 3, "Invalid input: no frames to decode");
@@ -276,11 +275,13 @@ int CodecRunner::decode(const int32_t* codes_dev, int code_stride_frames, const 
     for (int r0 = 0; r0 < B; r0 += rows_per_chunk) {
         Pass ps{};
         ps.nb = std::min(rows_per_chunk, B - r0);
+        ps.row0 = r0;
         ps.fr = lens_dev_ + r0;
         ps.stage = &stage; ps.stage_out = stage_out; ps.stage_T = stage_T; ps.stage_C = stage_C;
         run_front(ps, codes_dev + size_t(r0) * code_stride_frames * 16, code_stride_frames, Fmax, bufs);
         run_tail(ps, Fmax, bufs, pcm + size_t(r0) * Fmax * up_);
     }
+    if (nonfinite_host) Q3_HIP(hipMemcpyAsync(nonfinite_host, nf_dev_, size_t(B) * 4, hipMemcpyDeviceToHost, st_));
     *pcm_dev = pcm;
     return Fmax;
 }
@@ -292,12 +293,14 @@ int CodecRunner::decode(const int32_t* codes_dev, int code_stride_frames, const 
 // (tests/test_streaming.py). Each chunk's samples are copied to pcm_host ([B][Fmax * upsample], pinned) at their final
 // place and chunk_done[k] is recorded behind the copy.
 int CodecRunner::decode_chunked(const int32_t* codes_dev, int code_stride_frames, const std::vector<int>& frames, int chunk_frames,
-                                float* pcm_host, std::vector<hipEvent_t>& chunk_done) {
+                                float* pcm_host, std::vector<hipEvent_t>& chunk_done, int32_t* nonfinite_host) {
     const CodecDecoderConfig& dc = m_.cfg.codec;
     const int B = int(frames.size());
     int Fmax = 0;
     for (int f : frames) Fmax = std::max(Fmax, f);
     Q3_CHECK(Fmax > 0 && chunk_frames > 0, 3, "Invalid input: no frames to decode");
+    Q3_CHECK(B <= kMaxRows, 3, "Invalid input: too many rows in one codec decode");
+    Q3_HIP(hipMemsetAsync(nf_dev_, 0, size_t(B) * 4, st_));
     const int H = tail_context_frames();
     const int n_chunks = ceil_div(Fmax, chunk_frames);
     const int Tc = std::min(Fmax, chunk_frames + H);  // frames per tail pass, at most
@@ -346,6 +349,7 @@ int CodecRunner::decode_chunked(const int32_t* codes_dev, int code_stride_frames
                                 hipMemcpyDeviceToHost, st_));
         Q3_HIP(hipEventRecord(chunk_done[size_t(k)], st_));
     }
+    if (nonfinite_host) Q3_HIP(hipMemcpyAsync(nonfinite_host, nf_dev_, size_t(B) * 4, hipMemcpyDeviceToHost, st_));
     return n_chunks;
 }
 
@@ -452,10 +456,14 @@ void CodecRunner::stream_open(const StreamCfg& cfg) {
         Q3_HIP(hipMalloc(reinterpret_cast<void**>(&S.lens_dev), slots * cfg.rows * 4));
         S.lens_slots = slots * cfg.rows;
     }
+    Q3_CHECK(cfg.rows <= kMaxRows, 3, "Invalid input: too many rows in one codec decode");
+    Q3_HIP(hipMemsetAsync(nf_dev_, 0, size_t(cfg.rows) * 4, st_));
     S.open = true;
 }
 
-void CodecRunner::stream_close() {
+void CodecRunner::stream_close(int32_t* nonfinite_host) {
+    if (stream_.open && nonfinite_host)
+        Q3_HIP(hipMemcpyAsync(nonfinite_host, nf_dev_, size_t(stream_.cfg.rows) * 4, hipMemcpyDeviceToHost, st_));
     stream_.open = false;  // the arena stays for the next stream of the same shape
 }
 
@@ -603,7 +611,7 @@ void CodecRunner::run_tail_stream(const Pass& ps, float* lat, float* pcm) {
         const bool lastb = i + 1 == nblk;
         bool fused = !fp32_mfma_ && !no_fuse_ && resunit_supported(Bk.Cout, Bk.res[0].conv1.K, 9);
         for (int j = 0; j < 3; ++j)
-            fused = fused && Bk.res[j].conv1.w3 && Bk.res[j].conv2.w3p && Bk.res[j].conv1.wh && Bk.res[j].conv2.whp &&
+            fused = fused && Bk.res[j].conv1.wh && Bk.res[j].conv2.whp &&
                     Bk.res[j].conv1.N == Bk.Cout && Bk.res[j].conv2.K == 1 &&
                     resunit_supported(Bk.Cout, Bk.res[j].conv1.K, Bk.res[j].conv1.dil);
         const size_t ff = size_t(ppf) * Bk.stride * Bk.Cout;
@@ -620,8 +628,7 @@ void CodecRunner::run_tail_stream(const Pass& ps, float* lat, float* pcm) {
                 r.y = yb[j] + size_t(H) * ff; r.out = yb[j + 1] + size_t(H) * ff;
                 if (j == 2 && after) { r.out2 = hs_next + size_t(H) * ff; r.post_ea = after->ea; r.post_ib = after->ib; }
                 r.b1 = Bk.res[j].conv1.bias; r.b2 = Bk.res[j].conv2.bias;
-                if (bf16x3_) { r.w1 = Bk.res[j].conv1.w3; r.w2p = Bk.res[j].conv2.w3p; }
-                else { r.w1h = Bk.res[j].conv1.wh; r.w2ph = Bk.res[j].conv2.whp; r.wsc1 = Bk.res[j].conv1.wsc; r.wsc2 = Bk.res[j].conv2.wsc; }
+                r.w1h = Bk.res[j].conv1.wh; r.w2ph = Bk.res[j].conv2.whp; r.wsc1 = Bk.res[j].conv1.wsc; r.wsc2 = Bk.res[j].conv2.wsc;
                 r.ea1 = Bk.res[j].act1.ea; r.ib1 = Bk.res[j].act1.ib; r.ea2 = Bk.res[j].act2.ea; r.ib2 = Bk.res[j].act2.ib;
                 r.frames = fr; r.ppf = ppf; r.Tmax = T; r.B = nb; r.C = Bk.Cout; r.K = Bk.res[j].conv1.K; r.dil = Bk.res[j].conv1.dil;
                 r.hist = H * ppf;
@@ -649,7 +656,7 @@ void CodecRunner::run_tail_stream(const Pass& ps, float* lat, float* pcm) {
     if (!S.dry) {
         const size_t ff = size_t(ppf) * w.out_C;
         launch_out_conv(h + size_t(H) * ff, w.out_C, w.out_snake.ea, w.out_snake.ib, w.out_w, w.out_b, fr, ppf, T, nb,
-                        pcm + size_t(H) * ppf, st_, H * ppf);
+                        pcm + size_t(H) * ppf, st_, H * ppf, nf_dev_);
     }
     Q3_CHECK(ppf == up_, 7, "internal error: codec upsampling mismatch");
     (void)dc;

@@ -11,20 +11,23 @@ namespace q3 {
 
 class CodecRunner {
   public:
-    CodecRunner(const Model& m, hipStream_t st);
+    CodecRunner(const Model& m, hipStream_t st, bool fp32_convs = false);
     ~CodecRunner();
     // codes_dev: [B][code_stride_frames][16] int32 on the device; rows decode frames[b] frames.
     // pcm_dev receives [B][Fmax*upsample] float32 (Fmax = max(frames)); returns Fmax.
     // If `stage` is non-empty the activation after that stage is copied to stage_out ([B][T][C]).
+    // nonfinite_host (pinned, one int per row, optional): set to 1 behind the decode for rows whose waveform came out
+    // non-finite -- with the default fp16 two-plane convs that is what an activation beyond 65504 turns into (codec_conv.hip);
+    // the fp32 matrix-core path (q3tts_load_opts.codec_fp32) has the reference's range.
     int decode(const int32_t* codes_dev, int code_stride_frames, const std::vector<int>& frames, float** pcm_dev,
                const std::string& stage = std::string(), std::vector<float>* stage_out = nullptr, int* stage_T = nullptr,
-               int* stage_C = nullptr);
+               int* stage_C = nullptr, int32_t* nonfinite_host = nullptr);
     // The same decode with the causal tail (everything behind the pre-transformer) evaluated `chunk_frames` frames at a
     // time (row f1 of SURVEY 8f): each chunk's samples land in pcm_host ([B][Fmax * upsample], pinned host memory) at
     // their final place and chunk_done[k] is recorded behind chunk k's copy. Bit-identical to decode(). Returns the
     // number of chunks; chunk k covers frames [k * chunk_frames, min(Fmax, (k + 1) * chunk_frames)).
     int decode_chunked(const int32_t* codes_dev, int code_stride_frames, const std::vector<int>& frames, int chunk_frames,
-                       float* pcm_host, std::vector<hipEvent_t>& chunk_done);
+                       float* pcm_host, std::vector<hipEvent_t>& chunk_done, int32_t* nonfinite_host = nullptr);
     int tail_context_frames() const;
 
     // ---- streamed decode (row f1: audio while tokens are still being generated) -------------------------------------
@@ -45,7 +48,7 @@ class CodecRunner {
     // [rows][code_stride_frames][16], frames below avail[b] final. No host synchronisation.
     int stream_push(const int32_t* codes_dev, int code_stride_frames, const int* avail, const uint8_t* final_rows, float* pcm_host,
                     size_t pcm_row_stride, std::vector<hipEvent_t>& chunk_done);
-    void stream_close();
+    void stream_close(int32_t* nonfinite_host = nullptr);
     bool streaming() const { return stream_.open; }
     int hist_frames() const;
     int upsample() const { return up_; }
@@ -55,6 +58,7 @@ class CodecRunner {
   private:
     struct Pass {  // one pass of kernels over `nb` rows
         int nb = 0;
+        int row0 = 0;         // first row of this pass in the call's batch (non-finite flags)
         int hist_frames = 0;  // streamed decode: tensors carry this many frames of history in front of their first row
         const int32_t* fr = nullptr;  // device: valid frames per row
         const std::string* stage = nullptr;
@@ -89,12 +93,13 @@ class CodecRunner {
     size_t floats_per_frame() const;
     void upload_lens(const int32_t* lens, int n);
     int32_t* lens_host_ = nullptr;
+    int32_t* nf_dev_ = nullptr;  // [kMaxRows] non-finite flags of the decode in flight (out_conv)
+    static constexpr int kMaxRows = 4096;
     const Model& m_;
     hipStream_t st_;
     int up_ = 1920;
     bool no_fuse_ = false;    // Q3TTS_CODEC_NO_FUSE=1: residual units of the narrow blocks as two launches each
     bool fp32_mfma_ = false;  // Q3TTS_CODEC_FP32=1: contract on the fp32 matrix-core path instead of the split one
-    bool bf16x3_ = false;     // Q3TTS_CODEC_BF16X3=1: three bf16 planes / six products instead of two fp16 planes / three
     uint8_t* buf_ = nullptr;
     size_t buf_bytes_ = 0;
     int32_t* lens_dev_ = nullptr;

@@ -13,8 +13,6 @@ struct ConvGemmArgs {
     int ldx;
     int64_t x_bstride;
     const float* w;      // [N][K][Cin]
-    const uint16_t* w3;  // optional: w split into three bf16 planes (hi | mid | lo, exact), [K][ceil(Cin/32)][N][3][32];
-                         // selects the bf16x3 kernel (six bf16 MFMAs per product block instead of eight fp32 ones)
     const uint16_t* wh;  // optional: w * 2^s[n] split into two fp16 planes (hi | lo), [K][ceil(Cin/32)][N][2][32]; selects the
     const float* wsc;    // fp16x2 kernel (three fp16 MFMAs per product block); wsc[n] = 2^-s[n] rescales the accumulators
     const float* bias;   // [N] or nullptr
@@ -55,12 +53,10 @@ struct ResUnitArgs {
     float* out2;          // optional: SnakeBeta(post_ea, post_ib) of the result (next block's input) or nullptr
     const float* post_ea;
     const float* post_ib;
-    const uint16_t* w1;   // conv1 split planes [K][C/32][C][3][32]
     const float* b1;      // [C] or nullptr
-    const uint16_t* w2p;  // conv2 split planes, permuted k order [C/32][C][3][32] (model.cc attach_split_perm)
     const float* b2;
-    const uint16_t* w1h;  // fp16x2 form of both (model.cc attach_h2 / attach_h2_perm): [K][C/32][C][2][32], [C/32][C][2][32];
-    const uint16_t* w2ph; // when set, the fp16x2 kernel runs and w1 / w2p are not read
+    const uint16_t* w1h;  // conv1 / conv2 as two fp16 planes (model.cc attach_h2 / attach_h2_perm): [K][C/32][C][2][32] and, in the
+    const uint16_t* w2ph; // fused kernel's k order, [C/32][C][2][32]
     const float* wsc1;    // [C] 2^-s of conv1's / conv2's rows
     const float* wsc2;
     const float* ea1;     // act1: exp(alpha), 1/(exp(beta)+1e-9)
@@ -93,7 +89,8 @@ void launch_attn_full_f32(const float* qkv, int heads, const int32_t* frames, in
                           hipStream_t st);
 // SnakeBeta -> k7 conv C->1 -> clip(-1,1) (MainDecoder tail, SpeechTokenizer.swift:687-688,781)
 void launch_out_conv(const float* x, int C, const float* ea, const float* ib, const float* w, const float* bias,
-                     const int32_t* frames, int ppf, int Tmax, int B, float* pcm, hipStream_t st, int hist = 0);
+                     const int32_t* frames, int ppf, int Tmax, int B, float* pcm, hipStream_t st, int hist = 0,
+                     int32_t* nonfinite = nullptr);  // nonfinite[b] |= 1 when row b's pre-clip waveform holds an inf / NaN
 // streamed decode: rows [chunk_rows - keep_rows, chunk_rows) of every batch row move to [-keep_rows, 0) (history of the next chunk)
 void launch_roll_history(float* cur, int64_t bstride, int64_t keep_floats, int64_t chunk_floats, int B, hipStream_t st);
 

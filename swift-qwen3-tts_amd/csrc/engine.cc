@@ -19,6 +19,9 @@ std::string lower(const std::string& s) {
     for (auto& c : o) c = char(std::tolower((unsigned char)c));
     return o;
 }
+const char* const kCodecRangeMsg =
+    "Audio decoding failed: a codec decoder activation left the fp16 range of the two-plane convolutions; load the model with "
+    "q3tts_load_opts.codec_fp32 = 1 (fp32 matrix-core convolutions, the reference's range)";
 double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -68,6 +71,8 @@ Engine::Engine(Model* model, const q3tts_load_opts& opts) : m_(model), opts_(opt
         for (auto& e : J.ev_codec) Q3_HIP(hipEventCreate(&e));
         Q3_HIP(hipEventCreate(&J.ev_begin));
         Q3_HIP(hipEventCreate(&J.ev_first_audio));
+        Q3_HIP(hipHostMalloc(reinterpret_cast<void**>(&J.nf_host), size_t(std::max(opts.max_batch, 1)) * 4, hipHostMallocDefault));
+        std::memset(J.nf_host, 0, size_t(std::max(opts.max_batch, 1)) * 4);
     }
     for (auto& e : ev_) Q3_HIP(hipEventCreate(&e));
     for (auto& e : burst_ev_) Q3_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -90,7 +95,7 @@ Engine::Engine(Model* model, const q3tts_load_opts& opts) : m_(model), opts_(opt
         Q3_HIP(hipMalloc(reinterpret_cast<void**>(&stamps_), 64 * 8));
         Q3_HIP(hipMemset(stamps_, 0, 64 * 8));
     }
-    if (m_->has_codec) codec_ = std::make_unique<CodecRunner>(*m_, st_codec_);
+    if (m_->has_codec) codec_ = std::make_unique<CodecRunner>(*m_, st_codec_, opts.codec_fp32 != 0);
     if (m_->has_codec_encoder || m_->has_speaker_encoder) fe_ = std::make_unique<VoiceFrontEnd>(*m_, st_);
 }
 
@@ -125,6 +130,7 @@ Engine::~Engine() {
         if (J.pcm_host) (void)hipHostFree(J.pcm_host);
         for (auto& e : J.ev_codec)
             if (e) (void)hipEventDestroy(e);
+        if (J.nf_host) (void)hipHostFree(J.nf_host);
         if (J.ev_begin) (void)hipEventDestroy(J.ev_begin);
         if (J.ev_first_audio) (void)hipEventDestroy(J.ev_first_audio);
     }
@@ -973,7 +979,7 @@ int Engine::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3
     Q3_HIP(hipMemsetAsync(finished_, 0, size_t(n), st_));
     Q3_HIP(hipMemsetAsync(seen_, 0, size_t(n) * V, st_));
     Q3_HIP(hipMemsetAsync(codes_, 0, size_t(n) * Fcap_ * 16 * 4, st_));
-    SamplingParams sph{sp.temperature, sp.top_k, sp.top_p, sp.repetition_penalty, sp.seed, row_offset, sp.force_frames > 0 ? 1 : 0};
+    SamplingParams sph{sp.temperature, sp.top_k, sp.top_p, sp.repetition_penalty, sp.seed, row_offset + sp.row_base, sp.force_frames > 0 ? 1 : 0};
     Q3_HIP(hipMemcpyAsync(sp_dev_, &sph, sizeof(sph), hipMemcpyHostToDevice, st_));
     int frames_cap = 0;
     for (int f : maxf) frames_cap = std::max(frames_cap, f);
@@ -1033,6 +1039,7 @@ int Engine::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3
     hipStream_t sst = nullptr;
     std::vector<int> s_avail((size_t)(n), 0);
     std::vector<uint8_t> s_final((size_t)(n), 0);
+    std::memset(J.nf_host, 0, size_t(Bm_) * 4);
     J.streamed = false;
     J.chunks_fired = 0;
     J.t_first_audio = 0;
@@ -1195,7 +1202,7 @@ int Engine::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3
             s_final[size_t(b)] = 1;
         }
         stream_feed(launched);
-        codec_->stream_close();
+        codec_->stream_close(J.nf_host);
         Q3_HIP(hipStreamSynchronize(st_));
         Q3_HIP(hipEventRecord(J.ev_codec[1], sst));
         J.decoded = Fdec > 0;
@@ -1242,10 +1249,10 @@ int Engine::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3
         }
         if (J.chunk_frames > 0) {
             // pre-transformer once over all frames, then the causal tail chunk by chunk (codec.h decode_chunked)
-            J.n_chunks = codec_->decode_chunked(J.dec_codes, Fdec, dframes, J.chunk_frames, J.pcm_host, J.chunk_done);
+            J.n_chunks = codec_->decode_chunked(J.dec_codes, Fdec, dframes, J.chunk_frames, J.pcm_host, J.chunk_done, J.nf_host);
         } else {
             float* pcm_dev = nullptr;
-            codec_->decode(J.dec_codes, Fdec, dframes, &pcm_dev);
+            codec_->decode(J.dec_codes, Fdec, dframes, &pcm_dev, std::string(), nullptr, nullptr, nullptr, J.nf_host);
             Q3_HIP(hipMemcpyAsync(J.pcm_host, pcm_dev, floats * 4, hipMemcpyDeviceToHost, cst));
         }
         J.decoded = true;
@@ -1464,6 +1471,15 @@ void Engine::end(int job, q3tts_result* results) {
             r.status = Q3TTS_ERR_GENERATION_FAILED;
             continue;
         }
+        if (J.nf_host[b]) {  // never hand out a waveform with holes in it
+            r.status = Q3TTS_ERR_AUDIO_DECODING_FAILED;
+            last_error = kCodecRangeMsg;
+            std::free(J.st_pcm[size_t(b)]);
+            std::free(J.st_codes[size_t(b)]);
+            J.st_pcm[size_t(b)] = nullptr;
+            J.st_codes[size_t(b)] = nullptr;
+            continue;
+        }
         r.n_frames = F;
         r.codes = J.st_codes[size_t(b)];  // ownership passes to the result (q3tts_result_free)
         r.n_samples = row_ns[size_t(b)];
@@ -1573,13 +1589,22 @@ void Engine::codec_decode(const int32_t* codes, const int32_t* n_frames, int bat
     hipStream_t cst = codec_stream(false);
     Q3_HIP(hipEventRecord(ev_[2], cst));
     try {
-        if (Fmax > 0) codec_->decode(dcodes, max_frames, frames, &pcm_dev);
+        if (Fmax > 0) codec_->decode(dcodes, max_frames, frames, &pcm_dev, std::string(), nullptr, nullptr, nullptr, jobs_[0].busy ? nullptr : jobs_[0].nf_host);
     } catch (...) {
         (void)hipFree(dcodes);
         throw;
     }
     Q3_HIP(hipEventRecord(ev_[3], cst));
     Q3_HIP(hipStreamSynchronize(cst));
+    if (!jobs_[0].busy && batch <= Bm_) {
+        bool bad = false;
+        for (int b = 0; b < batch; ++b) bad = bad || jobs_[0].nf_host[b] != 0;
+        std::memset(jobs_[0].nf_host, 0, size_t(Bm_) * 4);
+        if (bad) {
+            (void)hipFree(dcodes);
+            throw Error(4, kCodecRangeMsg);
+        }
+    }
     float ms = 0;
     Q3_HIP(hipEventElapsedTime(&ms, ev_[2], ev_[3]));
     timing.codec_ms = ms;

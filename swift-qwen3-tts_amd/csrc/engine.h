@@ -151,6 +151,7 @@ class Engine {
         float* pcm_host = nullptr;        // pinned [n][Fdec * up]
         size_t pcm_host_cap = 0;
         hipEvent_t ev_codec[2] = {nullptr, nullptr};
+        int32_t* nf_host = nullptr;  // pinned [max_batch]: rows whose waveform came out non-finite (CodecRunner::decode)
         hipEvent_t ev_begin = nullptr, ev_first_audio = nullptr;  // request in / first streamed chunk on the host
         std::vector<hipEvent_t> chunk_done;  // chunked decode (audio_chunk_frames > 0): one per chunk, behind its copy
         int n_chunks = 0, chunk_frames = 0;

@@ -1,6 +1,9 @@
-// codec_conv.hip -- causal (dilated) 1-D convolution as an implicit GEMM on the fp32 matrix cores.
+// codec_conv.hip -- causal (dilated) 1-D convolution as an implicit GEMM on the matrix cores: conv_gemm_h2_kernel (fp16
+// MFMA, every fp32 operand split into two fp16 planes: the decoder's default), resunit_h2_kernel (a whole residual unit of
+// the narrow blocks in one launch) and conv_gemm_kernel (plain fp32 MFMA: the voice-clone front end, and the decoder when
+// an activation leaves the fp16 range or Q3TTS_CODEC_FP32=1 asks for it).
 //
-// One kernel serves every dense contraction of the codec decoder
+// One kernel body serves every dense contraction of the codec decoder
 // (/root/reference/Sources/Qwen3TTS/Models/SpeechTokenizer.swift): CausalConv1d (:259-306),
 // CausalTransposeConv1d (:311-354, stored in polyphase form by model.cc so that it is a causal
 // K<=2 conv whose N = stride*Cout outputs ARE the upsampled rows in channels-last memory), the
@@ -305,182 +308,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
     if (a.out2) snake_pass<CT>(a, smem, b, t0, n0, wn, T, wave, lane, acc, wm);
 }
 
-// ---- bf16x3 variant ---------------------------------------------------------------------------------
-// The same contraction with every fp32 operand written as an exact sum of three bf16 values (hi + mid + lo, 3 x 8
-// significand bits) and each product block evaluated as six v_mfma_f32_16x16x32_bf16 -- lo*hi, hi*lo, mid*mid, mid*hi,
-// hi*mid, hi*hi, smallest first -- accumulated in fp32. The three dropped cross terms are below 3 * 2^-24 of the product,
-// i.e. the result carries fp32-level rounding noise (PCM differs from the fp32-MFMA kernel by ~1e-7, tests/
-// test_gpu_parity.py), while the matrix cores spend 6 x 16 cycles per 16x16x32 block instead of 8 x 32: 2.67x less.
-// Weights are split once at load (model.cc attach_split), activations while they are staged into LDS. An LDS row holds
-// the three planes of 32 input channels (3 x 64 B) + 32 B of padding = 14 sixteen-byte units: 14 = 2 (mod 4) keeps the
-// ds_read_b128 lane groups of MI355X_MICROARCH.md on distinct banks. Weight tiles are single-buffered so that two
-// workgroups (70 KiB each at the widest halo) share a CU.
-constexpr int ROW3 = 56;  // dwords per LDS row
-
-__device__ __forceinline__ void split3(float x, uint32_t& h, uint32_t& m, uint32_t& l) {
-    h = __float_as_uint(x) & 0xffff0000u;
-    const float r1 = x - __uint_as_float(h);
-    m = __float_as_uint(r1) & 0xffff0000u;
-    const float r2 = r1 - __uint_as_float(m);
-    l = __float_as_uint(r2) & 0xffff0000u;
-}
-
-__device__ __forceinline__ f32x4 mfma_bf16(const uint4& a, const uint4& b, f32x4 c) {
-    bf16x8 av, bv;
-    __builtin_memcpy(&av, &a, 16);
-    __builtin_memcpy(&bv, &b, 16);
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, c, 0, 0, 0);
-}
-
-// PRO: input prologues compiled in (pre-add, ELU, SnakeBeta, reflect/shift windows). The decoder's convs need none of them
-// since SnakeBeta moved to the producers' epilogues, and their staging loop is then a bare load + split.
-template <int BN, bool PRO>
-__global__ __launch_bounds__(256, 2) void conv_gemm_split_kernel(ConvGemmArgs a) {
-    constexpr int CT = BN / 32;
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem3[];
-    const int halo = (a.K - 1) * a.dil;
-    uint32_t* As = smem3;                        // [(BM + halo)][ROW3]
-    uint32_t* Ws = smem3 + (BM + halo) * ROW3;   // [BN][ROW3]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int b = blockIdx.z;
-    const int n0 = blockIdx.x * BN;
-    const int t0 = blockIdx.y * BM;
-    const int T = a.frames[b] * a.ppf;
-    if (t0 >= T) return;
-    const int rows = BM + halo;
-    const float* xb = a.x + (size_t)b * a.x_bstride;
-    const float* x2b = a.x2;
-    const int nchunks = (a.Cin + KC - 1) / KC;
-    const int steps = nchunks * a.K;
-
-    f32x4 acc[4][CT];
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int c = 0; c < CT; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // weight tile of one (tap, chunk) step: BN x 12 sixteen-byte pieces, contiguous in global memory
-    constexpr int WV = (BN * 12 + 255) / 256;
-    uint4 wreg[WV];
-    auto load_w = [&](int step) {
-        const int chunk = step / a.K, tap = step % a.K;
-        const uint4* src = reinterpret_cast<const uint4*>(a.w3 + ((size_t)(tap * nchunks + chunk) * a.N + n0) * 96);
-#pragma unroll
-        for (int i = 0; i < WV; ++i) {
-            const int item = i * 256 + tid;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (item < BN * 12 && n0 + item / 12 < a.N) v = src[item];
-            wreg[i] = v;
-        }
-    };
-    auto store_w = [&]() {
-#pragma unroll
-        for (int i = 0; i < WV; ++i) {
-            const int item = i * 256 + tid;
-            if (item < BN * 12) *reinterpret_cast<uint4*>(&Ws[(item / 12) * ROW3 + (item % 12) * 4]) = wreg[i];
-        }
-    };
-
-    constexpr int AV = ((BM + MAX_HALO) * 8 + 255) / 256;
-    float4 areg[AV];
-    auto load_a = [&](int chunk) {
-        const int c0 = chunk * KC;
-#pragma unroll
-        for (int i = 0; i < AV; ++i) {
-            const int item = i * 256 + tid;
-            const int r = item >> 3, c4 = (item & 7) * 4;
-            int t = t0 - halo + r;
-            if constexpr (PRO) {
-                t += a.shift;
-                if (a.reflect) t = t < 0 ? -t : (t >= T ? 2 * (T - 1) - t : t);
-            }
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < rows && t >= -a.hist && t < T && c0 + c4 < a.Cin) {
-                v = *reinterpret_cast<const float4*>(xb + (int64_t)t * a.ldx + c0 + c4);
-                if constexpr (PRO) {
-                    if (x2b) {
-                        const float4 u = *reinterpret_cast<const float4*>(x2b + (int64_t)t * a.ldx2 + c0 + c4);
-                        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-                    }
-                    if (a.pre_act == 1) {
-                        v.x = v.x > 0.f ? v.x : expf(v.x) - 1.0f;
-                        v.y = v.y > 0.f ? v.y : expf(v.y) - 1.0f;
-                        v.z = v.z > 0.f ? v.z : expf(v.z) - 1.0f;
-                        v.w = v.w > 0.f ? v.w : expf(v.w) - 1.0f;
-                    }
-                    if (a.snake_ea) {
-                        const float4 ea = *reinterpret_cast<const float4*>(a.snake_ea + c0 + c4);
-                        const float4 ib = *reinterpret_cast<const float4*>(a.snake_ib + c0 + c4);
-                        float s;
-                        s = sinf(v.x * ea.x); v.x = v.x + ib.x * (s * s);
-                        s = sinf(v.y * ea.y); v.y = v.y + ib.y * (s * s);
-                        s = sinf(v.z * ea.z); v.z = v.z + ib.z * (s * s);
-                        s = sinf(v.w * ea.w); v.w = v.w + ib.w * (s * s);
-                    }
-                }
-            }
-            areg[i] = v;
-        }
-    };
-    auto store_a = [&]() {
-#pragma unroll
-        for (int i = 0; i < AV; ++i) {
-            const int item = i * 256 + tid;
-            const int r = item >> 3, c4 = (item & 7) * 4;
-            if (r >= rows) continue;
-            uint32_t h[4], m[4], l[4];
-            split3(areg[i].x, h[0], m[0], l[0]);
-            split3(areg[i].y, h[1], m[1], l[1]);
-            split3(areg[i].z, h[2], m[2], l[2]);
-            split3(areg[i].w, h[3], m[3], l[3]);
-            uint32_t* dst = &As[r * ROW3 + (c4 >> 1)];
-            *reinterpret_cast<uint2*>(dst) = make_uint2((h[0] >> 16) | h[1], (h[2] >> 16) | h[3]);
-            *reinterpret_cast<uint2*>(dst + 16) = make_uint2((m[0] >> 16) | m[1], (m[2] >> 16) | m[3]);
-            *reinterpret_cast<uint2*>(dst + 32) = make_uint2((l[0] >> 16) | l[1], (l[2] >> 16) | l[3]);
-        }
-    };
-
-    load_w(0);
-    load_a(0);
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        __syncthreads();  // the previous chunk's MFMAs are done with As and Ws
-        store_a();
-        if (chunk + 1 < nchunks) load_a(chunk + 1);
-        for (int tap = 0; tap < a.K; ++tap) {
-            const int step = chunk * a.K + tap;
-            if (tap > 0) __syncthreads();  // the previous tap's reads of Ws
-            store_w();
-            __syncthreads();
-            if (step + 1 < steps) load_w(step + 1);
-            const uint32_t* arow = &As[(wm * 64 + tap * a.dil + (lane & 15)) * ROW3 + 4 * (lane >> 4)];
-            const uint32_t* wrow = &Ws[(wn * (BN / 2) + (lane & 15)) * ROW3 + 4 * (lane >> 4)];
-            uint4 xa[3][4], wa[3][CT];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-#pragma unroll
-                for (int p = 0; p < 4; ++p) xa[pl][p] = *reinterpret_cast<const uint4*>(arow + p * 16 * ROW3 + pl * 16);
-#pragma unroll
-                for (int c = 0; c < CT; ++c) wa[pl][c] = *reinterpret_cast<const uint4*>(wrow + c * 16 * ROW3 + pl * 16);
-            }
-            // (weight plane, activation plane) pairs, smallest product first
-            constexpr int PW[6] = {2, 0, 1, 1, 0, 0};
-            constexpr int PX[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-#pragma unroll
-                for (int p = 0; p < 4; ++p)
-#pragma unroll
-                    for (int c = 0; c < CT; ++c) acc[p][c] = mfma_bf16(wa[PW[q]][c], xa[PX[q]][p], acc[p][c]);
-        }
-    }
-
-    if (a.act != 0) epilogue_tile<CT, true>(a, b, t0 + wm * 64, n0 + wn * (BN / 2), T, lane, acc);
-    else epilogue_tile<CT, false>(a, b, t0 + wm * 64, n0 + wn * (BN / 2), T, lane, acc);
-    if (a.out2) snake_pass<CT>(a, reinterpret_cast<float*>(smem3), b, t0, n0, wn, T, wave, lane, acc, wm);
-}
-
 // ---- fp16x2 variant ------------------------------------------------------------------------------------
 // Three matrix-core products per block instead of six. fp16 carries 11 significand bits, so two planes hold 22:
 //   activations  x = xh + 2^-11 xl'   xh = fp16(x) (round to nearest), xl' = fp16((x - xh) * 2^11)   -- split while staging;
@@ -703,285 +530,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_h2_kernel(ConvGemmArgs a) {
 //  * act1 is applied while the raw tile of y (+ causal halo) is staged -- one N tile, so nothing is evaluated twice
 //    except the halo rows;
 //  * each wave owns 32 positions x ALL channels, so conv1's accumulators already hold conv2's whole reduction dimension:
-//    an accumulator pair (tiles 2m, 2m+1) of a lane is exactly one bf16 MFMA B fragment (8 k values of its position)
-//    once conv2's weights are stored with the matching k order (model.cc attach_split_perm) -- act2 and the 3-way
-//    split happen in registers and conv1's output never leaves the wave;
+//    an accumulator pair (tiles 2m, 2m+1) of a lane is exactly one MFMA B fragment (8 k values of its position) once
+//    conv2's weights are stored with the matching k order (model.cc attach_h2_perm) -- act2 and the two-plane split
+//    happen in registers and conv1's output never leaves the wave;
 //  * the residual is the raw y tile again (L2-warm), the sum goes to a second buffer because neighbouring workgroups
 //    still need the old halo rows.
-// LDS: (128 + halo + C) rows x 224 B <= 62 KiB, two workgroups per CU.
-template <int CT2>
-__global__ __launch_bounds__(256, 2) void resunit_split_kernel(ResUnitArgs a) {
-    constexpr int C = 16 * CT2, NCH = CT2 / 2;
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem3[];
-    const int halo = (a.K - 1) * a.dil;
-    uint32_t* As = smem3;                        // [(BM + halo)][ROW3]
-    uint32_t* Ws = smem3 + (BM + halo) * ROW3;   // [C][ROW3]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.z;
-    const int t0 = blockIdx.y * BM;
-    const int T = a.frames[b] * a.ppf;
-    if (t0 >= T) return;
-    const int rows = BM + halo;
-    const size_t boff = (size_t)b * a.Tmax * C;
-    const float* yb = a.y + boff;
-    const int S1 = NCH * a.K;  // conv1 steps; conv2 adds NCH more
-
-    f32x4 acc1[2][CT2];
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int c = 0; c < CT2; ++c) acc1[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    constexpr int WV = (C * 12 + 255) / 256;
-    uint4 wreg[WV];
-    auto load_w = [&](int step) {
-        const uint4* src;
-        if (step < S1) {
-            const int chunk = step / a.K, tap = step % a.K;
-            src = reinterpret_cast<const uint4*>(a.w1 + (size_t)(tap * NCH + chunk) * C * 96);
-        } else {
-            src = reinterpret_cast<const uint4*>(a.w2p + (size_t)(step - S1) * C * 96);
-        }
-#pragma unroll
-        for (int i = 0; i < WV; ++i) {
-            const int item = i * 256 + tid;
-            wreg[i] = item < C * 12 ? src[item] : make_uint4(0u, 0u, 0u, 0u);
-        }
-    };
-    auto store_w = [&]() {
-#pragma unroll
-        for (int i = 0; i < WV; ++i) {
-            const int item = i * 256 + tid;
-            if (item < C * 12) *reinterpret_cast<uint4*>(&Ws[(item / 12) * ROW3 + (item % 12) * 4]) = wreg[i];
-        }
-    };
-
-    constexpr int AV = ((BM + MAX_HALO) * 8 + 255) / 256;
-    float4 areg[AV];
-    auto load_a = [&](int chunk) {
-        const int c0 = chunk * KC;
-#pragma unroll
-        for (int i = 0; i < AV; ++i) {
-            const int item = i * 256 + tid;
-            const int r = item >> 3, c4 = (item & 7) * 4;
-            const int t = t0 - halo + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < rows && t >= -a.hist && t < T) {
-                v = *reinterpret_cast<const float4*>(yb + (int64_t)t * C + c0 + c4);
-                const float4 ea = *reinterpret_cast<const float4*>(a.ea1 + c0 + c4);
-                const float4 ib = *reinterpret_cast<const float4*>(a.ib1 + c0 + c4);
-                v.x = v.x + ib.x * snake_sin2(v.x * ea.x);
-                v.y = v.y + ib.y * snake_sin2(v.y * ea.y);
-                v.z = v.z + ib.z * snake_sin2(v.z * ea.z);
-                v.w = v.w + ib.w * snake_sin2(v.w * ea.w);
-            }
-            areg[i] = v;
-        }
-    };
-    auto store_a = [&]() {
-#pragma unroll
-        for (int i = 0; i < AV; ++i) {
-            const int item = i * 256 + tid;
-            const int r = item >> 3, c4 = (item & 7) * 4;
-            if (r >= rows) continue;
-            uint32_t h[4], m[4], l[4];
-            split3(areg[i].x, h[0], m[0], l[0]);
-            split3(areg[i].y, h[1], m[1], l[1]);
-            split3(areg[i].z, h[2], m[2], l[2]);
-            split3(areg[i].w, h[3], m[3], l[3]);
-            uint32_t* dst = &As[r * ROW3 + (c4 >> 1)];
-            *reinterpret_cast<uint2*>(dst) = make_uint2((h[0] >> 16) | h[1], (h[2] >> 16) | h[3]);
-            *reinterpret_cast<uint2*>(dst + 16) = make_uint2((m[0] >> 16) | m[1], (m[2] >> 16) | m[3]);
-            *reinterpret_cast<uint2*>(dst + 32) = make_uint2((l[0] >> 16) | l[1], (l[2] >> 16) | l[3]);
-        }
-    };
-    constexpr int PW[6] = {2, 0, 1, 1, 0, 0};  // (weight plane, activation plane), smallest product first
-    constexpr int PX[6] = {0, 2, 1, 0, 1, 0};
-    const uint32_t* wrow = &Ws[(lane & 15) * ROW3 + 4 * (lane >> 4)];
-
-    // ---- conv1 ----
-    load_w(0);
-    load_a(0);
-    for (int chunk = 0; chunk < NCH; ++chunk) {
-        __syncthreads();
-        store_a();
-        if (chunk + 1 < NCH) load_a(chunk + 1);
-        for (int tap = 0; tap < a.K; ++tap) {
-            const int step = chunk * a.K + tap;
-            if (tap > 0) __syncthreads();
-            store_w();
-            __syncthreads();
-            load_w(step + 1);  // the step after conv1's last one is conv2's first
-            const uint32_t* arow = &As[(32 * wave + tap * a.dil + (lane & 15)) * ROW3 + 4 * (lane >> 4)];
-            uint4 xa[3][2], wa[3][CT2];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-#pragma unroll
-                for (int p = 0; p < 2; ++p) xa[pl][p] = *reinterpret_cast<const uint4*>(arow + p * 16 * ROW3 + pl * 16);
-#pragma unroll
-                for (int c = 0; c < CT2; ++c) wa[pl][c] = *reinterpret_cast<const uint4*>(wrow + c * 16 * ROW3 + pl * 16);
-            }
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-#pragma unroll
-                for (int p = 0; p < 2; ++p)
-#pragma unroll
-                    for (int c = 0; c < CT2; ++c) acc1[p][c] = mfma_bf16(wa[PW[q]][c], xa[PX[q]][p], acc1[p][c]);
-        }
-    }
-
-    // ---- + bias1, act2 in registers (lane: channels 16c + 4(lane >> 4) + j of its two position tiles) ----
-    const int q4 = 4 * (lane >> 4);
-    int big = 0;
-#pragma unroll
-    for (int c = 0; c < CT2; ++c) {
-        const float4 bv = a.b1 ? *reinterpret_cast<const float4*>(a.b1 + 16 * c + q4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 ea = *reinterpret_cast<const float4*>(a.ea2 + 16 * c + q4);
-        const float e[4] = {ea.x, ea.y, ea.z, ea.w}, bb[4] = {bv.x, bv.y, bv.z, bv.w};
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc1[p][c][j] += bb[j];
-                big |= !(fabsf(acc1[p][c][j] * e[j]) < 1.0e6f);
-            }
-    }
-    // block-wide vote (also the barrier that retires conv1's tiles): arguments beyond the polynomial's range are possible
-    // only in a diverged model; the whole workgroup then goes through the libm path, one tile at a time via LDS
-    if (__syncthreads_or(big)) {
-        float4* stash = reinterpret_cast<float4*>(As) + wave * (CT2 * 64);
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-#pragma unroll
-            for (int c = 0; c < CT2; ++c) stash[c * 64 + lane] = make_float4(acc1[p][c][0], acc1[p][c][1], acc1[p][c][2], acc1[p][c][3]);
-#pragma unroll 1
-            for (int c = 0; c < CT2; ++c) {
-                float4 v = stash[c * 64 + lane];
-                const float4 ea = *reinterpret_cast<const float4*>(a.ea2 + 16 * c + q4);
-                const float4 ib = *reinterpret_cast<const float4*>(a.ib2 + 16 * c + q4);
-                v.x = v.x + ib.x * snake_sin2(v.x * ea.x);
-                v.y = v.y + ib.y * snake_sin2(v.y * ea.y);
-                v.z = v.z + ib.z * snake_sin2(v.z * ea.z);
-                v.w = v.w + ib.w * snake_sin2(v.w * ea.w);
-                stash[c * 64 + lane] = v;
-            }
-#pragma unroll
-            for (int c = 0; c < CT2; ++c) {
-                const float4 v = stash[c * 64 + lane];
-                acc1[p][c] = f32x4{v.x, v.y, v.z, v.w};
-            }
-        }
-    } else {
-#pragma unroll
-        for (int c = 0; c < CT2; ++c) {
-            const float4 ea = *reinterpret_cast<const float4*>(a.ea2 + 16 * c + q4);
-            const float4 ib = *reinterpret_cast<const float4*>(a.ib2 + 16 * c + q4);
-            const float e[4] = {ea.x, ea.y, ea.z, ea.w}, ii[4] = {ib.x, ib.y, ib.z, ib.w};
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc1[p][c][j] = acc1[p][c][j] + ii[j] * snake_sin2_poly(acc1[p][c][j] * e[j]);
-        }
-    }
-
-    // ---- conv2: the B fragments come out of acc1 ----
-    f32x4 acc2[2][CT2];
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int c = 0; c < CT2; ++c) acc2[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int m = 0; m < NCH; ++m) {
-        if (m > 0) __syncthreads();  // the previous chunk's reads of Ws (chunk 0: the vote above)
-        store_w();
-        __syncthreads();
-        if (m + 1 < NCH) load_w(S1 + m + 1);
-        uint4 xb[3][2], wa[3][CT2];
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const float v[8] = {acc1[p][2 * m][0], acc1[p][2 * m][1], acc1[p][2 * m][2], acc1[p][2 * m][3],
-                                acc1[p][2 * m + 1][0], acc1[p][2 * m + 1][1], acc1[p][2 * m + 1][2], acc1[p][2 * m + 1][3]};
-            uint32_t h[8], mm[8], l[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) split3(v[j], h[j], mm[j], l[j]);
-            xb[0][p] = make_uint4((h[0] >> 16) | h[1], (h[2] >> 16) | h[3], (h[4] >> 16) | h[5], (h[6] >> 16) | h[7]);
-            xb[1][p] = make_uint4((mm[0] >> 16) | mm[1], (mm[2] >> 16) | mm[3], (mm[4] >> 16) | mm[5], (mm[6] >> 16) | mm[7]);
-            xb[2][p] = make_uint4((l[0] >> 16) | l[1], (l[2] >> 16) | l[3], (l[4] >> 16) | l[5], (l[6] >> 16) | l[7]);
-        }
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-            for (int c = 0; c < CT2; ++c) wa[pl][c] = *reinterpret_cast<const uint4*>(wrow + c * 16 * ROW3 + pl * 16);
-#pragma unroll
-        for (int q = 0; q < 6; ++q)
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-#pragma unroll
-                for (int c = 0; c < CT2; ++c) acc2[p][c] = mfma_bf16(wa[PW[q]][c], xb[PX[q]][p], acc2[p][c]);
-    }
-
-    // ---- + bias2 + y -> out; optionally the next block's SnakeBeta of the sum -> out2 ----
-    // (every residual request before the first store: out and y could alias as far as the compiler knows, and it had
-    // emitted one load-wait-store round trip per accumulator tile)
-    float4 rvs[2][CT2], bv2[CT2];
-#pragma unroll
-    for (int c = 0; c < CT2; ++c) bv2[c] = a.b2 ? *reinterpret_cast<const float4*>(a.b2 + 16 * c + q4) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int t = t0 + 32 * wave + 16 * p + (lane & 15);
-#pragma unroll
-        for (int c = 0; c < CT2; ++c) {
-            rvs[p][c] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t < T) rvs[p][c] = *reinterpret_cast<const float4*>(yb + (size_t)t * C + 16 * c + q4);
-        }
-    }
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int t = t0 + 32 * wave + 16 * p + (lane & 15);
-        if (t >= T) continue;
-#pragma unroll
-        for (int c = 0; c < CT2; ++c) {
-            const int n = 16 * c + q4;
-            const float4 rv = rvs[p][c];
-            float4 v = make_float4(acc2[p][c][0] + rv.x, acc2[p][c][1] + rv.y, acc2[p][c][2] + rv.z, acc2[p][c][3] + rv.w);
-            if (a.b2) {
-                const float4 bv = bv2[c];
-                v = make_float4((acc2[p][c][0] + bv.x) + rv.x, (acc2[p][c][1] + bv.y) + rv.y, (acc2[p][c][2] + bv.z) + rv.z,
-                                (acc2[p][c][3] + bv.w) + rv.w);
-            }
-            st16(a.out + boff + (size_t)t * C + n, v);
-            acc2[p][c] = f32x4{v.x, v.y, v.z, v.w};
-        }
-    }
-    if (a.out2) {  // As is free since the vote; every lane uses its own stash slots
-        float4* stash = reinterpret_cast<float4*>(As) + wave * (CT2 * 64);
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-#pragma unroll
-            for (int c = 0; c < CT2; ++c) stash[c * 64 + lane] = make_float4(acc2[p][c][0], acc2[p][c][1], acc2[p][c][2], acc2[p][c][3]);
-            const int t = t0 + 32 * wave + 16 * p + (lane & 15);
-            if (t >= T) continue;
-#pragma unroll 1
-            for (int c = 0; c < CT2; ++c) {
-                const int n = 16 * c + q4;
-                float4 v = stash[c * 64 + lane];
-                const float4 ea = *reinterpret_cast<const float4*>(a.post_ea + n);
-                const float4 ib = *reinterpret_cast<const float4*>(a.post_ib + n);
-                v.x = v.x + ib.x * snake_sin2(v.x * ea.x);
-                v.y = v.y + ib.y * snake_sin2(v.y * ea.y);
-                v.z = v.z + ib.z * snake_sin2(v.z * ea.z);
-                v.w = v.w + ib.w * snake_sin2(v.w * ea.w);
-                st16(a.out2 + boff + (size_t)t * C + n, v);
-            }
-        }
-    }
-}
-
-// ---- fused residual unit, fp16x2 --------------------------------------------------------------------------
-// resunit_split_kernel's structure with the two-plane fp16 split of conv_gemm_h2_kernel: three products per block, two
-// LDS planes, weight tiles double-buffered. conv1's accumulators (scaled by its 2^-s, + bias, SnakeBeta act2) are split in
-// registers into conv2's B fragments as before.
+// Numerics and LDS layout as conv_gemm_h2_kernel: three fp16 products per block, weight tiles double-buffered;
+// (128 + halo + 2 C) rows x 160 B <= 60 KiB, two workgroups per CU.
 template <int CT2>
 __global__ __launch_bounds__(256, 2) void resunit_h2_kernel(ResUnitArgs a) {
     constexpr int C = 16 * CT2, NCH = CT2 / 2;
@@ -1274,28 +829,18 @@ void launch_resunit(const ResUnitArgs& a, hipStream_t st) {
     if (mt <= 0 || a.B <= 0) return;
     static bool attr_set = false;
     if (!attr_set) {
-        void (*ks[6])(ResUnitArgs) = {&resunit_split_kernel<2>, &resunit_split_kernel<4>, &resunit_split_kernel<6>,
-                                      &resunit_h2_kernel<2>,    &resunit_h2_kernel<4>,    &resunit_h2_kernel<6>};
+        void (*ks[3])(ResUnitArgs) = {&resunit_h2_kernel<2>, &resunit_h2_kernel<4>, &resunit_h2_kernel<6>};
         for (auto k : ks)
             Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         attr_set = true;
     }
     dim3 grid(1, mt, a.B), block(256);
-    if (a.w1h) {
-        Q3_CHECK(a.w2ph && a.wsc1 && a.wsc2, 3, "resunit: incomplete fp16x2 weights");
-        const size_t smemh = size_t(BM + (a.K - 1) * a.dil + 2 * a.C) * ROWH * sizeof(uint32_t);
-        switch (a.C) {
-            case 32: hipLaunchKernelGGL(resunit_h2_kernel<2>, grid, block, smemh, st, a); break;
-            case 64: hipLaunchKernelGGL(resunit_h2_kernel<4>, grid, block, smemh, st, a); break;
-            default: hipLaunchKernelGGL(resunit_h2_kernel<6>, grid, block, smemh, st, a); break;
-        }
-        return;
-    }
-    const size_t smem = size_t(BM + (a.K - 1) * a.dil + a.C) * ROW3 * sizeof(uint32_t);
+    Q3_CHECK(a.w1h && a.w2ph && a.wsc1 && a.wsc2, 3, "resunit: incomplete fp16x2 weights");
+    const size_t smemh = size_t(BM + (a.K - 1) * a.dil + 2 * a.C) * ROWH * sizeof(uint32_t);
     switch (a.C) {
-        case 32: hipLaunchKernelGGL(resunit_split_kernel<2>, grid, block, smem, st, a); break;
-        case 64: hipLaunchKernelGGL(resunit_split_kernel<4>, grid, block, smem, st, a); break;
-        default: hipLaunchKernelGGL(resunit_split_kernel<6>, grid, block, smem, st, a); break;
+        case 32: hipLaunchKernelGGL(resunit_h2_kernel<2>, grid, block, smemh, st, a); break;
+        case 64: hipLaunchKernelGGL(resunit_h2_kernel<4>, grid, block, smemh, st, a); break;
+        default: hipLaunchKernelGGL(resunit_h2_kernel<6>, grid, block, smemh, st, a); break;
     }
 }
 
@@ -1316,11 +861,6 @@ void launch_conv_gemm(const ConvGemmArgs& a, hipStream_t st) {
         Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<96>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        void (*split_kernels[6])(ConvGemmArgs) = {&conv_gemm_split_kernel<128, true>, &conv_gemm_split_kernel<128, false>,
-                                                   &conv_gemm_split_kernel<96, true>,  &conv_gemm_split_kernel<96, false>,
-                                                   &conv_gemm_split_kernel<64, true>,  &conv_gemm_split_kernel<64, false>};
-        for (auto k : split_kernels)
-            Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         void (*h2_kernels[6])(ConvGemmArgs) = {&conv_gemm_h2_kernel<128, true>, &conv_gemm_h2_kernel<128, false>,
                                                 &conv_gemm_h2_kernel<96, true>,  &conv_gemm_h2_kernel<96, false>,
                                                 &conv_gemm_h2_kernel<64, true>,  &conv_gemm_h2_kernel<64, false>};
@@ -1337,17 +877,6 @@ void launch_conv_gemm(const ConvGemmArgs& a, hipStream_t st) {
             case 128: pro ? go(&conv_gemm_h2_kernel<128, true>) : go(&conv_gemm_h2_kernel<128, false>); break;
             case 96: pro ? go(&conv_gemm_h2_kernel<96, true>) : go(&conv_gemm_h2_kernel<96, false>); break;
             default: pro ? go(&conv_gemm_h2_kernel<64, true>) : go(&conv_gemm_h2_kernel<64, false>); break;
-        }
-        return;
-    }
-    if (a.w3) {
-        const size_t smem3 = size_t(BM + (a.K - 1) * a.dil + BN) * ROW3 * sizeof(uint32_t);
-        const bool pro = a.x2 || a.pre_act || a.snake_ea || a.shift || a.reflect;
-        auto go = [&](void (*kern)(ConvGemmArgs)) { hipLaunchKernelGGL(kern, grid, block, smem3, st, a); };
-        switch (BN) {
-            case 128: pro ? go(&conv_gemm_split_kernel<128, true>) : go(&conv_gemm_split_kernel<128, false>); break;
-            case 96: pro ? go(&conv_gemm_split_kernel<96, true>) : go(&conv_gemm_split_kernel<96, false>); break;
-            default: pro ? go(&conv_gemm_split_kernel<64, true>) : go(&conv_gemm_split_kernel<64, false>); break;
         }
         return;
     }

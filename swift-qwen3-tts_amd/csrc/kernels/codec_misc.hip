@@ -155,7 +155,7 @@ __global__ __launch_bounds__(64) void attn_full_f32_kernel(const float* qkv, int
 // the banks) and the 7 x C taps sit in LDS; a lane owns every fourth 4-channel group of its position.
 __global__ __launch_bounds__(256) void out_conv_kernel(const float* x, int C, const float* ea, const float* ib,
                                                        const float* w, const float* bias, const int32_t* frames, int ppf,
-                                                       int Tmax, float* pcm, int hist) {
+                                                       int Tmax, float* pcm, int hist, int32_t* nonfinite) {
     extern __shared__ __attribute__((aligned(16))) float xs[];  // [(64+6)][C + 4] snake(x), then [7][C] taps
     const int ld = C + 4, C4 = C >> 2;
     float* ws = xs + 70 * ld;
@@ -206,6 +206,8 @@ __global__ __launch_bounds__(256) void out_conv_kernel(const float* x, int C, co
     const int t = t0 + p;
     if (part == 0 && t < T) {
         const float v = acc + bias[0];
+        // an activation beyond the fp16 range of the two-plane convs (codec_conv.hip) arrives here as inf / NaN: tell the host
+        if (nonfinite && !(fabsf(v) < INFINITY)) atomicOr(nonfinite + b, 1);
         pcm[(size_t)b * Tmax + t] = fminf(fmaxf(v, -1.0f), 1.0f);
     }
 }
@@ -252,11 +254,11 @@ void launch_attn_full_f32(const float* qkv, int heads, const int32_t* frames, in
                        out);
 }
 void launch_out_conv(const float* x, int C, const float* ea, const float* ib, const float* w, const float* bias,
-                     const int32_t* frames, int ppf, int Tmax, int B, float* pcm, hipStream_t st, int hist) {
+                     const int32_t* frames, int ppf, int Tmax, int B, float* pcm, hipStream_t st, int hist, int32_t* nonfinite) {
     const size_t smem = (size_t(70) * (C + 4) + size_t(7) * C) * sizeof(float);
     Q3_CHECK(smem <= 64 * 1024 && C % 4 == 0 && C >= 4 && C <= 1024, 3, "out_conv: unsupported channel count");
     hipLaunchKernelGGL(out_conv_kernel, dim3((Tmax + 63) / 64, B), dim3(256), smem, st, x, C, ea, ib, w, bias, frames, ppf,
-                       Tmax, pcm, hist);
+                       Tmax, pcm, hist, nonfinite);
 }
 
 }  // namespace q3

@@ -298,7 +298,7 @@ struct Builder {
     size_t off = 0;
     uint8_t* staging = nullptr;   // device staging for raw matrices before tiling
     size_t max_staging = 0;       // bytes, collected in the dry pass
-    bool split3 = false;          // codec decoder: convs also get the three-plane bf16 copy of their weights
+    bool split3 = false;          // codec decoder: convs also get the two-plane fp16 copy of their weights (attach_h2)
 
     template <class T>
     T* alloc(size_t n) {
@@ -527,66 +527,6 @@ const HostTensor* maybe(const TMap& t, const std::string& k) {
     return it == t.end() ? nullptr : &it->second;
 }
 
-// x = hi + mid + lo exactly, each a bf16 (truncation keeps the next 8 significand bits each time: 3 x 8 = 24).
-// The device side splits activations the same way (codec_conv.hip).
-inline void split_bf16x3(float x, uint16_t& hi, uint16_t& mid, uint16_t& lo) {
-    uint32_t u;
-    std::memcpy(&u, &x, 4);
-    const uint32_t h = u & 0xffff0000u;
-    float hf;
-    std::memcpy(&hf, &h, 4);
-    const float r1 = x - hf;
-    std::memcpy(&u, &r1, 4);
-    const uint32_t m = u & 0xffff0000u;
-    float mf;
-    std::memcpy(&mf, &m, 4);
-    const float r2 = r1 - mf;
-    std::memcpy(&u, &r2, 4);
-    hi = uint16_t(h >> 16);
-    mid = uint16_t(m >> 16);
-    lo = uint16_t(u >> 16);
-}
-
-// w [N][K][Cin] fp32 -> [K][chunks of 32 input channels][N][3 planes][32] bf16 (zero beyond Cin): one (tap, chunk)
-// step of conv_gemm_split_kernel reads BN * 192 contiguous bytes
-void attach_split(Builder& b, ConvW& c, const std::vector<float>& w) {
-    if (!b.split3) return;
-    const int chunks = (c.Cin + 31) / 32;
-    const size_t n = size_t(c.K) * chunks * c.N * 96;
-    std::vector<uint16_t> p;
-    if (!b.dry && b.fill && !w.empty()) {
-        p.assign(n, 0);
-        for (int nn = 0; nn < c.N; ++nn)
-            for (int tap = 0; tap < c.K; ++tap)
-                for (int ci = 0; ci < c.Cin; ++ci) {
-                    uint16_t* d = &p[((size_t(tap) * chunks + ci / 32) * c.N + nn) * 96 + (ci % 32)];
-                    split_bf16x3(w[(size_t(nn) * c.K + tap) * c.Cin + ci], d[0], d[32], d[64]);
-                }
-    }
-    c.w3 = b.put<uint16_t>(p.empty() ? nullptr : p.data(), n);
-}
-
-// conv2 of a residual unit for the fused kernel: k slot s = 8q + 4e + j of chunk m holds input channel 32m + 16e + 4q + j,
-// i.e. what lane group q of an MFMA accumulator pair (tiles 2m, 2m+1) carries in registers j of tile e
-void attach_split_perm(Builder& b, ConvW& c, const std::vector<float>& w) {
-    if (!b.split3 || c.K != 1 || c.Cin % 32 != 0) return;
-    const int chunks = c.Cin / 32;
-    const size_t n = size_t(chunks) * c.N * 96;
-    std::vector<uint16_t> p;
-    if (!b.dry && b.fill && !w.empty()) {
-        p.assign(n, 0);
-        for (int nn = 0; nn < c.N; ++nn)
-            for (int m = 0; m < chunks; ++m)
-                for (int s = 0; s < 32; ++s) {
-                    const int q = s >> 3, e = (s >> 2) & 1, j = s & 3;
-                    const int ci = 32 * m + 16 * e + 4 * q + j;
-                    uint16_t* d = &p[(size_t(m) * c.N + nn) * 96 + s];
-                    split_bf16x3(w[size_t(nn) * c.Cin + ci], d[0], d[32], d[64]);
-                }
-    }
-    c.w3p = b.put<uint16_t>(p.empty() ? nullptr : p.data(), n);
-}
-
 // ---- fp16x2 form (codec_conv.hip conv_gemm_h2_kernel) ----
 inline uint16_t f32_to_f16_bits(float x) {  // round to nearest even (the compiler's conversion; |x| < 65520 here)
     const _Float16 h = static_cast<_Float16>(x);
@@ -652,7 +592,9 @@ void attach_h2(Builder& b, ConvW& c, const std::vector<float>& w) {
     put_row_scales(b, c, s, have);
 }
 
-// conv2 of a residual unit in the fused kernel's k order (see attach_split_perm); shares wsc with attach_h2's copy
+// conv2 of a residual unit for the fused kernel: k slot s = 8q + 4e + j of chunk m holds input channel 32m + 16e + 4q + j,
+// i.e. what lane group q of an MFMA accumulator pair (tiles 2m, 2m+1) carries in registers j of tile e; shares wsc with
+// attach_h2's copy
 void attach_h2_perm(Builder& b, ConvW& c, const std::vector<float>& w) {
     if (!b.split3 || c.K != 1 || c.Cin % 32 != 0) return;
     const int chunks = c.Cin / 32;
@@ -687,7 +629,6 @@ ConvW put_conv(Builder& b, const TMap& t, const std::string& name, int dil = 1) 
     }
     c.dil = dil;
     c.w = b.put_f32(w);
-    attach_split(b, c, w.data);
     attach_h2(b, c, w.data);
     if (const HostTensor* bias = maybe(t, name + ".bias")) c.bias = b.put_f32(*bias);
     return c;
@@ -715,7 +656,6 @@ ConvW put_linear_concat(Builder& b, const TMap& t, const std::vector<std::string
     c.K = 1;
     c.Cin = K;
     c.w = b.put_f32(cat);
-    attach_split(b, c, cat.data);
     attach_h2(b, c, cat.data);
     return c;
 }
@@ -747,7 +687,6 @@ ConvW put_tconv(Builder& b, const TMap& t, const std::string& name, int stride) 
     c.Cin = Cin;
     c.dil = 1;
     c.w = b.put_f32(p);
-    attach_split(b, c, p.data);
     attach_h2(b, c, p.data);
     if (const HostTensor* bias = maybe(t, name + ".bias")) {
         HostTensor bb;
@@ -810,7 +749,6 @@ void build_codec(Builder& b, const TMap& t, const CodecDecoderConfig& dc, CodecW
         c.rvq_out.K = 1;
         c.rvq_out.Cin = 2 * in;
         c.rvq_out.w = b.put_f32(f);
-        attach_split(b, c.rvq_out, f.data);
         attach_h2(b, c.rvq_out, f.data);
     }
     c.pre_conv = put_conv(b, t, "decoder.pre_conv.conv");
@@ -863,7 +801,6 @@ void build_codec(Builder& b, const TMap& t, const CodecDecoderConfig& dc, CodecW
             B.res[j].conv1 = put_conv(b, t, rp + ".conv1.conv", dils[j]);
             B.res[j].act2 = put_snake(b, t, rp + ".act2");
             B.res[j].conv2 = put_conv(b, t, rp + ".conv2.conv");
-            attach_split_perm(b, B.res[j].conv2, need(t, rp + ".conv2.conv.weight").data);
             attach_h2_perm(b, B.res[j].conv2, need(t, rp + ".conv2.conv.weight").data);
         }
     }

@@ -48,12 +48,10 @@ struct StackW {
 
 struct ConvW {  // fp32 conv as GEMM: w[N][K][Cin]; transposed convs are stored in polyphase form
     const float* w = nullptr;
-    const uint16_t* w3 = nullptr;  // codec decoder only: the same weights as three bf16 planes, [K][ceil(Cin/32)][N][3][32]
-    const uint16_t* w3p = nullptr; // pointwise conv behind a k7 conv (DecoderResidualUnit conv2): w3 with the 32 input channels of a
-                                   // chunk in the order the fused kernel's accumulators hold them (codec_conv.hip resunit_split_kernel)
     const uint16_t* wh = nullptr;  // codec decoder only: w * 2^s[n] as two fp16 planes (hi | lo), [K][ceil(Cin/32)][N][2][32], and
     const float* wsc = nullptr;    // wsc[n] = 2^-s[n] (codec_conv.hip conv_gemm_h2_kernel; model.cc attach_h2)
-    const uint16_t* whp = nullptr; // wh in the fused kernel's k order (like w3p)
+    const uint16_t* whp = nullptr; // pointwise conv behind a k7 conv (DecoderResidualUnit conv2): wh with the 32 input channels of a
+                                   // chunk in the order the fused kernel's accumulators hold them (codec_conv.hip resunit_h2_kernel)
     const float* bias = nullptr;   // [N] or nullptr
     const float* scale = nullptr;  // per-output-channel scale (LayerScale / ConvNeXt gamma) or nullptr
     int Cin = 0, N = 0, K = 1, dil = 1;

@@ -18,7 +18,7 @@ u8p = C.POINTER(C.c_uint8)
 class LoadOpts(C.Structure):
     _fields_ = [("device", C.c_int32), ("max_batch", C.c_int32), ("max_frames", C.c_int32),
                 ("max_prompt", C.c_int32), ("use_graph", C.c_int32), ("weights_from_broadcast", C.c_int32),
-                ("n_streams", C.c_int32), ("codec_overlap_cus", C.c_int32)]
+                ("n_streams", C.c_int32), ("codec_overlap_cus", C.c_int32), ("codec_fp32", C.c_int32)]
 
 
 class ModelInfo(C.Structure):
@@ -42,7 +42,7 @@ class Request(C.Structure):
 class Sampling(C.Structure):
     _fields_ = [("temperature", C.c_float), ("top_k", C.c_int32), ("top_p", C.c_float),
                 ("repetition_penalty", C.c_float), ("seed", C.c_uint64), ("force_frames", C.c_int32), ("audio_chunk_frames", C.c_int32),
-                ("audio_window_frames", C.c_int32), ("audio_lookahead_frames", C.c_int32)]
+                ("audio_window_frames", C.c_int32), ("audio_lookahead_frames", C.c_int32), ("row_base", C.c_uint32)]
 
 
 class GenInfo(C.Structure):

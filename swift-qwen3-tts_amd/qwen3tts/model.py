@@ -113,7 +113,7 @@ class Qwen3TTSModel:
     def from_pretrained(cls, model_path: str, device: int = 0, max_batch: int = 1, max_frames: int = 2048,
                         max_prompt: int = 512, use_graph: bool = True,
                         weights_from_broadcast: bool = False, n_streams: int = 0,
-                        codec_overlap_cus: int = 0) -> "Qwen3TTSModel":
+                        codec_overlap_cus: int = 0, codec_fp32: bool = False) -> "Qwen3TTSModel":
         lib = L.lib()
         o = L.LoadOpts()
         lib.q3tts_default_load_opts(C.byref(o))
@@ -122,6 +122,7 @@ class Qwen3TTSModel:
         o.weights_from_broadcast = 1 if weights_from_broadcast else 0
         o.n_streams = n_streams
         o.codec_overlap_cus = codec_overlap_cus
+        o.codec_fp32 = 1 if codec_fp32 else 0
         h = C.c_void_p()
         st = lib.q3tts_model_load(model_path.encode(), C.byref(o), C.byref(h))
         if st != 0:
@@ -205,19 +206,20 @@ class Qwen3TTSModel:
 
     @staticmethod
     def _sampling(temperature, top_k, top_p, repetition_penalty, seed, force_frames, audio_chunk_frames=0,
-                  audio_window_frames=0, audio_lookahead_frames=4) -> L.Sampling:
+                  audio_window_frames=0, audio_lookahead_frames=4, row_base=0) -> L.Sampling:
         s = L.Sampling()
         s.temperature, s.top_k, s.top_p = temperature, top_k, top_p
         s.repetition_penalty, s.seed, s.force_frames = repetition_penalty, seed, force_frames
         s.audio_chunk_frames = audio_chunk_frames
         s.audio_window_frames, s.audio_lookahead_frames = audio_window_frames, audio_lookahead_frames
+        s.row_base = row_base
         return s
 
     def generate_batch(self, reqs: Sequence[GenerationRequest], temperature: float = 0.9, top_k: int = 50,
                        top_p: float = 1.0, repetition_penalty: float = 1.05, seed: int = 0, force_frames: int = 0,
                        on_event: Optional[Callable[[int, str, object], None]] = None,
                        audio_chunk_frames: int = 0, audio_window_frames: int = 0,
-                       audio_lookahead_frames: int = 4) -> List[GenerationResult]:
+                       audio_lookahead_frames: int = 4, row_base: int = 0) -> List[GenerationResult]:
         """n utterances in one call (row-independent). `on_event(request_index, kind, payload)` receives
         ("token", id) / ("info", AudioGenerationInfo) / ("audio", ndarray) in the reference's order; with
         audio_chunk_frames > 0 also ("audio_chunk", (sample_offset, ndarray)) pieces of the final audio, in order,
@@ -226,7 +228,7 @@ class Qwen3TTSModel:
         pre-transformer then sees a sliding window; the waveform is within a stated tolerance of the one-shot decode)."""
         arr, keep = self._marshal(reqs)
         s = self._sampling(temperature, top_k, top_p, repetition_penalty, seed, force_frames, audio_chunk_frames,
-                           audio_window_frames, audio_lookahead_frames)
+                           audio_window_frames, audio_lookahead_frames, row_base)
         cb = self._event_cb(on_event)
         res = (L.Result * len(reqs))()
         st = self._lib.q3tts_generate(self._h, arr, len(reqs), C.byref(s), cb, None, res)
@@ -278,13 +280,13 @@ class Qwen3TTSModel:
     def generate_batch_begin(self, reqs: Sequence[GenerationRequest], temperature: float = 0.9, top_k: int = 50,
                              top_p: float = 1.0, repetition_penalty: float = 1.05, seed: int = 0, force_frames: int = 0,
                              on_event: Optional[Callable[[int, str, object], None]] = None, audio_chunk_frames: int = 0,
-                             more_follows: bool = True):
+                             more_follows: bool = True, row_base: int = 0):
         """First half of generate_batch (q3tts_generate_begin): returns a job once the AR loop has produced the codes and
         their codec decode is queued. The next batch may be begun before this one is ended: its AR loop then overlaps
         this batch's decode. At most two jobs may be outstanding. more_follows=False (the last batch of a queue) lets the
         decode use the whole chip instead of leaving room for a next batch."""
         arr, keep = self._marshal(reqs)
-        s = self._sampling(temperature, top_k, top_p, repetition_penalty, seed, force_frames, audio_chunk_frames)
+        s = self._sampling(temperature, top_k, top_p, repetition_penalty, seed, force_frames, audio_chunk_frames, row_base=row_base)
         cb = self._event_cb(on_event)
         job = C.c_void_p()
         self._check(self._lib.q3tts_generate_begin(self._h, arr, len(reqs), C.byref(s), cb, None, 1 if more_follows else 0,

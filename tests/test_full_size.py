@@ -96,9 +96,10 @@ def full_codec_dir(tmp_path_factory):
 
 
 def test_full_size_codec_both_contraction_paths_match_the_oracle(full_codec_dir, monkeypatch):
-    """The codec decoder contracts on bf16 matrix cores with every fp32 operand split exactly into three bf16 planes
-    (six products per block, csrc/kernels/codec_conv.hip); Q3TTS_CODEC_FP32=1 selects the plain fp32 matrix-core
-    kernel. Both must sit at fp32 rounding noise from the oracle's fmaf chains at the real layer widths, stage by stage."""
+    """The codec decoder contracts on fp16 matrix cores with every fp32 operand split into two fp16 planes (three
+    products per block, csrc/kernels/codec_conv.hip); Q3TTS_CODEC_FP32=1 (q3tts_load_opts.codec_fp32) selects the plain
+    fp32 matrix-core kernel. Both must sit at fp32 rounding noise from the oracle's fmaf chains at the real layer widths,
+    stage by stage."""
     from oracle import oracle as O
     from qwen3tts import Qwen3TTSModel
     om = O.OracleModel(full_codec_dir)
@@ -119,7 +120,7 @@ def test_full_size_codec_both_contraction_paths_match_the_oracle(full_codec_dir,
                 assert err <= 1e-4, (mode, s, err)      # tolerance of the codec stages (test_gpu_parity.py)
         finally:
             m.close()
-    print("worst stage error / stage scale: bf16x3 %.2e, fp32 MFMA %.2e" % (worst["0"], worst["1"]))
+    print("worst stage error / stage scale: fp16x2 %.2e, fp32 MFMA %.2e" % (worst["0"], worst["1"]))
     # measured: 4.3e-5 for both at block3 (the SnakeBeta chain amplifies fp32 rounding noise of ANY summation order)
     assert worst["0"] <= 1.5 * worst["1"] + 1e-6         # the split path is no noisier than the fp32 matrix cores
 
@@ -181,6 +182,8 @@ def _forced_parity(m, om, reqs, rows, F, seed, rep=1.05, ref_codes=None):
     # first codes below the suppressed range and away from EOS so that no row finishes early
     forced = np.concatenate([rng.integers(1, V - 1024, size=(n, F, 1)), rng.integers(0, Vc, size=(n, F, 15))], -1).astype(np.int32)
     tl, cl, sampled = m.debug_generate_forced(reqs, forced, temperature=0.0, repetition_penalty=rep)
+    sampled_run = m.debug_generate_forced(reqs, forced, temperature=0.9, top_k=50, repetition_penalty=rep, seed=seed)
+    assert (sampled_run[0] == tl).all() and (sampled_run[1] == cl).all()   # teacher forcing: the logits do not depend on the draws
     worst = 0.0
     for r in rows:
         oreq = _oracle_request(reqs[r], None if ref_codes is None else ref_codes[r])
@@ -202,6 +205,29 @@ def _forced_parity(m, om, reqs, rows, F, seed, rep=1.05, ref_codes=None):
             worst = max(worst, float(err.max()))
             assert err.max() <= max(2.0, 1.5 * floor.max()), (what, r, float(err.max()), float(floor.max()))
             assert err.mean() <= max(0.25, 1.5 * floor.mean()), (what, r, float(err.mean()), float(floor.mean()))
+            # ... and absolutely: the floor is the oracle's own property, so a regression THERE must not widen the bar silently
+            # (measured over all five configs: engine mean <= 0.36 / max <= 3.7 ulp, floor mean <= 0.57 / max <= 4.2 ulp)
+            assert floor.mean() <= 0.8 and floor.max() <= 6.5, ("oracle order floor grew", what, r, float(floor.mean()), float(floor.max()))
+            assert err.mean() <= 0.5 and err.max() <= 6.0, (what, r, float(err.mean()), float(err.max()))
+            # per element against ITS OWN floor: beyond 2 ulp + 1.5x the distance between the oracle's two readings of that
+            # very element only a handful of rounding flips remain
+            far = float((err > 2.0 + 1.5 * floor).mean())
+            print("   elements beyond 2 ulp + 1.5 x own floor: %.2e" % far)
+            assert far <= 1e-3, (what, r, far)   # measured <= 3.3e-4
+        # sampled decoding as the bench runs it (T = 0.9, top-k 50): the oracle's sampler on the ENGINE's logits with the same
+        # Philox key (seed, global row, frame * 16 + codebook) must draw the engine's token -- every codebook of every frame
+        import ctypes as C
+        tl_s, cl_s, sampled_s = sampled_run
+        seen = np.zeros(V, np.uint8)
+        for f in range(F):
+            tok = O.lib().o_sample_token(O._p16(tl_s[r, f]), V, C.c_float(0.9), 50, C.c_float(1.0), C.c_float(rep),
+                                         seen.ctypes.data_as(O.u8p), V - 1024, V, m.info.codec_eos_token_id, 0, C.c_uint64(seed), r, f * 16)
+            assert tok == int(sampled_s[r, f, 0]), ("sampled talker token", r, f, tok, int(sampled_s[r, f, 0]))
+            seen[forced[r, f, 0]] = 1   # generatedTokens holds what was fed back (the forced code)
+            for i in range(15):
+                tok = O.lib().o_sample_token(O._p16(cl_s[r, f, i]), Vc, C.c_float(0.9), 50, C.c_float(1.0), C.c_float(1.0), None, 0, 0,
+                                             -1, 0, C.c_uint64(seed), r, f * 16 + 1 + i)
+                assert tok == int(sampled_s[r, f, 1 + i]), ("sampled predictor token", r, f, i)
         # the engine's greedy picks from its own logits: the oracle's argmax wherever the oracle's margin exceeds the bar
         for f in range(F):
             b = bf16_to_f32(tr.cp_logits[f])
@@ -321,7 +347,19 @@ def test_config3_1p7b_base_voice_clone_batch16_logits_match_the_oracle():
         row = 9
         codes = {row: m.codec_encode(reqs[row].ref_audio)}
         assert codes[row].shape == (16, 38)
-        worst = _forced_parity(m, O.OracleModel(d), reqs, rows=(row,), F=4, seed=103, rep=1.5, ref_codes=codes)
+        om = O.OracleModel(d)
+        worst = _forced_parity(m, om, reqs, rows=(row,), F=4, seed=103, rep=1.5, ref_codes=codes)
         print("1.7B-Base clone batch 16: worst logit error %.2f bf16 ulp of the row scale" % worst)
+        # ... and one row END TO END against the oracle: its own encoder, its own x-vector, its own ICL prompt. Taken from the
+        # rows whose reference codes the two encoders agree on exactly (an RVQ near-tie flipped by fp32 summation order would
+        # change the whole prompt; the encoder's own tests cover those).
+        row2 = None
+        for cand in (2, 5, 12, 14):
+            if np.array_equal(m.codec_encode(reqs[cand].ref_audio), om.codec_encode(reqs[cand].ref_audio)):
+                row2 = cand
+                break
+        assert row2 is not None, "no row whose reference codes match the oracle's exactly"
+        worst2 = _forced_parity(m, om, reqs, rows=(row2,), F=3, seed=113, rep=1.5, ref_codes=None)
+        print("1.7B-Base clone batch 16, row %d end to end (oracle's own encoder): worst %.2f ulp" % (row2, worst2))
     finally:
         m.close()

@@ -1,0 +1,66 @@
+"""SURVEY 8(e) on the hardware this pool offers (one card): two fresh processes -- started before either touches the GPU --
+share device 0 over gloo. Rank 0 loads the checkpoint, rank 1 receives the weight arena through bench.broadcast_weights
+(the only collective of the job), checksums agree, and each rank's shard of the rows equals the single-process result for
+the same global row indices bit for bit (prompts AND random streams are keyed by the global row index)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import tiny_request
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.gpu
+def test_two_ranks_one_device_equal_the_single_process_rows(ckpt_dirs, tmp_path):
+    from qwen3tts import GenerationRequest, Qwen3TTSModel
+    total, world = 4, 2
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_two_rank_worker.py"), ckpt_dirs["tiny-b"], str(tmp_path),
+                                       str(total)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o.decode(errors="replace"))
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    r0, r1 = (np.load(tmp_path / f"rank{r}.npz") for r in range(world))
+    assert (int(r0["lo"]), int(r0["hi"]), int(r1["lo"]), int(r1["hi"])) == (0, 2, 2, 4)
+    assert int(r0["nbytes"]) == int(r1["nbytes"]) and int(r0["after"]) == int(r1["after"]) == int(r0["before"])
+    assert int(r1["before"]) != int(r1["after"])          # rank 1 really started without the weights
+    assert int(r0["frames"]) == int(r1["frames"]) == total * 12
+    # the same four rows in ONE process
+    m = Qwen3TTSModel.from_pretrained(ckpt_dirs["tiny-b"], max_batch=total, max_frames=32, max_prompt=96)
+    try:
+        reqs = []
+        for row in range(total):
+            r = tiny_request(row=row, n_text=6 + row)
+            reqs.append(GenerationRequest(r["text_ids"], r["target_token_count"], r["instruct_ids"], r["speaker"], r["language"]))
+        want = m.generate_batch(reqs, temperature=0.9, top_k=40, repetition_penalty=1.05, seed=77, force_frames=12)
+    finally:
+        m.close()
+    got_codes = np.concatenate([r0["codes"], r1["codes"]])
+    got_audio = np.concatenate([r0["audio"], r1["audio"]])
+    for i, w in enumerate(want):
+        assert (got_codes[i] == w.codes).all() and (got_audio[i] == w.audio).all(), i
+    assert len({tuple(c[:, 0]) for c in got_codes}) == total   # and the rows are not copies of each other

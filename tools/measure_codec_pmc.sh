@@ -8,7 +8,7 @@ out=gpurun_out/codec_pmc
 rm -rf $out && mkdir -p $out
 sets=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS"
       "SQ_WAVE_CYCLES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE")
-echo "# tools/codec_only.py 16 100 (bf16x3 kernels of this build), rocprofv3 --kernel-trace --pmc, two passes; values / SQ_WAVE_CYCLES" > $out/summary.txt
+echo "# tools/codec_only.py 16 100 (fp16x2 kernels of this build), rocprofv3 --kernel-trace --pmc, two passes; values / SQ_WAVE_CYCLES" > $out/summary.txt
 i=0
 for s in "${sets[@]}"; do
   timeout -k 10 280 rocprofv3 --kernel-trace --pmc $s --output-format csv -d $out/p$i -o t -- python3 tools/codec_only.py 16 100 > $out/p$i.log 2>&1
