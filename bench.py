@@ -305,6 +305,15 @@ def main():
     codec_products = 3
     codec_flops_bf16 = codec_products * 2 * 2.484e9 * n_frames_step
     latency_ms = (solo["voice_frontend"] + solo["prefill"] + solo["ar_decode"] + solo["codec_decode"]) if solo else None
+    # HBM GB/s of the decoder's two narrow stages from the PMC passes committed under profiles/ (FETCH_SIZE x 2 +
+    # WRITE_SIZE per launch over un-profiled durations, tools/measure_codec_traffic.sh); reported while the kernel sources match
+    codec_hbm = None
+    cpath = os.path.join(ROOT, "profiles", "codec_traffic.json")
+    if os.path.exists(cpath):
+        cj = json.load(open(cpath))
+        codec_hbm = {k: {"hbm_gbs": v["hbm_gbs"], "gb": v["bytes"] / 1e9, "ms": v["ms"]} for k, v in cj["stages"].items()}
+        codec_hbm["source"] = "profiles/codec_traffic.json (%d rows x %d frames; rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE)%s" % (
+            cj["rows"], cj["frames"], "" if cj.get("kernel_sources_sha16") == kernel_sources_sha16() else "; measured on EARLIER kernel sources")
     out = {
         "metric": "codec_tokens_per_s", "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -341,6 +350,7 @@ def main():
                            "unit": "TFLOP/s", "frac": codec_flops_bf16 / (codec_solo_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                            "fp32_equivalent_tflops": 2 * 2.484e9 * n_frames_step / (codec_solo_ms * 1e-3) / 1e12,
                            "algorithmic_gmac_per_frame": 2.484, "frames_per_launch_sequence": n_frames_step,
+                           "narrow_stages_hbm": codec_hbm, "hbm_peak_gbs": HBM_PEAK_GBS,
                            "ms": codec_solo_ms, "measured": "one batch alone (last warm-up step)" if solo else "overlapped steps"},
     }
     if world == 1 and not clone:

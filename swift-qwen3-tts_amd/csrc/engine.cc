@@ -1587,19 +1587,23 @@ void Engine::codec_decode(const int32_t* codes, const int32_t* n_frames, int bat
     }
     float* pcm_dev = nullptr;
     hipStream_t cst = codec_stream(false);
+    int32_t* nf = nullptr;  // pinned: rows whose waveform came out non-finite
+    Q3_HIP(hipHostMalloc(reinterpret_cast<void**>(&nf), size_t(batch) * 4, hipHostMallocDefault));
+    std::memset(nf, 0, size_t(batch) * 4);
     Q3_HIP(hipEventRecord(ev_[2], cst));
     try {
-        if (Fmax > 0) codec_->decode(dcodes, max_frames, frames, &pcm_dev, std::string(), nullptr, nullptr, nullptr, jobs_[0].busy ? nullptr : jobs_[0].nf_host);
+        if (Fmax > 0) codec_->decode(dcodes, max_frames, frames, &pcm_dev, std::string(), nullptr, nullptr, nullptr, nf);
     } catch (...) {
         (void)hipFree(dcodes);
+        (void)hipHostFree(nf);
         throw;
     }
     Q3_HIP(hipEventRecord(ev_[3], cst));
     Q3_HIP(hipStreamSynchronize(cst));
-    if (!jobs_[0].busy && batch <= Bm_) {
+    {
         bool bad = false;
-        for (int b = 0; b < batch; ++b) bad = bad || jobs_[0].nf_host[b] != 0;
-        std::memset(jobs_[0].nf_host, 0, size_t(Bm_) * 4);
+        for (int b = 0; b < batch; ++b) bad = bad || nf[b] != 0;
+        (void)hipHostFree(nf);
         if (bad) {
             (void)hipFree(dcodes);
             throw Error(4, kCodecRangeMsg);

@@ -1,0 +1,89 @@
+"""Join the PMC passes of tools/measure_codec_traffic.sh with the un-profiled kernel trace, launch by launch (the decoder's
+conv launches come in a fixed order, labelled as in tools/conv_trace.py): HBM-side bytes (FETCH_SIZE x 2 per
+MI355X_MICROARCH.md's gfx950 correction for 16-byte-per-lane streaming reads, + WRITE_SIZE) and GB/s per launch, summed
+per decoder block. Writes profiles-ready JSON next to the text table.
+usage: codec_traffic.py fetch_counter.csv write_counter.csv kernel_trace.csv B F"""
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+fetch_csv, write_csv, trace_csv = sys.argv[1:4]
+B, F = int(sys.argv[4]), int(sys.argv[5])
+REPS = 3
+
+
+def is_conv(name):
+    return "conv_gemm" in name or "out_conv" in name or "resunit" in name
+
+
+def last_decode(rows, key):
+    rows = [r for r in rows if is_conv(r["Kernel_Name"])]
+    rows.sort(key=key)
+    n = len(rows) // REPS
+    return rows[-n:]
+
+
+def counter_rows(path, cname):
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == cname]
+    return last_decode(rows, lambda r: int(r["Dispatch_Id"]))
+
+
+fe = counter_rows(fetch_csv, "FETCH_SIZE")
+wr = counter_rows(write_csv, "WRITE_SIZE")
+tr = last_decode(list(csv.DictReader(open(trace_csv))), lambda r: int(r["Start_Timestamp"]))
+assert len(fe) == len(wr) == len(tr), (len(fe), len(wr), len(tr))
+
+# launch labels: the same walk as tools/conv_trace.py
+seq = [("rvq_out", 512, 512, 1, 1), ("pre_conv", 512, 1024, 3, 1), ("t_in", 1024, 512, 1, 1)]
+for l in range(8):
+    seq += [(f"t{l}.qkv", 512, 1536, 1, 1), (f"t{l}.o", 512, 512, 1, 1), (f"t{l}.gateup", 512, 2048, 1, 1), (f"t{l}.down", 1024, 512, 1, 1)]
+seq += [("t_out", 512, 1024, 1, 1)]
+ppf = 1
+for i in range(2):
+    seq += [(f"up{i}.tconv", 1024, 2048, 1, ppf)]
+    ppf *= 2
+    seq += [(f"up{i}.pw1", 1024, 4096, 1, ppf), (f"up{i}.pw2", 4096, 1024, 1, ppf)]
+seq += [("init_conv", 1024, 1536, 7, ppf)]
+C = 1536
+for i, s in enumerate((8, 5, 4, 3)):
+    seq += [(f"b{i}.tconv", C, s * (C // 2), 2, ppf)]
+    ppf *= s
+    C //= 2
+    for j in range(3):
+        if C <= 96:
+            seq += [(f"b{i}.res{j}.fused", C, C, 8, ppf)]
+        else:
+            seq += [(f"b{i}.res{j}.conv1", C, C, 7, ppf), (f"b{i}.res{j}.conv2", C, C, 1, ppf)]
+seq += [("out_conv", 96, 1, 7, ppf)]
+assert len(seq) == len(tr), (len(seq), len(tr))
+
+rows, blocks = [], {}
+print(f"{'launch':18s} {'us':>9s} {'fetch GB':>9s} {'write GB':>9s} {'GB/s':>8s}   (FETCH_SIZE x 2 + WRITE_SIZE, un-profiled duration)")
+for (name, cin, n, k, p), f, w, t in zip(seq, fe, wr, tr):
+    us = (int(t["End_Timestamp"]) - int(t["Start_Timestamp"])) / 1e3
+    fb = float(f["Counter_Value"]) * 1024 * 2   # KB; x2 on gfx950 for 16-byte-per-lane streaming reads
+    wb = float(w["Counter_Value"]) * 1024
+    gbs = (fb + wb) / us / 1e3
+    print(f"{name:18s} {us:9.1f} {fb / 1e9:9.3f} {wb / 1e9:9.3f} {gbs:8.0f}")
+    rows.append({"launch": name, "us": us, "fetch_bytes": fb, "write_bytes": wb, "gbs": gbs})
+    g = name.split(".")[0]
+    b = blocks.setdefault(g, {"us": 0.0, "bytes": 0.0})
+    b["us"] += us
+    b["bytes"] += fb + wb
+print()
+for g in ("b2", "b3"):
+    b = blocks[g]
+    print(f"{g}: {b['bytes'] / 1e9:.1f} GB in {b['us'] / 1e3:.2f} ms = {b['bytes'] / b['us'] / 1e3:.0f} GB/s")
+import bench  # noqa: E402
+out = {"what": f"HBM-side bytes per conv launch of one codec decode ({B} rows x {F} frames), rocprofv3 FETCH_SIZE (x2) + WRITE_SIZE, "
+               "durations from an un-profiled kernel trace of the same workload",
+       "kernel_sources_sha16": bench.kernel_sources_sha16(), "rows": B, "frames": F,
+       "stages": {"C192 (block 2)": {"bytes": blocks["b2"]["bytes"], "ms": blocks["b2"]["us"] / 1e3,
+                                     "hbm_gbs": blocks["b2"]["bytes"] / blocks["b2"]["us"] / 1e3},
+                  "C96 (block 3)": {"bytes": blocks["b3"]["bytes"], "ms": blocks["b3"]["us"] / 1e3,
+                                    "hbm_gbs": blocks["b3"]["bytes"] / blocks["b3"]["us"] / 1e3}},
+       "launches": rows}
+json.dump(out, open(os.path.join(os.path.dirname(fetch_csv), "..", "codec_traffic.json"), "w"), indent=1)
