@@ -39,6 +39,9 @@ constexpr int MAX_HALO = 56;   // (K-1)*dil <= 54 in the decoder (k7, dil 9)
 // 16-byte tensor store. (Written through to memory -- `sc0 sc1`, with or without `nt` -- the decode's stores leave no
 // dirty lines in the XCD L2s; measured beside a frame loop that changes nothing: 775-778 ms per pipelined step either way.)
 __device__ __forceinline__ void st16(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+// (Non-temporal tensor loads and stores were measured too: the decode alone 125 -> 133 ms, and the frame loop beside it no
+// faster -- what the loop loses beside a decode is not cache space)
+__device__ __forceinline__ float4 ld16f(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
             if (a.reflect) t = t < 0 ? -t : (t >= T ? 2 * (T - 1) - t : t);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < rows && t >= -a.hist && t < T && c0 + c4 < a.Cin) {
-                v = *reinterpret_cast<const float4*>(xb + (int64_t)t * a.ldx + c0 + c4);
+                v = ld16f(xb + (int64_t)t * a.ldx + c0 + c4);
                 if (x2b) {
                     const float4 u = *reinterpret_cast<const float4*>(x2b + (int64_t)t * a.ldx2 + c0 + c4);
                     v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
@@ -436,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_h2_kernel(ConvGemmArgs a) {
             }
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < rows && t >= -a.hist && t < T && c0 + c4 < a.Cin) {
-                v = *reinterpret_cast<const float4*>(xb + (int64_t)t * a.ldx + c0 + c4);
+                v = ld16f(xb + (int64_t)t * a.ldx + c0 + c4);
                 if constexpr (PRO) {
                     if (x2b) {
                         const float4 u = *reinterpret_cast<const float4*>(x2b + (int64_t)t * a.ldx2 + c0 + c4);
@@ -596,7 +599,7 @@ __global__ __launch_bounds__(256, 2) void resunit_h2_kernel(ResUnitArgs a) {
             const int t = t0 - halo + r;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < rows && t >= -a.hist && t < T) {
-                v = *reinterpret_cast<const float4*>(yb + (int64_t)t * C + c0 + c4);
+                v = ld16f(yb + (int64_t)t * C + c0 + c4);
                 const float4 ea = *reinterpret_cast<const float4*>(a.ea1 + c0 + c4);
                 const float4 ib = *reinterpret_cast<const float4*>(a.ib1 + c0 + c4);
                 v.x = v.x + ib.x * snake_sin2(v.x * ea.x);
