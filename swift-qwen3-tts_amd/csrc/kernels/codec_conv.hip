@@ -385,9 +385,26 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_h2_kernel(ConvGemmArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int b = blockIdx.z;
-    const int n0 = blockIdx.x * BN;
-    const int t0 = blockIdx.y * BM;
+    // Workgroup -> tile. The dispatcher hands consecutive workgroup ids to the eight XCDs in turn (cdna_hip_programming.md T1),
+    // each with its own L2: with the N tiles of a position tile on consecutive ids every L2 fetched every input tile (the
+    // K = 7 convs read 6-10 GB for 0.6-3 GB of input, profiles/r03_codec_traffic.txt). Each XCD now takes a contiguous run of
+    // the (row, position tile, N tile) list, so the N tiles of a position tile run side by side on one L2: K = 7 convs 2-4 %
+    // faster, the decode 121.2 -> 119.2 ms. (Blocks of 8 position tiles x 8 N tiles per L2 -- weights shared eight ways as
+    // well -- measured no better: 121.6 ms; the transposed convs, 15-48 N tiles wide, are not bound by these fetches.)
+    // Bijective for any grid; placement is a speed matter only.
+    int b, n_tile, m_tile;
+    {
+        const uint32_t gx = gridDim.x, gy = gridDim.y, nwg = gx * gy * gridDim.z;
+        const uint32_t bid = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const uint32_t q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u;
+        const uint32_t swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        n_tile = int(swz % gx);
+        const uint32_t rest = swz / gx;
+        m_tile = int(rest % gy);
+        b = int(rest / gy);
+    }
+    const int n0 = n_tile * BN;
+    const int t0 = m_tile * BM;
     const int T = a.frames[b] * a.ppf;
     if (t0 >= T) return;
     const int rows = BM + halo;
