@@ -66,6 +66,7 @@ struct ResUnitArgs {
     const int32_t* frames;
     int ppf, Tmax, B, C, K, dil;
     int hist;             // as ConvGemmArgs::hist, for y
+    int wdb;              // set by launch_resunit: conv1's weight tiles double-buffered in LDS
 };
 bool resunit_supported(int C, int K, int dil);
 void launch_resunit(const ResUnitArgs& a, hipStream_t st);

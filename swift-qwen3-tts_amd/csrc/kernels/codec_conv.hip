@@ -545,67 +545,90 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_h2_kernel(ConvGemmArgs a) {
 
 // ---- fused residual unit -------------------------------------------------------------------------------
 // out = y + conv2(act2(conv1(act1(y)))) (DecoderResidualUnit, SpeechTokenizer.swift:430-437) for the narrow, long blocks
-// (C <= 96 channels at up to 384 k positions per row), which are HBM-bound when every conv is its own launch: six
+// (C <= 192 channels at up to 384 k positions per row), which are HBM-bound when every conv is its own launch: six
 // tensor passes per unit (act1 copy in, conv1 out, conv1 out back in, y in, y out, act1 copy out) become two.
 //  * act1 is applied while the raw tile of y (+ causal halo) is staged -- one N tile, so nothing is evaluated twice
 //    except the halo rows;
-//  * each wave owns 32 positions x ALL channels, so conv1's accumulators already hold conv2's whole reduction dimension:
+//  * each wave owns 16 PT positions x ALL channels, so conv1's accumulators already hold conv2's whole reduction dimension:
 //    an accumulator pair (tiles 2m, 2m+1) of a lane is exactly one MFMA B fragment (8 k values of its position) once
 //    conv2's weights are stored with the matching k order (model.cc attach_h2_perm) -- act2 and the two-plane split
 //    happen in registers and conv1's output never leaves the wave;
 //  * the residual is the raw y tile again (L2-warm), the sum goes to a second buffer because neighbouring workgroups
 //    still need the old halo rows.
-// Numerics and LDS layout as conv_gemm_h2_kernel: three fp16 products per block, weight tiles double-buffered;
-// (128 + halo + 2 C) rows x 160 B <= 60 KiB, two workgroups per CU.
-template <int CT2>
+// Numerics and LDS layout as conv_gemm_h2_kernel: three fp16 products per block, rows of 160 B; conv1's weight tiles are
+// double-buffered where two workgroups still fit a CU (launch_resunit).
+// Tile shape as template parameters: CT2 = C / 16 channel tiles, PT = 16-position tiles per wave (a workgroup covers 64 PT
+// positions; the first build of this kernel had PT = 2 for every width). Two instantiations matter:
+//   <6, 4>  C = 96, 256 positions per workgroup. With 32 positions per wave a step was 36 MFMAs per wave
+//           between barriers and every wave re-read all of the weight fragments: matrix pipe 27 % busy, waves parked on
+//           barriers / LDS 42 % of the time (profiles/r03_codec_pmc_summary.txt). 64 positions per wave double the work per
+//           barrier and per weight fragment and halve the halo's share of the staging.
+//   <12, 2> C = 192, 128 positions per workgroup: the unit that used to be two launches (k7 conv over two 96-wide N tiles,
+//           then an HBM-bound pointwise conv: 5.5 TB/s of tensor traffic, profiles/r03_codec_traffic.txt) -- the input is
+//           staged once instead of once per N tile and conv1's output never leaves the registers.
+// conv2 runs in passes over CG output-channel tiles (its accumulators would not fit beside conv1's otherwise); each pass
+// stages only its own rows of conv2's weights, so nothing is staged twice. Per accumulator the MFMA sequence -- products
+// smallest first, steps in order -- does not depend on the tile shape: same results bit for bit as the PT = 2 build.
+// Where the time goes (profiles/r03_codec_pmc_summary.txt, <6, 4>): 1728 MFMAs but also ~6300 other vector instructions per
+// wave (two SnakeBeta evaluations and two fp16 splits per element) -- the matrix pipe shares its issue port with them.
+template <int CT2, int PT>
 __global__ __launch_bounds__(256, 2) void resunit_h2_kernel(ResUnitArgs a) {
-    constexpr int C = 16 * CT2, NCH = CT2 / 2;
+    constexpr int C = 16 * CT2, NCH = CT2 / 2, PW = 16 * PT, BMU = 4 * PW;
+    constexpr int CG = CT2 >= 12 ? 4 : (CT2 == 6 ? 3 : CT2);  // channel tiles per fragment group / conv2 pass
+    constexpr int NG = CT2 / CG;
+    static_assert(CT2 % CG == 0 && CT2 % 2 == 0, "channel tiles must split into groups and into 32-channel chunks");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem3[];
     const int halo = (a.K - 1) * a.dil;
-    uint32_t* As = smem3;                        // [(BM + halo)][ROWH]
-    uint32_t* Ws = smem3 + (BM + halo) * ROWH;   // [2][C][ROWH]
+    uint32_t* As = smem3;                         // [(BMU + halo)][ROWH]
+    uint32_t* Ws = smem3 + (BMU + halo) * ROWH;   // [wdb ? 2 : 1][C][ROWH]
+    const bool wdb = a.wdb != 0;                  // conv1's weight tiles double-buffered (launch_resunit: when LDS allows)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z;
-    const int t0 = blockIdx.y * BM;
+    const int t0 = blockIdx.y * BMU;
     const int T = a.frames[b] * a.ppf;
     if (t0 >= T) return;
-    const int rows = BM + halo;
+    const int rows = BMU + halo;
     const size_t boff = (size_t)b * a.Tmax * C;
     const float* yb = a.y + boff;
-    const int S1 = NCH * a.K;  // conv1 steps; conv2 adds NCH more
+    const int S1 = NCH * a.K;  // conv1 steps; conv2 adds NG * NCH more (pass-major)
 
-    f32x4 acc1[2][CT2];
+    f32x4 acc1[PT][CT2];
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+    for (int p = 0; p < PT; ++p)
 #pragma unroll
         for (int c = 0; c < CT2; ++c) acc1[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     constexpr int WV = (C * 8 + 255) / 256;
     uint4 wreg[WV];
+    // step < S1: conv1's (tap, chunk) tile, C rows; else conv2's rows of pass h for chunk m, 16 CG rows
     auto load_w = [&](int step) {
         const uint4* src;
+        int items;
         if (step < S1) {
             const int chunk = step / a.K, tap = step % a.K;
             src = reinterpret_cast<const uint4*>(a.w1h + (size_t)(tap * NCH + chunk) * C * 64);
+            items = C * 8;
         } else {
-            src = reinterpret_cast<const uint4*>(a.w2ph + (size_t)(step - S1) * C * 64);
+            const int j = step - S1, h = j / NCH, m = j % NCH;
+            src = reinterpret_cast<const uint4*>(a.w2ph + ((size_t)m * C + h * CG * 16) * 64);
+            items = CG * 16 * 8;
         }
 #pragma unroll
         for (int i = 0; i < WV; ++i) {
             const int item = i * 256 + tid;
-            wreg[i] = item < C * 8 ? src[item] : make_uint4(0u, 0u, 0u, 0u);
+            wreg[i] = item < items ? src[item] : make_uint4(0u, 0u, 0u, 0u);
         }
     };
-    auto store_w = [&](int buf) {
+    auto store_w = [&](int buf, int items) {
 #pragma unroll
         for (int i = 0; i < WV; ++i) {
             const int item = i * 256 + tid;
-            if (item < C * 8) *reinterpret_cast<uint4*>(&Ws[(buf * C + (item >> 3)) * ROWH + (item & 7) * 4]) = wreg[i];
+            if (item < items) *reinterpret_cast<uint4*>(&Ws[(buf * C + (item >> 3)) * ROWH + (item & 7) * 4]) = wreg[i];
         }
     };
 
-    constexpr int AV = ((BM + MAX_HALO) * 8 + 255) / 256;
+    constexpr int AV = ((BMU + MAX_HALO) * 8 + 255) / 256;
     float4 areg[AV];
     auto load_a = [&](int chunk) {
         const int c0 = chunk * KC;
@@ -646,43 +669,49 @@ __global__ __launch_bounds__(256, 2) void resunit_h2_kernel(ResUnitArgs a) {
     load_a(0);
     int buf = 0;
     for (int chunk = 0; chunk < NCH; ++chunk) {
-        __syncthreads();
+        __syncthreads();  // the previous chunk's MFMAs are done with As (and, single-buffered, with Ws)
         store_a();
         if (chunk + 1 < NCH) load_a(chunk + 1);
         for (int tap = 0; tap < a.K; ++tap) {
             const int step = chunk * a.K + tap;
-            store_w(buf);
+            if (!wdb && tap > 0) __syncthreads();  // one weight buffer: the previous tap's reads
+            store_w(buf, C * 8);
             __syncthreads();
             load_w(step + 1);  // the step after conv1's last one is conv2's first
-            const uint32_t* arow = &As[(32 * wave + tap * a.dil + (lane & 15)) * ROWH + 4 * (lane >> 4)];
+            const uint32_t* arow = &As[(PW * wave + tap * a.dil + (lane & 15)) * ROWH + 4 * (lane >> 4)];
             const uint32_t* wrow = &Ws[(buf * C + (lane & 15)) * ROWH + 4 * (lane >> 4)];
-            uint4 xa[2][2], wa[2][CT2], wb[CT2];
+            uint4 xa[2][PT];
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
+            for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-                for (int p = 0; p < 2; ++p) xa[pl][p] = *reinterpret_cast<const uint4*>(arow + p * 16 * ROWH + pl * 16);
+                for (int p = 0; p < PT; ++p) xa[pl][p] = *reinterpret_cast<const uint4*>(arow + p * 16 * ROWH + pl * 16);
 #pragma unroll
-                for (int c = 0; c < CT2; ++c) wa[pl][c] = *reinterpret_cast<const uint4*>(wrow + c * 16 * ROWH + pl * 16);
+            for (int g = 0; g < NG; ++g) {
+                uint4 wa[2][CG], wb[CG];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                    for (int c = 0; c < CG; ++c) wa[pl][c] = *reinterpret_cast<const uint4*>(wrow + (g * CG + c) * 16 * ROWH + pl * 16);
+#pragma unroll
+                for (int c = 0; c < CG; ++c) wb[c] = f16x8_scale_m11(wa[0][c]);
+#pragma unroll
+                for (int p = 0; p < PT; ++p)
+#pragma unroll
+                    for (int c = 0; c < CG; ++c) acc1[p][g * CG + c] = mfma_f16(wb[c], xa[1][p], acc1[p][g * CG + c]);
+#pragma unroll
+                for (int p = 0; p < PT; ++p)
+#pragma unroll
+                    for (int c = 0; c < CG; ++c) acc1[p][g * CG + c] = mfma_f16(wa[1][c], xa[0][p], acc1[p][g * CG + c]);
+#pragma unroll
+                for (int p = 0; p < PT; ++p)
+#pragma unroll
+                    for (int c = 0; c < CG; ++c) acc1[p][g * CG + c] = mfma_f16(wa[0][c], xa[0][p], acc1[p][g * CG + c]);
             }
-#pragma unroll
-            for (int c = 0; c < CT2; ++c) wb[c] = f16x8_scale_m11(wa[0][c]);
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-#pragma unroll
-                for (int c = 0; c < CT2; ++c) acc1[p][c] = mfma_f16(wb[c], xa[1][p], acc1[p][c]);
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-#pragma unroll
-                for (int c = 0; c < CT2; ++c) acc1[p][c] = mfma_f16(wa[1][c], xa[0][p], acc1[p][c]);
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-#pragma unroll
-                for (int c = 0; c < CT2; ++c) acc1[p][c] = mfma_f16(wa[0][c], xa[0][p], acc1[p][c]);
-            buf ^= 1;
+            if (wdb) buf ^= 1;
         }
     }
 
-    // ---- 2^-s, + bias1, act2 in registers (lane: channels 16c + 4(lane >> 4) + j of its two position tiles) ----
+    // ---- 2^-s, + bias1, act2 in registers (lane: channels 16c + 4(lane >> 4) + j of its PT position tiles) ----
     const int q4 = 4 * (lane >> 4);
     int big = 0;
 #pragma unroll
@@ -692,19 +721,21 @@ __global__ __launch_bounds__(256, 2) void resunit_h2_kernel(ResUnitArgs a) {
         const float4 ea = *reinterpret_cast<const float4*>(a.ea2 + 16 * c + q4);
         const float e[4] = {ea.x, ea.y, ea.z, ea.w}, bb[4] = {bv.x, bv.y, bv.z, bv.w}, ss[4] = {sv.x, sv.y, sv.z, sv.w};
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
+        for (int p = 0; p < PT; ++p)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 acc1[p][c][j] = acc1[p][c][j] * ss[j] + bb[j];
                 big |= !(fabsf(acc1[p][c][j] * e[j]) < 1.0e6f);
             }
     }
-    // block-wide vote (also the barrier that retires conv1's reads of As): arguments beyond the polynomial's range are
-    // possible only in a diverged model; the whole workgroup then goes through the libm path, one tile at a time via LDS
+    // block-wide vote (also the barrier that retires conv1's reads of As and Ws): arguments beyond the polynomial's range
+    // are possible only in a diverged model; the whole workgroup then takes the libm path, one tile at a time via LDS
     if (__syncthreads_or(big)) {
+        // (the stash may run over As into Ws: nobody reads either between the vote and conv2's first store below, which
+        // every wave reaches only after its own stash traffic)
         float4* stash = reinterpret_cast<float4*>(As) + wave * (CT2 * 64);
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < PT; ++p) {
 #pragma unroll
             for (int c = 0; c < CT2; ++c) stash[c * 64 + lane] = make_float4(acc1[p][c][0], acc1[p][c][1], acc1[p][c][2], acc1[p][c][3]);
 #pragma unroll 1
@@ -724,6 +755,7 @@ __global__ __launch_bounds__(256, 2) void resunit_h2_kernel(ResUnitArgs a) {
                 acc1[p][c] = f32x4{v.x, v.y, v.z, v.w};
             }
         }
+        __syncthreads();  // the stash of a slow wave must not meet a fast wave's weight store
     } else {
 #pragma unroll
         for (int c = 0; c < CT2; ++c) {
@@ -731,109 +763,112 @@ __global__ __launch_bounds__(256, 2) void resunit_h2_kernel(ResUnitArgs a) {
             const float4 ib = *reinterpret_cast<const float4*>(a.ib2 + 16 * c + q4);
             const float e[4] = {ea.x, ea.y, ea.z, ea.w}, ii[4] = {ib.x, ib.y, ib.z, ib.w};
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
+            for (int p = 0; p < PT; ++p)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc1[p][c][j] = acc1[p][c][j] + ii[j] * snake_sin2_poly(acc1[p][c][j] * e[j]);
         }
     }
 
-    // ---- conv2: the B fragments come out of acc1 ----
-    f32x4 acc2[2][CT2];
+    // ---- conv2 in NG passes of CG output-channel tiles; the B fragments come out of acc1 ----
+    const uint32_t* wrow2 = &Ws[(lane & 15) * ROWH + 4 * (lane >> 4)];
+    float4* stash = reinterpret_cast<float4*>(As) + wave * (CG * 64);  // As is free since the vote; per-lane slots
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+    for (int h = 0; h < NG; ++h) {
+        f32x4 acc2[PT][CG];
 #pragma unroll
-        for (int c = 0; c < CT2; ++c) acc2[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < PT; ++p)
 #pragma unroll
-    for (int m = 0; m < NCH; ++m) {
-        store_w(buf);
-        __syncthreads();
-        if (m + 1 < NCH) load_w(S1 + m + 1);
-        const uint32_t* wrow = &Ws[(buf * C + (lane & 15)) * ROWH + 4 * (lane >> 4)];
-        uint4 xb[2][2], wa[2][CT2], wb[CT2];
+            for (int c = 0; c < CG; ++c) acc2[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const float4 v0 = make_float4(acc1[p][2 * m][0], acc1[p][2 * m][1], acc1[p][2 * m][2], acc1[p][2 * m][3]);
-            const float4 v1 = make_float4(acc1[p][2 * m + 1][0], acc1[p][2 * m + 1][1], acc1[p][2 * m + 1][2], acc1[p][2 * m + 1][3]);
-            uint2 h0, l0, h1, l1;
-            split_h2(v0, h0, l0);
-            split_h2(v1, h1, l1);
-            xb[0][p] = make_uint4(h0.x, h0.y, h1.x, h1.y);
-            xb[1][p] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        for (int m = 0; m < NCH; ++m) {
+            const int j = h * NCH + m;
+            if (j > 0) __syncthreads();  // the previous tile's reads of Ws (tile 0: the vote above)
+            store_w(0, CG * 16 * 8);
+            __syncthreads();
+            if (j + 1 < NG * NCH) load_w(S1 + j + 1);
+            uint4 xb[2][PT], wa[2][CG], wb[CG];
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                const float4 v0 = make_float4(acc1[p][2 * m][0], acc1[p][2 * m][1], acc1[p][2 * m][2], acc1[p][2 * m][3]);
+                const float4 v1 = make_float4(acc1[p][2 * m + 1][0], acc1[p][2 * m + 1][1], acc1[p][2 * m + 1][2], acc1[p][2 * m + 1][3]);
+                uint2 h0, l0, h1, l1;
+                split_h2(v0, h0, l0);
+                split_h2(v1, h1, l1);
+                xb[0][p] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                xb[1][p] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+            }
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int c = 0; c < CG; ++c) wa[pl][c] = *reinterpret_cast<const uint4*>(wrow2 + c * 16 * ROWH + pl * 16);
+#pragma unroll
+            for (int c = 0; c < CG; ++c) wb[c] = f16x8_scale_m11(wa[0][c]);
+#pragma unroll
+            for (int p = 0; p < PT; ++p)
+#pragma unroll
+                for (int c = 0; c < CG; ++c) acc2[p][c] = mfma_f16(wb[c], xb[1][p], acc2[p][c]);
+#pragma unroll
+            for (int p = 0; p < PT; ++p)
+#pragma unroll
+                for (int c = 0; c < CG; ++c) acc2[p][c] = mfma_f16(wa[1][c], xb[0][p], acc2[p][c]);
+#pragma unroll
+            for (int p = 0; p < PT; ++p)
+#pragma unroll
+                for (int c = 0; c < CG; ++c) acc2[p][c] = mfma_f16(wa[0][c], xb[0][p], acc2[p][c]);
+        }
+        // ---- this pass's channels: 2^-s, + bias2, + y -> out; optionally the next block's SnakeBeta of the sum -> out2 ----
+        // (every residual request before the first store: out and y could alias as far as the compiler knows)
+        float4 rvs[PT][CG], bv2[CG], sv2[CG];
+#pragma unroll
+        for (int c = 0; c < CG; ++c) {
+            const int n = 16 * (h * CG + c) + q4;
+            bv2[c] = a.b2 ? *reinterpret_cast<const float4*>(a.b2 + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            sv2[c] = *reinterpret_cast<const float4*>(a.wsc2 + n);
         }
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl)
+        for (int p = 0; p < PT; ++p) {
+            const int t = t0 + PW * wave + 16 * p + (lane & 15);
 #pragma unroll
-            for (int c = 0; c < CT2; ++c) wa[pl][c] = *reinterpret_cast<const uint4*>(wrow + c * 16 * ROWH + pl * 16);
-#pragma unroll
-        for (int c = 0; c < CT2; ++c) wb[c] = f16x8_scale_m11(wa[0][c]);
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-            for (int c = 0; c < CT2; ++c) acc2[p][c] = mfma_f16(wb[c], xb[1][p], acc2[p][c]);
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-            for (int c = 0; c < CT2; ++c) acc2[p][c] = mfma_f16(wa[1][c], xb[0][p], acc2[p][c]);
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-            for (int c = 0; c < CT2; ++c) acc2[p][c] = mfma_f16(wa[0][c], xb[0][p], acc2[p][c]);
-        buf ^= 1;
-    }
-
-    // ---- 2^-s, + bias2, + y -> out; optionally the next block's SnakeBeta of the sum -> out2 ----
-    float4 rvs[2][CT2], bv2[CT2], sv2[CT2];
-#pragma unroll
-    for (int c = 0; c < CT2; ++c) {
-        bv2[c] = a.b2 ? *reinterpret_cast<const float4*>(a.b2 + 16 * c + q4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        sv2[c] = *reinterpret_cast<const float4*>(a.wsc2 + 16 * c + q4);
-    }
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int t = t0 + 32 * wave + 16 * p + (lane & 15);
-#pragma unroll
-        for (int c = 0; c < CT2; ++c) {
-            rvs[p][c] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t < T) rvs[p][c] = *reinterpret_cast<const float4*>(yb + (size_t)t * C + 16 * c + q4);
+            for (int c = 0; c < CG; ++c) {
+                rvs[p][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (t < T) rvs[p][c] = *reinterpret_cast<const float4*>(yb + (size_t)t * C + 16 * (h * CG + c) + q4);
+            }
         }
-    }
-    __syncthreads();  // every wave is done with the weight tiles before As / Ws double as the stash below
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int t = t0 + 32 * wave + 16 * p + (lane & 15);
-        if (t >= T) continue;
+        for (int p = 0; p < PT; ++p) {
+            const int t = t0 + PW * wave + 16 * p + (lane & 15);
 #pragma unroll
-        for (int c = 0; c < CT2; ++c) {
-            const int n = 16 * c + q4;
-            const float4 rv = rvs[p][c], bv = bv2[c], sv = sv2[c];
-            float4 v = make_float4(acc2[p][c][0] * sv.x + rv.x, acc2[p][c][1] * sv.y + rv.y, acc2[p][c][2] * sv.z + rv.z,
-                                   acc2[p][c][3] * sv.w + rv.w);
-            if (a.b2)
-                v = make_float4((acc2[p][c][0] * sv.x + bv.x) + rv.x, (acc2[p][c][1] * sv.y + bv.y) + rv.y,
-                                (acc2[p][c][2] * sv.z + bv.z) + rv.z, (acc2[p][c][3] * sv.w + bv.w) + rv.w);
-            st16(a.out + boff + (size_t)t * C + n, v);
-            acc2[p][c] = f32x4{v.x, v.y, v.z, v.w};
+            for (int c = 0; c < CG; ++c) {
+                const int n = 16 * (h * CG + c) + q4;
+                const float4 rv = rvs[p][c], bv = bv2[c], sv = sv2[c];
+                float4 v = make_float4(acc2[p][c][0] * sv.x + rv.x, acc2[p][c][1] * sv.y + rv.y, acc2[p][c][2] * sv.z + rv.z,
+                                       acc2[p][c][3] * sv.w + rv.w);
+                if (a.b2)
+                    v = make_float4((acc2[p][c][0] * sv.x + bv.x) + rv.x, (acc2[p][c][1] * sv.y + bv.y) + rv.y,
+                                    (acc2[p][c][2] * sv.z + bv.z) + rv.z, (acc2[p][c][3] * sv.w + bv.w) + rv.w);
+                if (t < T) st16(a.out + boff + (size_t)t * C + n, v);
+                acc2[p][c] = f32x4{v.x, v.y, v.z, v.w};
+            }
         }
-    }
-    if (a.out2) {  // As is free since the vote; every lane uses its own stash slots
-        float4* stash = reinterpret_cast<float4*>(As) + wave * (CT2 * 64);
+        if (a.out2) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+            for (int p = 0; p < PT; ++p) {
 #pragma unroll
-            for (int c = 0; c < CT2; ++c) stash[c * 64 + lane] = make_float4(acc2[p][c][0], acc2[p][c][1], acc2[p][c][2], acc2[p][c][3]);
-            const int t = t0 + 32 * wave + 16 * p + (lane & 15);
-            if (t >= T) continue;
+                for (int c = 0; c < CG; ++c) stash[c * 64 + lane] = make_float4(acc2[p][c][0], acc2[p][c][1], acc2[p][c][2], acc2[p][c][3]);
+                const int t = t0 + PW * wave + 16 * p + (lane & 15);
+                if (t >= T) continue;
 #pragma unroll 1
-            for (int c = 0; c < CT2; ++c) {
-                const int n = 16 * c + q4;
-                float4 v = stash[c * 64 + lane];
-                const float4 ea = *reinterpret_cast<const float4*>(a.post_ea + n);
-                const float4 ib = *reinterpret_cast<const float4*>(a.post_ib + n);
-                v.x = v.x + ib.x * snake_sin2(v.x * ea.x);
-                v.y = v.y + ib.y * snake_sin2(v.y * ea.y);
-                v.z = v.z + ib.z * snake_sin2(v.z * ea.z);
-                v.w = v.w + ib.w * snake_sin2(v.w * ea.w);
-                st16(a.out2 + boff + (size_t)t * C + n, v);
+                for (int c = 0; c < CG; ++c) {
+                    const int n = 16 * (h * CG + c) + q4;
+                    float4 v = stash[c * 64 + lane];
+                    const float4 ea = *reinterpret_cast<const float4*>(a.post_ea + n);
+                    const float4 ib = *reinterpret_cast<const float4*>(a.post_ib + n);
+                    v.x = v.x + ib.x * snake_sin2(v.x * ea.x);
+                    v.y = v.y + ib.y * snake_sin2(v.y * ea.y);
+                    v.z = v.z + ib.z * snake_sin2(v.z * ea.z);
+                    v.w = v.w + ib.w * snake_sin2(v.w * ea.w);
+                    st16(a.out2 + boff + (size_t)t * C + n, v);
+                }
             }
         }
     }
@@ -841,26 +876,33 @@ __global__ __launch_bounds__(256, 2) void resunit_h2_kernel(ResUnitArgs a) {
 
 }  // namespace
 
-bool resunit_supported(int C, int K, int dil) { return (C == 32 || C == 64 || C == 96) && K >= 1 && (K - 1) * dil <= MAX_HALO; }
+bool resunit_supported(int C, int K, int dil) {
+    return (C == 32 || C == 64 || C == 96 || C == 192) && K >= 1 && (K - 1) * dil <= MAX_HALO;
+}
 
-void launch_resunit(const ResUnitArgs& a, hipStream_t st) {
+void launch_resunit(const ResUnitArgs& a0, hipStream_t st) {
+    ResUnitArgs a = a0;
     Q3_CHECK(resunit_supported(a.C, a.K, a.dil) && a.out != a.y, 3, "resunit: unsupported geometry");
-    const int mt = (a.Tmax + BM - 1) / BM;
-    if (mt <= 0 || a.B <= 0) return;
+    Q3_CHECK(a.w1h && a.w2ph && a.wsc1 && a.wsc2, 3, "resunit: incomplete fp16x2 weights");
+    if (a.Tmax <= 0 || a.B <= 0) return;
     static bool attr_set = false;
     if (!attr_set) {
-        void (*ks[3])(ResUnitArgs) = {&resunit_h2_kernel<2>, &resunit_h2_kernel<4>, &resunit_h2_kernel<6>};
+        void (*ks[4])(ResUnitArgs) = {&resunit_h2_kernel<2, 2>, &resunit_h2_kernel<4, 2>, &resunit_h2_kernel<6, 4>, &resunit_h2_kernel<12, 2>};
         for (auto k : ks)
             Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         attr_set = true;
     }
-    dim3 grid(1, mt, a.B), block(256);
-    Q3_CHECK(a.w1h && a.w2ph && a.wsc1 && a.wsc2, 3, "resunit: incomplete fp16x2 weights");
-    const size_t smemh = size_t(BM + (a.K - 1) * a.dil + 2 * a.C) * ROWH * sizeof(uint32_t);
+    const int bmu = a.C == 96 ? 256 : 128;  // positions per workgroup (64 PT)
+    const int rows = bmu + (a.K - 1) * a.dil;
+    // conv1's weight tiles are double-buffered (one barrier per tap instead of two) where two workgroups still share a CU
+    a.wdb = size_t(rows + 2 * a.C) * ROWH * sizeof(uint32_t) <= 80 * 1024 ? 1 : 0;
+    const size_t smemh = size_t(rows + (a.wdb ? 2 : 1) * a.C) * ROWH * sizeof(uint32_t);
+    dim3 grid(1, (a.Tmax + bmu - 1) / bmu, a.B), block(256);
     switch (a.C) {
-        case 32: hipLaunchKernelGGL(resunit_h2_kernel<2>, grid, block, smemh, st, a); break;
-        case 64: hipLaunchKernelGGL(resunit_h2_kernel<4>, grid, block, smemh, st, a); break;
-        default: hipLaunchKernelGGL(resunit_h2_kernel<6>, grid, block, smemh, st, a); break;
+        case 32: hipLaunchKernelGGL((resunit_h2_kernel<2, 2>), grid, block, smemh, st, a); break;
+        case 64: hipLaunchKernelGGL((resunit_h2_kernel<4, 2>), grid, block, smemh, st, a); break;
+        case 96: hipLaunchKernelGGL((resunit_h2_kernel<6, 4>), grid, block, smemh, st, a); break;
+        default: hipLaunchKernelGGL((resunit_h2_kernel<12, 2>), grid, block, smemh, st, a); break;
     }
 }
 

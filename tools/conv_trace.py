@@ -31,7 +31,7 @@ for i, s in enumerate((8, 5, 4, 3)):
     ppf *= s
     C //= 2
     for j in range(3):
-        if C <= 96:
+        if C <= 96 or C == 192:
             seq += [(f"b{i}.res{j}.fused", C, C, 8, ppf)]
         else:
             seq += [(f"b{i}.res{j}.conv1", C, C, 7, ppf), (f"b{i}.res{j}.conv2", C, C, 1, ppf)]
