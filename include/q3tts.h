@@ -308,6 +308,10 @@ q3tts_status q3tts_debug_linear(q3tts_model* m, const uint16_t* x, const uint16_
 q3tts_status q3tts_debug_codec_stage(q3tts_model* m, const int32_t* codes, int32_t n_frames,
                                      const char* stage, float* out, int64_t cap_floats, int32_t* T, int32_t* C);
 
+/* Activation scratch the codec decoder may use per pass (default 24 GB; 0 restores it): a small value forces the paths that
+ * take a large batch through in groups of rows. Process-wide. */
+void q3tts_debug_set_codec_scratch(uint64_t bytes);
+
 /* Voice-clone front end with intermediate activations for one waveform. Codec encoder stages
  * (SpeechTokenizerEncoder.swift:1031-1056): "init_conv","layer0".."layer3","seanet","transformer","downsample",
  * "rvq_first_in","rvq_rest_in"; speaker encoder stages (SpeakerEncoder.swift:364-394): "mel","h0".."h3","mfa",

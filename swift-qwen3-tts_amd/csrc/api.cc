@@ -5,6 +5,7 @@
 #include <cstring>
 #include <vector>
 
+#include "codec.h"
 #include "engine.h"
 #include "tokenizer.h"
 
@@ -347,6 +348,8 @@ q3tts_status q3tts_codec_decode_streamed(q3tts_model* m, const int32_t* codes, c
         m->eng->lane0().codec_decode_streamed(codes, n_frames, batch, max_frames, chunk_frames, window, lookahead, pcm);
     });
 }
+
+void q3tts_debug_set_codec_scratch(uint64_t bytes) { q3::CodecRunner::set_scratch_budget(size_t(bytes)); }
 
 q3tts_status q3tts_debug_codec_stage(q3tts_model* m, const int32_t* codes, int32_t n_frames, const char* stage,
                                      float* out, int64_t cap_floats, int32_t* T, int32_t* C) {

@@ -11,8 +11,9 @@
 namespace q3 {
 
 namespace {
-constexpr size_t kScratchBudget = size_t(24) << 30;  // activation scratch per chunk of rows (of 288 GB HBM)
+size_t kScratchBudget = size_t(24) << 30;  // activation scratch per group of rows (of 288 GB HBM); tests lower it
 }
+void CodecRunner::set_scratch_budget(size_t bytes) { kScratchBudget = bytes ? bytes : (size_t(24) << 30); }
 
 CodecRunner::CodecRunner(const Model& m, hipStream_t st, bool fp32_convs) : m_(m), st_(st) {
     up_ = m.cfg.codec.total_upsample();
@@ -311,9 +312,12 @@ int CodecRunner::decode_chunked(const int32_t* codes_dev, int code_stride_frames
     front_pf = std::max(front_pf, size_t(3) * dc.num_attention_heads * 64);
     front_pf = std::max(front_pf, size_t(2) * dc.intermediate_size);
     front_pf = std::max(front_pf, size_t(dc.latent_dim));
-    const size_t big = align_up(std::max(size_t(B) * Fmax * front_pf, size_t(B) * Tc * per_frame) * sizeof(float), 256);
-    const size_t pcm_bytes = align_up(size_t(B) * Tc * up_ * sizeof(float), 256);
-    Q3_CHECK(4 * big <= kScratchBudget, 3, "Invalid input: batch too large for a chunked decode");
+    // rows per pass: like decode(), a batch whose activations exceed the scratch budget goes through in groups of rows (the
+    // codes of a finished AR loop must never be lost to a scratch limit); x_all always holds every row
+    const size_t per_row = std::max(size_t(Fmax) * front_pf, size_t(Tc) * per_frame) * sizeof(float);
+    const int G = int(std::min<size_t>(size_t(B), std::max<size_t>(1, kScratchBudget / (4 * per_row))));
+    const size_t big = align_up(size_t(G) * per_row, 256);
+    const size_t pcm_bytes = align_up(size_t(G) * Tc * up_ * sizeof(float), 256);
     ensure(pcm_bytes + front_bytes + 4 * big);
     float* pcm = reinterpret_cast<float*>(buf_);
     float* x_all = reinterpret_cast<float*>(buf_ + pcm_bytes);
@@ -333,20 +337,25 @@ int CodecRunner::decode_chunked(const int32_t* codes_dev, int code_stride_frames
         chunk_done.push_back(e);
     }
     const std::string none;
-    Pass ps{};
-    ps.nb = B; ps.fr = lens_dev_; ps.stage = &none;
-    run_front(ps, codes_dev, code_stride_frames, Fmax, bufs);
-    Q3_HIP(hipMemcpyAsync(x_all, bufs[0], size_t(B) * Fmax * dc.latent_dim * sizeof(float), hipMemcpyDeviceToDevice, st_));
     const size_t row_in = size_t(dc.latent_dim) * sizeof(float);
+    for (int r0 = 0; r0 < B; r0 += G) {
+        Pass ps{};
+        ps.nb = std::min(G, B - r0); ps.row0 = r0; ps.fr = lens_dev_ + r0; ps.stage = &none;
+        run_front(ps, codes_dev + size_t(r0) * code_stride_frames * 16, code_stride_frames, Fmax, bufs);
+        Q3_HIP(hipMemcpyAsync(x_all + size_t(r0) * Fmax * dc.latent_dim, bufs[0], size_t(ps.nb) * Fmax * row_in, hipMemcpyDeviceToDevice, st_));
+    }
     for (int k = 0; k < n_chunks; ++k) {
         const int f0 = k * chunk_frames, f1 = std::min(Fmax, f0 + chunk_frames), h0 = std::max(0, f0 - H), T = f1 - h0;
-        ps.fr = lens_dev_ + size_t(1 + k) * B;
-        Q3_HIP(hipMemcpy2DAsync(bufs[0], size_t(T) * row_in, x_all + size_t(h0) * dc.latent_dim, size_t(Fmax) * row_in, size_t(T) * row_in,
-                                size_t(B), hipMemcpyDeviceToDevice, st_));
-        run_tail(ps, T, bufs, pcm);
-        Q3_HIP(hipMemcpy2DAsync(pcm_host + size_t(f0) * up_, size_t(Fmax) * up_ * sizeof(float), pcm + size_t(f0 - h0) * up_,
-                                size_t(T) * up_ * sizeof(float), size_t(f1 - f0) * up_ * sizeof(float), size_t(B),
-                                hipMemcpyDeviceToHost, st_));
+        for (int r0 = 0; r0 < B; r0 += G) {
+            Pass ps{};
+            ps.nb = std::min(G, B - r0); ps.row0 = r0; ps.fr = lens_dev_ + size_t(1 + k) * B + r0; ps.stage = &none;
+            Q3_HIP(hipMemcpy2DAsync(bufs[0], size_t(T) * row_in, x_all + (size_t(r0) * Fmax + h0) * dc.latent_dim, size_t(Fmax) * row_in,
+                                    size_t(T) * row_in, size_t(ps.nb), hipMemcpyDeviceToDevice, st_));
+            run_tail(ps, T, bufs, pcm);
+            Q3_HIP(hipMemcpy2DAsync(pcm_host + (size_t(r0) * Fmax + f0) * up_, size_t(Fmax) * up_ * sizeof(float), pcm + size_t(f0 - h0) * up_,
+                                    size_t(T) * up_ * sizeof(float), size_t(f1 - f0) * up_ * sizeof(float), size_t(ps.nb),
+                                    hipMemcpyDeviceToHost, st_));
+        }
         Q3_HIP(hipEventRecord(chunk_done[size_t(k)], st_));
     }
     if (nonfinite_host) Q3_HIP(hipMemcpyAsync(nonfinite_host, nf_dev_, size_t(B) * 4, hipMemcpyDeviceToHost, st_));

@@ -29,6 +29,7 @@ class CodecRunner {
     int decode_chunked(const int32_t* codes_dev, int code_stride_frames, const std::vector<int>& frames, int chunk_frames,
                        float* pcm_host, std::vector<hipEvent_t>& chunk_done, int32_t* nonfinite_host = nullptr);
     int tail_context_frames() const;
+    static void set_scratch_budget(size_t bytes);  // test hook: forces the row-group paths of decode / decode_chunked (0: default)
 
     // ---- streamed decode (row f1: audio while tokens are still being generated) -------------------------------------
     // The causal tail keeps its own state between chunks: every tensor a causal conv reads lives in a persistent buffer

@@ -106,6 +106,8 @@ def lib() -> C.CDLL:
     L.q3tts_result_free.restype = None
     L.q3tts_codec_decode.argtypes = [vp, i32p, i32p, C.c_int32, C.c_int32, f32p, C.POINTER(C.c_int64)]
     L.q3tts_codec_decode_streamed.argtypes = [vp, i32p, i32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, f32p]
+    L.q3tts_debug_set_codec_scratch.argtypes = [C.c_uint64]
+    L.q3tts_debug_set_codec_scratch.restype = None
     L.q3tts_last_timing.argtypes = [vp, C.POINTER(Timing)]
     L.q3tts_codec_encode.argtypes = [vp, f32p, C.c_int64, i32p, C.c_int32, i32p]
     L.q3tts_codec_encoded_frames.argtypes = [vp, C.c_int64]

@@ -210,3 +210,26 @@ def test_audio_leaves_before_the_last_token(ckpt_dirs):
         assert 0 < tm.first_audio_ms < tm.prefill_ms + tm.decode_ms, (tm.first_audio_ms, tm.decode_ms)
     finally:
         m.close()
+
+
+def test_row_groups_when_the_scratch_is_short(ckpt_dirs):
+    """A batch whose activations exceed the decoder's scratch budget goes through in groups of rows -- one-shot and chunked
+    alike -- instead of failing after the AR loop has already produced the codes; the samples do not change."""
+    from qwen3tts import Qwen3TTSModel, _lib
+    m = Qwen3TTSModel.from_pretrained(ckpt_dirs["tiny-b"], max_batch=4, max_frames=96, max_prompt=96)
+    try:
+        reqs = [_req(row=i, n_text=5 + i) for i in range(4)]
+        kw = dict(temperature=0.9, top_k=40, seed=5, force_frames=30)
+        want = m.generate_batch(reqs, **kw)
+        codes = np.stack([r.codes for r in want])
+        _lib.lib().q3tts_debug_set_codec_scratch(1 << 20)   # far below one row's activations: one row per group
+        try:
+            got = m.generate_batch(reqs, audio_chunk_frames=8, on_event=lambda *a: None, **kw)
+            pcm, _ = m.codec_decode(codes)
+        finally:
+            _lib.lib().q3tts_debug_set_codec_scratch(0)
+        for i in range(4):
+            assert (got[i].codes == want[i].codes).all() and (got[i].audio == want[i].audio).all()
+            assert (pcm[i] == want[i].audio).all()
+    finally:
+        m.close()
