@@ -163,6 +163,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (profiling)")
     ap.add_argument("--streams", type=int, default=0, help="lanes per GPU (0 = engine default)")
     ap.add_argument("--no-pipeline", action="store_true", help="one batch at a time (no codec / AR overlap between steps)")
+    ap.add_argument("--no-streaming", action="store_true", help="skip the streamed-audio batch behind the timed region (profiling runs)")
     ap.add_argument("--codec-cus", type=int, default=0, help="q3tts_load_opts.codec_overlap_cus (0 = engine default, -1 = no mask)")
     args = ap.parse_args()
 
@@ -353,7 +354,7 @@ def main():
                            "narrow_stages_hbm": codec_hbm, "hbm_peak_gbs": HBM_PEAK_GBS,
                            "ms": codec_solo_ms, "measured": "one batch alone (last warm-up step)" if solo else "overlapped steps"},
     }
-    if world == 1 and not clone:
+    if world == 1 and not clone and not args.no_streaming:
         # row f1, outside the timed region: one batch with the waveform streamed while the tokens are generated (16-frame
         # chunks, 32 frames of left context, 4 of look-ahead) -- when does the first audio reach the host?
         sk = dict(gen_kw, audio_chunk_frames=16, audio_window_frames=32, audio_lookahead_frames=4)

@@ -121,6 +121,11 @@ typedef struct {
     int64_t n_ref_samples;
     const int32_t* ref_text_ids;
     int32_t n_ref_text_ids;
+    int32_t route; /* 0: generate() -- the prompt builder is chosen by tts_model_type and its requirements are enforced
+                      (Qwen3.swift:1302-1372). 1: generateVoiceDesign called directly (:587-597): no speaker, instruct optional,
+                      whatever the checkpoint's type. 2: generateCustomVoice called directly (:783-794): the speaker is
+                      required and validated against talker_config.spk_id (:803-811), instruct optional. Ignored for
+                      voice-clone requests (ref_audio != NULL) */
 } q3tts_request;
 
 /* Defaults as generate(): 0.9 / 50 / 1.0 / 1.05 (Qwen3.swift:1296-1299). */

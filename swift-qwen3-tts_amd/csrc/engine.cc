@@ -437,13 +437,11 @@ void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
         stamp(2);
         enqueue_layers(m_->cp, cp_, B, cp_kpool_, cp_vpool_, cp_kv_layer_stride_, cp_block_table_, 1, cp_len_, nullptr, ss_count, 0, 2,
                        nullptr, 0);
-        launch_advance_len(cp_len_, nullptr, B, st_);
-        stamp(3);
+        stamp(3);  // (no launch for cp_len_: the predictor's attention takes its cache length from the pass index, fixed_len)
     } else {
         launch_sampler(sa, st_);
         // code predictor, step 0 = [hidden, embed(code0)] run as two positions
         enqueue_cp_pass(B, true, -1, 0);
-        launch_advance_len(cp_len_, nullptr, B, st_);
         if (!m_->has_cp_proj) {  // second position: move the staged embedding (and its sum of squares) into place
             launch_copy_rows(cp_x2_, 0, cp_.h, 0, 1, Mp_ * H, st_);
             launch_copy_rows(reinterpret_cast<const uint16_t*>(cp_ss2_), 0, reinterpret_cast<uint16_t*>(cp_.ss_a), 0, 1, Mp_ * 2, st_);
@@ -519,6 +517,7 @@ ResolvedRequest Engine::resolve(const q3tts_request& r, const q3tts_sampling& sp
     const TalkerConfig& t = cfg.talker;
     ResolvedRequest o;
     Q3_CHECK(r.text_ids && r.n_text_ids >= 4, 3, "Invalid input: text_ids must hold the chat-template tokens");
+    Q3_CHECK(r.route >= 0 && r.route <= 2, 3, "Invalid input: unknown q3tts_request.route");
     o.text_ids.assign(r.text_ids, r.text_ids + r.n_text_ids);
     const bool have_instruct = r.instruct_ids && r.n_instruct_ids > 0;
     const std::string type = cfg.tts_model_type;
@@ -554,7 +553,13 @@ ResolvedRequest Engine::resolve(const q3tts_request& r, const q3tts_sampling& sp
         for (int id : o.ref_text_ids) Q3_CHECK(id >= 0 && id < t.text_vocab_size, 3, "Invalid input: reference text token id out of range");
         return o;
     }
-    if (type == "custom_voice" || type == "base") {
+    if (r.route == 1) {         // generateVoiceDesign(text:language:instruct:...) on any checkpoint (Qwen3.swift:587-620)
+        use_instruct = true;
+    } else if (r.route == 2) {  // generateCustomVoice(text:speaker:language:instruct:...) on any checkpoint (:783-811)
+        Q3_CHECK(r.speaker != nullptr, 3, "Invalid input: generateCustomVoice requires 'speaker'");
+        use_speaker = true;
+        use_instruct = true;
+    } else if (type == "custom_voice" || type == "base") {
         const char* nm = type == "custom_voice" ? "CustomVoice" : "Base";
         Q3_CHECK(r.speaker != nullptr, 3,
                  std::string("Invalid input: ") + nm + " model requires 'speaker' (e.g., 'Vivian', 'Ryan'). Available speakers: " + speaker_list());

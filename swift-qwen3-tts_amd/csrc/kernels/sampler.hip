@@ -202,6 +202,9 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(SamplerArgs a) {
             a.logits_dump[((size_t)b * a.forced_frames + frame) * a.dump_ld + a.dump_off + i] = lrow[i];
 
     // ---- 1+2: suppress, repetition penalty ----
+    // the LDS copy of the row is read by the EOS save / restore (talker) and by top-p only: the predictor's draws skip it
+    const bool use_top_p = sp.top_p > 0.f && sp.top_p < 1.0f;
+    const bool need_vals = TALKER || use_top_p;
     const float pen = rbf(sp.rep_penalty);
     const bool use_pen = want_seen && sp.rep_penalty != 1.0f;
     float l[kElems];
@@ -218,9 +221,9 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(SamplerArgs a) {
             }
         }
         l[k] = v;
-        vals[k * kThreads + tid] = v;
+        if (need_vals) vals[k * kThreads + tid] = v;
     }
-    __syncthreads();
+    __syncthreads();  // also orders the zeroed histograms / n_surv before the atomics below
 
     int tok;
     if (sp.temperature <= 0.f) {
@@ -312,12 +315,14 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(SamplerArgs a) {
                     base += total;
                 }
             }
+            if (use_top_p) {
 #pragma unroll
-            for (int k = 0; k < kElems; ++k) vals[k * kThreads + tid] = l[k];
-            __syncthreads();
+                for (int k = 0; k < kElems; ++k) vals[k * kThreads + tid] = l[k];
+                __syncthreads();
+            }
         }
         // ---- 6: top-p (rare path): ascending sort, sequential cumulative sum like the oracle ----
-        if (sp.top_p > 0.f && sp.top_p < 1.0f) {
+        if (use_top_p) {
 #pragma unroll
             for (int k = 0; k < kElems; ++k) {
                 const int i = k * kThreads + tid;

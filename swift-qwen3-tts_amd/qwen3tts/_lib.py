@@ -36,7 +36,7 @@ class Request(C.Structure):
                 ("n_instruct_ids", C.c_int32), ("target_token_count", C.c_int32), ("speaker", C.c_char_p),
                 ("language", C.c_char_p), ("max_tokens", C.c_int32),
                 ("ref_audio", f32p), ("n_ref_samples", C.c_int64), ("ref_text_ids", i32p),
-                ("n_ref_text_ids", C.c_int32)]
+                ("n_ref_text_ids", C.c_int32), ("route", C.c_int32)]
 
 
 class Sampling(C.Structure):

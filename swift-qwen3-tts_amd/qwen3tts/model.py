@@ -58,6 +58,8 @@ class GenerationRequest:
     # "<|im_start|>assistant\n{referenceText}<|im_end|>\n"
     ref_audio: Optional[np.ndarray] = None
     ref_text_ids: Optional[Sequence[int]] = None
+    # 0: generate() (routed by tts_model_type); 1 / 2: generateVoiceDesign / generateCustomVoice called directly (q3tts.h)
+    route: int = 0
 
 
 @dataclass
@@ -194,6 +196,7 @@ class Qwen3TTSModel:
             arr[i].speaker = r.speaker.encode() if r.speaker is not None else None
             arr[i].language = (r.language or "auto").encode()
             arr[i].max_tokens = int(r.max_tokens)
+            arr[i].route = int(getattr(r, "route", 0))
             if r.ref_audio is not None:
                 ra = np.ascontiguousarray(np.asarray(r.ref_audio, np.float32).reshape(-1))
                 rt = np.ascontiguousarray(r.ref_text_ids if r.ref_text_ids is not None else [], np.int32)
@@ -331,6 +334,7 @@ class Qwen3TTSModel:
         """generateVoiceDesign(text:language:instruct:...:onToken:) (Qwen3.swift:587-597); on_token sees every first-codebook
         id as it is generated (:698)."""
         req = self._request_from_text(text, None, instruct, language, max_tokens, text_ids, instruct_ids, target_token_count)
+        req.route = 1  # the named prompt builder whatever the checkpoint's type, as the reference's direct call
         return self._one(req, temperature, top_k, top_p, repetition_penalty, seed, on_token)
 
     def generate_custom_voice(self, text: Optional[str] = None, speaker: str = "", language: str = "auto",
@@ -340,6 +344,7 @@ class Qwen3TTSModel:
                               instruct_ids=None, target_token_count=None) -> np.ndarray:
         """generateCustomVoice(text:speaker:language:instruct:...:onToken:) (Qwen3.swift:783-794)."""
         req = self._request_from_text(text, speaker, instruct, language, max_tokens, text_ids, instruct_ids, target_token_count)
+        req.route = 2
         return self._one(req, temperature, top_k, top_p, repetition_penalty, seed, on_token)
 
     def _one(self, req, temperature, top_k, top_p, repetition_penalty, seed, on_token) -> np.ndarray:

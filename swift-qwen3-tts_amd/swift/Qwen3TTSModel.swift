@@ -101,13 +101,13 @@ public final class Qwen3TTSModel {
     }
 
     /// generateVoiceDesign(text:language:instruct:...:onToken:) -- Qwen3.swift:587-597. `onToken` receives every first-codebook
-    /// id as it is generated (:698), EOS excluded. (The engine routes by tts_model_type like generate(); a direct call on a
-    /// checkpoint of another type is rejected there instead of running the VoiceDesign prompt.)
+    /// id as it is generated (:698), EOS excluded. `route: 1` asks the engine for this prompt builder whatever the checkpoint's
+    /// tts_model_type, as the reference's direct call does.
     public func generateVoiceDesign(text: String, language: String = "auto", instruct: String? = nil, temperature: Float = 0.9,
                                     topK: Int = 50, topP: Float = 1.0, repetitionPenalty: Float = 1.05, maxTokens: Int = 2048,
                                     seed: UInt64 = 0, onToken: ((Int) -> Void)? = nil) throws -> [Float] {
         try run(text: text, speaker: nil, instruct: instruct, language: language, temperature: temperature, topK: topK,
-                topP: topP, repetitionPenalty: repetitionPenalty, maxTokens: maxTokens, seed: seed,
+                topP: topP, repetitionPenalty: repetitionPenalty, maxTokens: maxTokens, seed: seed, route: 1,
                 onEvent: onToken.map { cb in { ev in if case .token(let t) = ev { cb(t) } } })
     }
 
@@ -117,7 +117,7 @@ public final class Qwen3TTSModel {
                                     temperature: Float = 0.9, topK: Int = 50, topP: Float = 1.0, repetitionPenalty: Float = 1.05,
                                     maxTokens: Int = 2048, seed: UInt64 = 0, onToken: ((Int) -> Void)? = nil) throws -> [Float] {
         try run(text: text, speaker: speaker, instruct: instruct, language: language, temperature: temperature, topK: topK,
-                topP: topP, repetitionPenalty: repetitionPenalty, maxTokens: maxTokens, seed: seed,
+                topP: topP, repetitionPenalty: repetitionPenalty, maxTokens: maxTokens, seed: seed, route: 2,
                 onEvent: onToken.map { cb in { ev in if case .token(let t) = ev { cb(t) } } })
     }
 
@@ -161,7 +161,7 @@ public final class Qwen3TTSModel {
     }
 
     private func run(text: String, speaker: String?, instruct: String?, language: String, temperature: Float, topK: Int,
-                     topP: Float, repetitionPenalty: Float, maxTokens: Int, seed: UInt64,
+                     topP: Float, repetitionPenalty: Float, maxTokens: Int, seed: UInt64, route: Int32 = 0,
                      referenceAudio: [Float] = [], refTextIds: [Int32] = [],
                      onEvent: ((Qwen3TTSGeneration) -> Void)?) throws -> [Float] {
         guard let tokenizer else { throw AudioGenerationError.modelNotInitialized("Model not initialized: Tokenizer not loaded") }
@@ -191,7 +191,8 @@ public final class Qwen3TTSModel {
                                                         instruct_ids: ip.count > 0 ? ip.baseAddress : nil, n_instruct_ids: Int32(ip.count),
                                                         target_token_count: targetCount, speaker: sp, language: lp, max_tokens: Int32(maxTokens),
                                                         ref_audio: ra.count > 0 ? ra.baseAddress : nil, n_ref_samples: Int64(ra.count),
-                                                        ref_text_ids: rt.count > 0 ? rt.baseAddress : nil, n_ref_text_ids: Int32(rt.count))
+                                                        ref_text_ids: rt.count > 0 ? rt.baseAddress : nil, n_ref_text_ids: Int32(rt.count),
+                                                        route: route)
                                 return q3tts_generate(handle, &req, 1, &sampling, onEvent == nil ? nil : eventTrampoline, box.toOpaque(), &result)
                             }
                         }

@@ -124,6 +124,38 @@ def test_prompt_assembly_bit_exact(engines, oracles, name, variant):
     assert (ie != oie).mean() < 0.02
 
 
+def test_direct_voice_design_and_custom_voice_routes(engines, oracles):
+    """generateVoiceDesign / generateCustomVoice called DIRECTLY (Qwen3.swift:587-597, 783-794) run their own prompt builder
+    whatever the checkpoint's tts_model_type; generate() routes by the type and enforces its requirements (:1302-1372).
+    q3tts_request.route selects which; the tiny checkpoints are custom_voice models."""
+    from qwen3tts import Qwen3TTSError
+    m, om = engines["tiny-a"], oracles["tiny-a"]
+    # generate(): a CustomVoice model wants a speaker
+    r = greq(n_instruct=4, speaker=None)
+    with pytest.raises(Qwen3TTSError) as e:
+        m.debug_prepare_inputs(r)
+    assert e.value.status == 3 and "CustomVoice model requires 'speaker'" in str(e.value)
+    # generateVoiceDesign directly on the same checkpoint: no speaker row, instruct in front -- the oracle's builder follows the request
+    r.route = 1
+    ie, tr, pad = m.debug_prepare_inputs(r)
+    oie, otr, opad = om.prepare_generation_inputs(oreq(n_instruct=4, speaker=None))
+    assert ie.shape == oie.shape and tr.shape == otr.shape
+    for a, b in ((ie, oie), (tr, otr), (pad, opad[0])):
+        fa, fb = bf16_to_f32(a), bf16_to_f32(b)
+        assert (np.abs(fa - fb) <= 2 * ULP * np.maximum(np.abs(fb), 2.0 ** -8)).all()
+    # generateCustomVoice directly: the speaker is validated with the reference's message (:803-811); a known one == generate()
+    bad = greq(speaker="nobody")
+    bad.route = 2
+    with pytest.raises(Qwen3TTSError) as e:
+        m.debug_prepare_inputs(bad)
+    assert e.value.status == 3 and "Speaker 'nobody' not found. Available speakers:" in str(e.value)
+    good = greq(n_instruct=3)
+    a0 = m.debug_prepare_inputs(good)
+    good.route = 2
+    a2 = m.debug_prepare_inputs(good)
+    assert all((x == y).all() for x, y in zip(a0, a2))
+
+
 # ---------------------------------------------------------------------------------------------
 # AR loop: teacher-forced logits, greedy consistency, batching contract
 # ---------------------------------------------------------------------------------------------
