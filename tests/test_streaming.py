@@ -233,3 +233,35 @@ def test_row_groups_when_the_scratch_is_short(ckpt_dirs):
             assert (pcm[i] == want[i].audio).all()
     finally:
         m.close()
+
+
+def test_streamed_rows_are_independent_and_ragged(ckpt_dirs):
+    """Rows that stop at different frames while the stream is running: every row's streamed audio equals the streamed decode of
+    ITS OWN final codes alone (a chunk's window only ever covers frames of the same row), rows that are already final do not
+    hold the others back, and a streamed job can be followed by an ordinary pipelined one on the same handle."""
+    from qwen3tts import GenerationRequest, Qwen3TTSModel
+    m = Qwen3TTSModel.from_pretrained(ckpt_dirs["tiny-a"], max_batch=4, max_frames=96, max_prompt=96)
+    try:
+        reqs = []
+        for i, cap in enumerate((9, 41, 20)):
+            r = tiny_request(row=i, n_text=6)
+            reqs.append(GenerationRequest(r["text_ids"], 1, None, "aiden", "english", max_tokens=cap))
+        pieces = {i: [] for i in range(3)}
+        got = m.generate_batch(reqs, temperature=0.0, audio_chunk_frames=8, audio_window_frames=16, audio_lookahead_frames=2,
+                               on_event=lambda i, k, p: pieces[i].append(p) if k == "audio_chunk" else None)
+        base = m.generate_batch(reqs, temperature=0.0)
+        for i, (a, b) in enumerate(zip(got, base)):
+            assert a.status == b.status == 0 and (a.codes == b.codes).all() and a.audio.size == b.audio.size
+            F = a.codes.shape[0]
+            alone = m.codec_decode_streamed(a.codes[None], 8, 16, 2)[0]
+            assert (a.audio == alone[:a.audio.size]).all(), i
+            cat = np.concatenate([p for _, p in pieces[i]])
+            assert (cat == a.audio).all() and len(pieces[i]) == -(-F // 8)
+        # an ordinary two-deep pipeline right behind it
+        j1 = m.generate_batch_begin(reqs, temperature=0.0)
+        j2 = m.generate_batch_begin(reqs, temperature=0.0, more_follows=False)
+        r1, r2 = m.generate_batch_end(j1), m.generate_batch_end(j2)
+        for x, y, z in zip(r1, r2, base):
+            assert (x.audio == z.audio).all() and (y.audio == z.audio).all()
+    finally:
+        m.close()
