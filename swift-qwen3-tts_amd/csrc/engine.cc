@@ -390,12 +390,6 @@ void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
     stamp(0);
     enqueue_talker_step(B, true);
     stamp(1);
-    {   // final norm (prologue) + codec_head (Talker.swift:573, 644)
-        GemmArgs hd = gemm_args(m_->codec_head, tk_.h, B);
-        hd.epi = 0; hd.y = tk_.logits; hd.ldy = tk_.ld_logits;
-        hd.norm_w = m_->talker.final_norm; hd.ss_in = tk_.ss_a; hd.ss_count = H / 16; hd.norm_dim = H; hd.norm_eps = m_->talker.eps;
-        launch_gemm_skinny(hd, st_);
-    }
     // where the samplers put the next code-predictor input
     uint16_t* next_x = m_->has_cp_proj ? cp_x_ : cp_.h;
     float* next_ss = m_->has_cp_proj ? nullptr : cp_.ss_a;
@@ -403,6 +397,22 @@ void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
     // activation buffers they go through the stack together (rows 0..B-1 and B..2B-1, chunk attention), which saves a
     // whole pass of launches per frame; otherwise they are two passes.
     const bool pair = 2 * B <= Mp_;
+    {   // final norm (prologue) + codec_head (Talker.swift:573, 644)
+        GemmArgs hd = gemm_args(m_->codec_head, tk_.h, B);
+        hd.epi = 0; hd.y = tk_.logits; hd.ldy = tk_.ld_logits;
+        hd.norm_w = m_->talker.final_norm; hd.ss_in = tk_.ss_a; hd.ss_count = H / 16; hd.norm_dim = H; hd.norm_eps = m_->talker.eps;
+        bool rode = false;
+        if (pair) {
+            // the predictor's first position -- the talker's final-normed hidden state (Talker.swift:573), materialised next to
+            // the embedding -- reads what this GEMM reads: B extra workgroups of its launch instead of a launch of its own
+            NormRowsArgs n{};
+            n.h = tk_.h; n.hMB = MBL; n.w = m_->talker.final_norm; n.eps = m_->talker.eps;
+            n.out = next_x; n.outMB = MBL; n.ss_out = next_ss; n.M = B; n.H = H;
+            rode = launch_gemm_skinny_with_norm_rows(hd, n, st_);
+            if (!rode) launch_norm_rows(n, st_);
+        }
+        if (!rode) launch_gemm_skinny(hd, st_);
+    }
     SamplerArgs sa{};
     sa.logits = tk_.logits; sa.ldl = tk_.ld_logits; sa.V = V; sa.sp = sp_dev_; sa.is_talker = 1;
     sa.suppress_lo = V - 1024; sa.suppress_hi = V; sa.eos_id = t.codec_eos_token_id;  // Qwen3.swift:829-835
@@ -421,11 +431,6 @@ void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
     }
     sa.logits_dump = (dbg && dbg->talker_logits) ? tl_dump_ : nullptr; sa.dump_ld = V; sa.dump_off = 0;
     if (pair) {
-        // first position: the talker's final-normed hidden state (Talker.swift:573), materialised next to the embedding
-        NormRowsArgs n{};
-        n.h = tk_.h; n.hMB = MBL; n.w = m_->talker.final_norm; n.eps = m_->talker.eps;
-        n.out = next_x; n.outMB = MBL; n.ss_out = next_ss; n.M = B; n.H = H;
-        launch_norm_rows(n, st_);
         launch_sampler(sa, st_);
         int ss_count = 1;
         if (m_->has_cp_proj) {  // small_to_mtp_projection over both positions (CodePredictor.swift:327-330)
@@ -447,6 +452,12 @@ void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
             launch_copy_rows(reinterpret_cast<const uint16_t*>(cp_ss2_), 0, reinterpret_cast<uint16_t*>(cp_.ss_a), 0, 1, Mp_ * 2, st_);
         }
     }
+    FrameEndArgs fe{};
+    fe.cur_codes = cur_codes_; fe.codec_emb = m_->codec_emb; fe.cp_emb = m_->cp_emb_dev;
+    fe.trailing = trailing_; fe.n_trailing = n_trailing_; fe.trailing_idx = trailing_idx_; fe.Tmax = Tcap_;
+    fe.tts_pad = tts_pad_; fe.h = tk_.h; fe.hMB = MBL; fe.ss_out = tk_.ss_a; fe.H = H; fe.B = B; fe.groups = groups;
+    fe.n_frames = n_frames_; fe.max_frames = max_frames_; fe.finished = finished_; fe.active = active_; fe.cp_len = cp_len_;
+    bool fe_done = false;
     for (int i = 0; i < groups - 1; ++i) {
         const bool second_of_pair = pair && i == 0;  // its stack forward already ran above; rows B..2B-1 hold it
         const int Mh = second_of_pair ? 2 * B : B;
@@ -477,15 +488,15 @@ void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
             sc.emb_ss = m_->cp_pss[size_t(i)]; sc.nss = CH / 16; sc.next_ss = cp_.ss_a; sc.next_ss_ld = Mp_;
         }
         sc.logits_dump = (dbg && dbg->cp_logits) ? cl_dump_ : nullptr; sc.dump_ld = (groups - 1) * Vc; sc.dump_off = i * Vc;
-        launch_sampler(sc, st_);
+        if (i == groups - 2 && Vc <= 2048) {  // the frame's last draw carries its row's end-of-frame job (Qwen3.swift:919-935; row_jobs.h)
+            launch_sampler_with_frame_end(sc, fe, st_);
+            fe_done = true;
+        } else {
+            launch_sampler(sc, st_);
+        }
         stamp(second_of_pair ? 4 : 6);
     }
-    FrameEndArgs fe{};
-    fe.cur_codes = cur_codes_; fe.codec_emb = m_->codec_emb; fe.cp_emb = m_->cp_emb_dev;
-    fe.trailing = trailing_; fe.n_trailing = n_trailing_; fe.trailing_idx = trailing_idx_; fe.Tmax = Tcap_;
-    fe.tts_pad = tts_pad_; fe.h = tk_.h; fe.hMB = MBL; fe.ss_out = tk_.ss_a; fe.H = H; fe.B = B; fe.groups = groups;
-    fe.n_frames = n_frames_; fe.max_frames = max_frames_; fe.finished = finished_; fe.active = active_; fe.cp_len = cp_len_;
-    launch_frame_end(fe, st_);
+    if (!fe_done) launch_frame_end(fe, st_);
     stamp(7);
 }
 

@@ -11,6 +11,25 @@ namespace q3 {
 constexpr int kPageTokens = 64;  // tokens per KV page
 constexpr int kHeadDim = 128;    // Qwen3-TTS talker / code predictor head_dim (Config.swift:154,301)
 
+// ---- RMSNorm of whole rows (lm_misc.hip): only where a normalised vector must be materialised --
+// (the code predictor's first input when there is no small_to_mtp_projection). In the layers the
+// norm lives in the consumer GEMM's prologue.
+struct NormRowsArgs {
+    const uint16_t* h;  // fragment-major [M][H]
+    int hMB;
+    const uint16_t* w;
+    float eps;
+    uint16_t* out;      // fragment-major
+    int outMB;
+    float* ss_out;      // [ss_ld]: sum(out^2) per row (first partial of the consumer's norm) or nullptr
+    int M, H;
+    // optional: sum(h^2) per row from the producer's per-tile partials [ss_count][ss_ld], added up exactly as the GEMM's
+    // norm prologue adds them (gemm_body.inc), so that this kernel + a GEMM without prologue == the GEMM with it, bit for bit
+    const float* ss_in;
+    int ss_count, ss_ld;
+};
+void launch_norm_rows(const NormRowsArgs& a, hipStream_t st);
+
 // ---- skinny GEMM (gemm_decode.hip) -------------------------------------------------------------
 struct GemmArgs {
     const uint16_t* W;  // tiled weights (repack.hip): bf16 tiles, or packed int4 tiles when Wsb != nullptr
@@ -35,25 +54,13 @@ struct GemmArgs {
     float* ss_out;           // [N/16][ss_ld] this tile's share of sum(y^2) per row, or nullptr
 };
 void launch_gemm_skinny(const GemmArgs& a, hipStream_t st);
+// The same launch with riders (kernels/row_jobs.h): n.M extra workgroups, each the RMSNorm of one row -- a job that reads what
+// this GEMM reads and nothing it writes, so it shares the launch instead of paying its own. Only the shapes of the talker's
+// codec_head (EPI 0 with norm prologue, K = 1024 or 2048, at most 32 rows per workgroup); returns false (nothing launched)
+// otherwise. A kernel of its own: the riders' dispatch test must not sit in front of every other GEMM's first load (as a
+// field of GemmArgs it cost 0.28 us per launch, 500 launches per frame step).
+bool launch_gemm_skinny_with_norm_rows(const GemmArgs& a, const NormRowsArgs& n, hipStream_t st);
 
-// ---- RMSNorm of whole rows (lm_misc.hip): only where a normalised vector must be materialised --
-// (the code predictor's first input when there is no small_to_mtp_projection). In the layers the
-// norm lives in the consumer GEMM's prologue.
-struct NormRowsArgs {
-    const uint16_t* h;  // fragment-major [M][H]
-    int hMB;
-    const uint16_t* w;
-    float eps;
-    uint16_t* out;      // fragment-major
-    int outMB;
-    float* ss_out;      // [ss_ld]: sum(out^2) per row (first partial of the consumer's norm) or nullptr
-    int M, H;
-    // optional: sum(h^2) per row from the producer's per-tile partials [ss_count][ss_ld], added up exactly as the GEMM's
-    // norm prologue adds them (gemm_body.inc), so that this kernel + a GEMM without prologue == the GEMM with it, bit for bit
-    const float* ss_in;
-    int ss_count, ss_ld;
-};
-void launch_norm_rows(const NormRowsArgs& a, hipStream_t st);
 
 // ---- QK-norm + RoPE + KV append + paged decode attention (attn_decode.hip) ---------------------
 struct AttnArgs {
@@ -86,6 +93,26 @@ struct AttnArgs {
     int nt_kv;           // 1: cache rows are loaded non-temporally (long caches read once per step)
 };
 void launch_attn_decode(const AttnArgs& a, hipStream_t st);
+
+struct FrameEndArgs {  // Qwen3.swift:919-935 + loop bookkeeping
+    const int32_t* cur_codes;     // [B][16]
+    const uint16_t* codec_emb;    // talker codec_embedding [V][H]
+    const uint16_t* const* cp_emb;  // device array of 15 tables [Vcp][H]
+    const uint16_t* trailing;     // [B][Tmax][H]
+    const int32_t* n_trailing;    // [B]
+    int32_t* trailing_idx;        // [B]
+    int Tmax;
+    const uint16_t* tts_pad;      // [H]
+    uint16_t* h;                  // fragment-major [B][H] next talker input
+    int hMB, H, B, groups;
+    float* ss_out;                // [B] sum of squares of the new input
+    int32_t* n_frames;
+    const int32_t* max_frames;
+    uint8_t* finished;
+    uint8_t* active;
+    int32_t* cp_len;              // [B] reset to 0
+};
+void launch_frame_end(const FrameEndArgs& a, hipStream_t st);
 
 // ---- sampler (sampler.hip) ---------------------------------------------------------------------
 struct SamplingParams {  // lives in device memory so the captured graph does not depend on it
@@ -133,6 +160,9 @@ struct SamplerArgs {
     int dump_ld, dump_off;
 };
 void launch_sampler(const SamplerArgs& a, hipStream_t st);
+// The frame's last draw with its row's end-of-frame job riding along (kernels/row_jobs.h frame_end_job): the sampler is that
+// job's only predecessor and works on the same row. Code-predictor draws only (a.is_talker == 0, V <= 2048).
+void launch_sampler_with_frame_end(const SamplerArgs& a, const FrameEndArgs& fe, hipStream_t st);
 // dst[r][j] = ss[j * ss_ld + r]: per-tile sums of squares of `rows` GEMM output rows -> table rows
 void launch_ss_to_table(const float* ss, int ss_ld, float* dst, int nss, int rows, hipStream_t st);
 
@@ -164,25 +194,6 @@ void launch_stamp(unsigned long long* acc, unsigned long long* last, int k, hipS
 void launch_prefill_chunk_load(const PrefillLoadArgs& a, int C, hipStream_t st);
 void launch_advance_len_chunk(int32_t* kv_len, const int32_t* n_prompt, int r_base, int C, int B, hipStream_t st);
 
-struct FrameEndArgs {  // Qwen3.swift:919-935 + loop bookkeeping
-    const int32_t* cur_codes;     // [B][16]
-    const uint16_t* codec_emb;    // talker codec_embedding [V][H]
-    const uint16_t* const* cp_emb;  // device array of 15 tables [Vcp][H]
-    const uint16_t* trailing;     // [B][Tmax][H]
-    const int32_t* n_trailing;    // [B]
-    int32_t* trailing_idx;        // [B]
-    int Tmax;
-    const uint16_t* tts_pad;      // [H]
-    uint16_t* h;                  // fragment-major [B][H] next talker input
-    int hMB, H, B, groups;
-    float* ss_out;                // [B] sum of squares of the new input
-    int32_t* n_frames;
-    const int32_t* max_frames;
-    uint8_t* finished;
-    uint8_t* active;
-    int32_t* cp_len;              // [B] reset to 0
-};
-void launch_frame_end(const FrameEndArgs& a, hipStream_t st);
 
 // prompt assembly (Qwen3.swift:371-406, 505-510): dst[dst_row[i]] = proj[a[i]] when b[i] == -1, else
 // bf16(proj[a[i]] + other) with other = table[b[i]] (b >= 0) or extra[-2 - b[i]] (voice-clone rows)

@@ -30,6 +30,7 @@
 
 #include "../common.h"
 #include "../kernels.h"
+#include "row_jobs.h"
 
 namespace q3 {
 
@@ -41,6 +42,24 @@ template <int MB, int EPI, int NW, int CH, bool NORM, bool QUANT, int NP = 1, bo
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a) {
     __builtin_amdgcn_s_setprio(3);  // the AR chain's waves go first where they share a CU with a codec decode (engine.cc)
     gemm_skinny_body<MB, EPI, NW, CH, NORM, QUANT, NP, NTW>(a, blockIdx.x, blockIdx.y * MB);
+}
+
+// gemm_skinny_kernel<MB, 0, 8, CH, true, QUANT> plus riders: workgroups tiles .. tiles + n.M - 1 of grid.x normalise one row each
+struct GemmSideArgs {
+    GemmArgs g;
+    NormRowsArgs n;
+    int tiles;
+};
+template <int MB, int CH, bool QUANT>
+__global__ __launch_bounds__(512) void gemm_skinny_side_kernel(GemmSideArgs s) {
+    __builtin_amdgcn_s_setprio(3);
+    if (int(blockIdx.x) >= s.tiles) {
+        __shared__ float side_sh[4];
+        __shared__ float side_parts[8];
+        if (blockIdx.y == 0) norm_row_job(s.n, int(blockIdx.x) - s.tiles, threadIdx.x, side_sh, side_parts);
+        return;
+    }
+    gemm_skinny_body<MB, 0, 8, CH, true, QUANT, 1, false>(s.g, blockIdx.x, blockIdx.y * MB);
 }
 
 template <int MB, int EPI, bool NORM, bool QUANT, bool NTW>
@@ -141,6 +160,33 @@ void launch_epi(const GemmArgs& a, hipStream_t st) {
 }
 
 }  // namespace
+
+bool launch_gemm_skinny_with_norm_rows(const GemmArgs& a, const NormRowsArgs& n, hipStream_t st) {
+    // exactly the launch launch_gemm_skinny would make for these arguments (launch_q / launch_mb), or nothing
+    if (a.epi != 0 || !a.norm_w || a.nt_weights || n.M <= 0 || n.H > 4096) return false;
+    const int KC = a.K / 128, tiles = a.N / 16, MBt = (a.Mpad + 15) / 16;
+    if (KC <= 4 || (KC + 7) / 8 > 2 || a.K % 128 != 0 || a.N % 16 != 0) return false;
+    const int ch = (KC + 7) / 8;
+    int split = 1;
+    if (MBt % 4 == 0 && tiles * 4 <= 256) split = 4;
+    else if (MBt % 2 == 0 && tiles * 2 <= 256) split = 2;
+    while (MBt / split > 2 || MBt % split != 0) ++split;
+    const int mbw = MBt / split;
+    if (mbw < 1 || mbw > 2 || std::getenv("Q3TTS_GEMM_NO_ROW_SPLIT")) return false;
+    Q3_CHECK(a.ss_in && a.ss_count >= 1 && a.ss_ld >= a.Mpad && a.xMB * 16 >= a.Mpad, 3, "gemm_skinny: norm prologue needs sums of squares");
+    GemmSideArgs s{a, n, tiles};
+    const dim3 grid(tiles + n.M, split), block(512);
+    const bool q = a.Wsb != nullptr;
+#define Q3_SIDE(MBv, CHv)                                                                              \
+    do {                                                                                               \
+        if (q) hipLaunchKernelGGL((gemm_skinny_side_kernel<MBv, CHv, true>), grid, block, 0, st, s);   \
+        else hipLaunchKernelGGL((gemm_skinny_side_kernel<MBv, CHv, false>), grid, block, 0, st, s);    \
+    } while (0)
+    if (mbw == 1) { if (ch == 1) Q3_SIDE(1, 1); else Q3_SIDE(1, 2); }
+    else { if (ch == 1) Q3_SIDE(2, 1); else Q3_SIDE(2, 2); }
+#undef Q3_SIDE
+    return true;
+}
 
 void launch_gemm_skinny(const GemmArgs& a, hipStream_t st) {
     Q3_CHECK(a.K % 128 == 0 && a.N % (a.epi == 2 ? 8 : 16) == 0, 3, "gemm_skinny: K must be a multiple of 128 and N of 16");

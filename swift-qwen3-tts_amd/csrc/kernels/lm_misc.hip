@@ -4,6 +4,7 @@
 // >= 17 eval()/.item() syncs per frame: SURVEY.md section 3.2).
 #include "../common.h"
 #include "../kernels.h"
+#include "row_jobs.h"
 
 namespace q3 {
 namespace {
@@ -16,67 +17,12 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {
     return ((sh[0] + sh[1]) + sh[2]) + sh[3];
 }
 
-// RMSNorm of whole rows, fragment-major in and out. One workgroup per row.
-//   out <- bf16( bf16(h * rstd) * w )            MLXNN.RMSNorm, Talker.swift:520,573
+// RMSNorm of whole rows, fragment-major in and out. One workgroup per row (the arithmetic lives in row_jobs.h: the frame
+// step carries the same job inside the codec_head launch).
 __global__ __launch_bounds__(256) void norm_rows_kernel(NormRowsArgs a) {
     __shared__ float sh[4];
     __shared__ float parts[8];
-    constexpr int kTrips = 2;  // H <= 4096
-    const int m = blockIdx.x, tid = threadIdx.x;
-    float v[kTrips][8];
-    uint4 wv[kTrips];
-    float ss = 0.f;
-#pragma unroll
-    for (int tr = 0; tr < kTrips; ++tr) {
-        const int i0 = tid * 8 + tr * 2048;
-        if (i0 < a.H) {
-            const uint4 hv = *reinterpret_cast<const uint4*>(a.h + act_tiled_offset(m, i0, a.hMB));
-            wv[tr] = *reinterpret_cast<const uint4*>(a.w + i0);
-            const uint32_t hw[4] = {hv.x, hv.y, hv.z, hv.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[tr][2 * j] = lo_bf(hw[j]);
-                v[tr][2 * j + 1] = hi_bf(hw[j]);
-                ss += v[tr][2 * j] * v[tr][2 * j] + v[tr][2 * j + 1] * v[tr][2 * j + 1];
-            }
-        }
-    }
-    float tot;
-    if (a.ss_in) {  // the prologue's order: eight strided partial sums, then those eight in order
-        if (tid < 8) {
-            float s = 0.f;
-            for (int j = tid; j < a.ss_count; j += 8) s += a.ss_in[(size_t)j * a.ss_ld + m];
-            parts[tid] = s;
-        }
-        __syncthreads();
-        tot = 0.f;
-#pragma unroll
-        for (int p = 0; p < 8; ++p) tot += parts[p];
-    } else {
-        tot = block_sum_256(ss, sh);
-    }
-    const float rstd = 1.0f / sqrtf(tot / (float)a.H + a.eps);
-    float so = 0.f;
-#pragma unroll
-    for (int tr = 0; tr < kTrips; ++tr) {
-        const int i0 = tid * 8 + tr * 2048;
-        if (i0 < a.H) {
-            const uint32_t ww[4] = {wv[tr].x, wv[tr].y, wv[tr].z, wv[tr].w};
-            uint32_t ow[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float o0 = rbf(rbf(v[tr][2 * j] * rstd) * lo_bf(ww[j]));
-                const float o1 = rbf(rbf(v[tr][2 * j + 1] * rstd) * hi_bf(ww[j]));
-                so += o0 * o0 + o1 * o1;
-                ow[j] = pack_bf(o0, o1);
-            }
-            *reinterpret_cast<uint4*>(a.out + act_tiled_offset(m, i0, a.outMB)) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-        }
-    }
-    if (a.ss_out) {
-        const float t2 = block_sum_256(so, sh);
-        if (tid == 0) a.ss_out[m] = t2;
-    }
+    norm_row_job(a, blockIdx.x, threadIdx.x, sh, parts);
 }
 
 __global__ void gather_rows_kernel(const uint16_t* table, int ld, const int32_t* ids, const int32_t* token_map,
@@ -228,62 +174,15 @@ __global__ void advance_len_kernel(int32_t* kv_len, const uint8_t* active, int B
     if (b < B && (!active || active[b])) kv_len[b] += 1;
 }
 
-// End of a frame (Qwen3.swift:914-935): next talker input = text embed (next trailing text row or
-// tts_pad) + sum of the 16 codebook embeddings, every add rounded to bf16 in the reference's
-// left-to-right order; then the loop bookkeeping that the Swift loop keeps on the host.
+// End of a frame as a launch of its own (row_jobs.h frame_end_job; the frame step runs it in the last sampler's launch)
 __global__ __launch_bounds__(256) void frame_end_kernel(FrameEndArgs a) {
+    __shared__ float sh[4];
     const int b = blockIdx.x;
     if (a.finished[b]) {
         if (threadIdx.x == 0) a.cp_len[b] = 0;
         return;
     }
-    const int32_t* cc = a.cur_codes + (size_t)b * 16;
-    const int ti = a.trailing_idx[b];
-    const bool has_text = ti < a.n_trailing[b];
-    const uint16_t* text = has_text ? a.trailing + ((size_t)b * a.Tmax + ti) * a.H : a.tts_pad;
-    const uint16_t* rows[16];
-    rows[0] = a.codec_emb + (size_t)cc[0] * a.H;
-#pragma unroll
-    for (int g = 1; g < 16; ++g) rows[g] = (g < a.groups) ? a.cp_emb[g - 1] + (size_t)cc[g] * a.H : rows[0];
-    __shared__ float sh[4];
-    float ss = 0.f;
-    for (int i0 = threadIdx.x * 8; i0 < a.H; i0 += 256 * 8) {
-        uint4 e[16];
-#pragma unroll
-        for (int g = 0; g < 16; ++g) e[g] = *reinterpret_cast<const uint4*>(rows[g] + i0);  // 16 independent loads
-        const uint4 tx = *reinterpret_cast<const uint4*>(text + i0);
-        const uint32_t tw[4] = {tx.x, tx.y, tx.z, tx.w};
-        uint32_t ow[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t first = (&e[0].x)[j];
-            float c0 = lo_bf(first), c1 = hi_bf(first);
-#pragma unroll
-            for (int g = 1; g < 16; ++g)
-                if (g < a.groups) {
-                    const uint32_t w = (&e[g].x)[j];
-                    c0 = rbf(c0 + lo_bf(w));
-                    c1 = rbf(c1 + hi_bf(w));
-                }
-            const float h0 = rbf(lo_bf(tw[j]) + c0), h1 = rbf(hi_bf(tw[j]) + c1);
-            ss += h0 * h0 + h1 * h1;
-            ow[j] = pack_bf(h0, h1);
-        }
-        *reinterpret_cast<uint4*>(a.h + act_tiled_offset(b, i0, a.hMB)) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-    }
-    const float tot = block_sum_256(ss, sh);
-    if (threadIdx.x == 0) a.ss_out[b] = tot;
-    __syncthreads();  // every thread has read trailing_idx before it moves
-    if (threadIdx.x == 0) {
-        if (has_text) a.trailing_idx[b] = ti + 1;
-        const int nf = a.n_frames[b] + 1;
-        a.n_frames[b] = nf;
-        if (nf >= a.max_frames[b]) {  // for _ in 0..<effectiveMaxTokens (Qwen3.swift:847)
-            a.finished[b] = 1;
-            a.active[b] = 0;
-        }
-        a.cp_len[b] = 0;  // fresh code-predictor cache per frame (Qwen3.swift:879)
-    }
+    frame_end_job(a, b, threadIdx.x, -1, sh);
 }
 
 }  // namespace

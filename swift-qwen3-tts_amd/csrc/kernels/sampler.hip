@@ -15,6 +15,7 @@
 // the next code-predictor pass (:884-892) and the KV-length advance.
 #include "../common.h"
 #include "../kernels.h"
+#include "row_jobs.h"
 
 namespace q3 {
 namespace {
@@ -156,8 +157,8 @@ __device__ Best block_argmax(Best x, Best* scratch) {
 // false>: the code predictor's fifteen draws per frame (V = 2048, no suppress range, no repetition penalty, no EOS:
 // Qwen3.swift:904-909) -- two elements per thread instead of four and the talker-only branches compiled out: frame step
 // 3.413 -> 3.375 ms (512 threads x 4 elements: 3.380; 256 x 8: 3.426). TALKER must equal a.is_talker.
-template <int kThreads, int kMaxV, bool TALKER>
-__global__ __launch_bounds__(kThreads) void sampler_kernel(SamplerArgs a) {
+template <int kThreads, int kMaxV, bool TALKER, bool FEND>
+__device__ __forceinline__ void sampler_body(const SamplerArgs& a, const FrameEndArgs* fe) {
     constexpr int kElems = kMaxV / kThreads;
     __builtin_amdgcn_s_setprio(3);
     __shared__ float vals[kMaxV];
@@ -436,9 +437,32 @@ __global__ __launch_bounds__(kThreads) void sampler_kernel(SamplerArgs a) {
             }
         }
     }
+    // the frame's last draw: its row's end-of-frame job rides along (next talker input from all sixteen codes + loop state)
+    if constexpr (FEND) {
+        __shared__ float fe_sh[4];
+        frame_end_job(*fe, b, tid, used, fe_sh);
+    }
+}
+
+template <int kThreads, int kMaxV, bool TALKER>
+__global__ __launch_bounds__(kThreads) void sampler_kernel(SamplerArgs a) {
+    sampler_body<kThreads, kMaxV, TALKER, false>(a, nullptr);
+}
+struct SamplerFendArgs {
+    SamplerArgs s;
+    FrameEndArgs fe;
+};
+__global__ __launch_bounds__(1024) void sampler_fend_kernel(SamplerFendArgs a) {
+    sampler_body<1024, 2048, false, true>(a.s, &a.fe);
 }
 
 }  // namespace
+
+void launch_sampler_with_frame_end(const SamplerArgs& a, const FrameEndArgs& fe, hipStream_t st) {
+    Q3_CHECK(!a.is_talker && a.V <= 2048, 3, "sampler: the end-of-frame rider belongs to a code-predictor draw");
+    SamplerFendArgs s{a, fe};
+    hipLaunchKernelGGL(sampler_fend_kernel, dim3(a.B), dim3(1024), 0, st, s);
+}
 
 void launch_sampler(const SamplerArgs& a, hipStream_t st) {
     Q3_CHECK(a.V <= kMaxVAll, 3, "sampler: vocabulary larger than 4096 is not supported");
