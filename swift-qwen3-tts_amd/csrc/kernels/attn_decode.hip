@@ -13,6 +13,8 @@
 // over T and are merged with a log-sum-exp reduction through LDS.
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "../common.h"
 #include "../kernels.h"
 
@@ -39,8 +41,13 @@ __global__ __launch_bounds__(NTH) void attn_chunk_kernel(AttnArgs a) {
     constexpr int NG = NTH / 16;
     constexpr int NWV = NTH / 64;
     __shared__ __attribute__((aligned(16))) float q_s[CMAX][REP][D];
-    __shared__ float k_s[CMAX][D];
-    __shared__ float v_s[CMAX][D];
+    // the chunk's keys / values are bf16-exact (norm_rope rounds, V is a copy): above eight positions they are kept as bf16 so
+    // that sixteen positions still fit the 64 KiB of static LDS next to the lane groups' partial results
+    using KV = typename std::conditional<(CMAX > 8), uint16_t, float>::type;
+    auto kv_put = [](float v) -> KV { if constexpr (CMAX > 8) return f2bf(v); else return v; };
+    auto kv_get = [](KV v) -> float { if constexpr (CMAX > 8) return bf2f(v); else return v; };
+    __shared__ KV k_s[CMAX][D];
+    __shared__ KV v_s[CMAX][D];
     __shared__ float m_s[NG][REP];
     __shared__ float l_s[NG][REP];
     __shared__ float acc_s[NG][REP][D];
@@ -74,15 +81,15 @@ __global__ __launch_bounds__(NTH) void attn_chunk_kernel(AttnArgs a) {
             const uint16_t* kp = row + qdim + (size_t)kvh * D;
             float o0, o1;
             norm_rope(bf2f(kp[lane]), bf2f(kp[lane + 64]), a.kn_w, a.eps, cosr, sinr, lane, o0, o1);
-            k_s[p][lane] = o0;
-            k_s[p][lane + 64] = o1;
+            k_s[p][lane] = kv_put(o0);
+            k_s[p][lane + 64] = kv_put(o1);
             a.kpool[nslot + lane] = f2bf(o0);
             a.kpool[nslot + lane + 64] = f2bf(o1);
         } else {
             const uint16_t* vp = row + qdim + kdim + (size_t)kvh * D;
             const uint16_t v0 = vp[lane], v1 = vp[lane + 64];
-            v_s[p][lane] = bf2f(v0);
-            v_s[p][lane + 64] = bf2f(v1);
+            v_s[p][lane] = kv_put(bf2f(v0));
+            v_s[p][lane + 64] = kv_put(bf2f(v1));
             a.vpool[nslot + lane] = v0;
             a.vpool[nslot + lane + 64] = v1;
         }
@@ -138,8 +145,8 @@ __global__ __launch_bounds__(NTH) void attn_chunk_kernel(AttnArgs a) {
                 const int e = p0 + (t - len0);  // chunk element that sits at position t
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    kf[j] = k_s[e][8 * c + j];
-                    vf[j] = v_s[e][8 * c + j];
+                    kf[j] = kv_get(k_s[e][8 * c + j]);
+                    vf[j] = kv_get(v_s[e][8 * c + j]);
                 }
             }
             step(kf, vf);
@@ -190,19 +197,19 @@ void launch_attn_decode(const AttnArgs& a, hipStream_t st) {
     // kv head). The chunk kernel uses the same counts, so both round identically.
     const bool wide = a.max_pages > 1 && rep <= 2;
     if (a.chunk > 1) {
-        Q3_CHECK(a.chunk <= 8, 3, "attn_decode: at most 8 positions per launch");
+        Q3_CHECK(a.chunk <= 16, 3, "attn_decode: at most 16 positions per launch");
+#define Q3_CHUNK(REPv, NTHv)                                                                                        \
+    do {                                                                                                            \
+        if (a.chunk > 8) hipLaunchKernelGGL((attn_chunk_kernel<REPv, NTHv, 16>), grid, dim3(NTHv), 0, st, a);        \
+        else hipLaunchKernelGGL((attn_chunk_kernel<REPv, NTHv, 8>), grid, dim3(NTHv), 0, st, a);                     \
+    } while (0)
         switch (rep) {
-            case 1:
-                if (wide) hipLaunchKernelGGL((attn_chunk_kernel<1, 512, 8>), grid, dim3(512), 0, st, a);
-                else hipLaunchKernelGGL((attn_chunk_kernel<1, 256, 8>), grid, dim3(256), 0, st, a);
-                break;
-            case 2:
-                if (wide) hipLaunchKernelGGL((attn_chunk_kernel<2, 512, 8>), grid, dim3(512), 0, st, a);
-                else hipLaunchKernelGGL((attn_chunk_kernel<2, 256, 8>), grid, dim3(256), 0, st, a);
-                break;
-            case 3: hipLaunchKernelGGL((attn_chunk_kernel<3, 256, 8>), grid, dim3(256), 0, st, a); break;
-            case 4: hipLaunchKernelGGL((attn_chunk_kernel<4, 256, 8>), grid, dim3(256), 0, st, a); break;
+            case 1: if (wide) Q3_CHUNK(1, 512); else Q3_CHUNK(1, 256); break;
+            case 2: if (wide) Q3_CHUNK(2, 512); else Q3_CHUNK(2, 256); break;
+            case 3: Q3_CHUNK(3, 256); break;
+            case 4: Q3_CHUNK(4, 256); break;
         }
+#undef Q3_CHUNK
         return;
     }
     switch (rep) {

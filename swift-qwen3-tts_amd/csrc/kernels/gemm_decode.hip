@@ -190,7 +190,7 @@ bool launch_gemm_skinny_with_norm_rows(const GemmArgs& a, const NormRowsArgs& n,
 
 void launch_gemm_skinny(const GemmArgs& a, hipStream_t st) {
     Q3_CHECK(a.K % 128 == 0 && a.N % (a.epi == 2 ? 8 : 16) == 0, 3, "gemm_skinny: K must be a multiple of 128 and N of 16");
-    Q3_CHECK(a.Mpad % 16 == 0 && a.M <= a.Mpad && a.Mpad <= 256, 3, "gemm_skinny: bad M padding");
+    Q3_CHECK(a.Mpad % 16 == 0 && a.M <= a.Mpad && a.Mpad <= 1024, 3, "gemm_skinny: bad M padding");
     Q3_CHECK(a.xMB * 16 >= a.Mpad, 3, "gemm_skinny: x allocation has fewer row blocks than the batch");
     const bool norm = a.norm_w != nullptr;
     if (norm) Q3_CHECK(a.ss_in && a.ss_count >= 1 && a.ss_ld >= a.Mpad, 3, "gemm_skinny: norm prologue needs sums of squares");
