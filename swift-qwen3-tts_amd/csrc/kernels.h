@@ -59,6 +59,9 @@ void launch_gemm_skinny(const GemmArgs& a, hipStream_t st);
 // codec_head (EPI 0 with norm prologue, K = 1024 or 2048, at most 32 rows per workgroup); returns false (nothing launched)
 // otherwise. A kernel of its own: the riders' dispatch test must not sit in front of every other GEMM's first load (as a
 // field of GemmArgs it cost 0.28 us per launch, 500 launches per frame step).
+// More than 64 rows, plain bf16 weights, no prologue / bias: the tall form (gemm_prefill.hip), bit-identical to the skinny one.
+// launch_gemm_skinny tries it first; false = nothing launched (shape or options it does not take).
+bool launch_gemm_tall(const GemmArgs& a, hipStream_t st);
 bool launch_gemm_skinny_with_norm_rows(const GemmArgs& a, const NormRowsArgs& n, hipStream_t st);
 
 

@@ -72,7 +72,7 @@ void launch_mb(const GemmArgs& a, int split, hipStream_t st) {
     hipLaunchKernelGGL((gemm_skinny_kernel<MB, EPI, NWv, CHv, NORM, QUANT, 1, NTW>), dim3(tiles, split), dim3(NWv * 64), 0, st, a)
     if constexpr (MB == 4 && !NORM && !NTW) {
         // prefill chunks: four tiles per workgroup through the chunk-streaming form (CH = 0)
-        static const bool one_tile = std::getenv("Q3TTS_GEMM_ONE_PAIR") != nullptr;
+        const bool one_tile = std::getenv("Q3TTS_GEMM_ONE_PAIR") != nullptr;
         if (!one_tile && nw == 8 && tiles >= 64) {
             // four tiles per workgroup quarter the x traffic (every workgroup reads all K of its 64 rows), but a narrow layer
             // (o_proj / down_proj: 128 tiles) is then 128 workgroups on 256 CUs: two tiles each there (prefill 17.0 -> 14.2 ms
@@ -87,7 +87,7 @@ void launch_mb(const GemmArgs& a, int split, hipStream_t st) {
     if constexpr (EPI == 2 && MB <= 2) {
         // gate/up tiles are self-contained, so a workgroup takes as many as it needs for the launch to be ONE round of at
         // most 256 workgroups: 768 tiles (6144 columns) -> 3 each, 384 (3072) -> 2 each
-        static const bool one_tile = std::getenv("Q3TTS_GEMM_ONE_PAIR") != nullptr;
+        const bool one_tile = std::getenv("Q3TTS_GEMM_ONE_PAIR") != nullptr;
         const int np = one_tile ? 1 : (tiles > 512 ? 3 : (tiles > 256 ? 2 : 1));
         if (nw == 8 && (ch == 1 || ch == 2) && np > 1) {
             const dim3 grid((tiles + np - 1) / np, split);
@@ -119,7 +119,7 @@ void launch_q(const GemmArgs& a, hipStream_t st) {
     // workgroup that carries two row blocks cannot keep every x fragment of a long K in registers. Their row blocks go
     // to separate workgroups instead (grid.y); tile x of both lands on the same XCD (128 = 0 mod 8), so the second
     // read of the weight tile is an L2 hit. Per-row arithmetic does not depend on the grouping: results are unchanged.
-    static const bool no_split = std::getenv("Q3TTS_GEMM_NO_ROW_SPLIT") != nullptr;
+    const bool no_split = std::getenv("Q3TTS_GEMM_NO_ROW_SPLIT") != nullptr;  // (per launch: tests switch it)
     int tiles = a.N / 16;  // workgroups along x
     if constexpr (EPI == 2) {  // eight columns per tile, up to three tiles per workgroup (launch_mb)
         const int t8 = a.N / 8;
@@ -193,14 +193,13 @@ void launch_gemm_skinny(const GemmArgs& a, hipStream_t st) {
     Q3_CHECK(a.Mpad % 16 == 0 && a.M <= a.Mpad && a.Mpad <= 1024, 3, "gemm_skinny: bad M padding");
     Q3_CHECK(a.xMB * 16 >= a.Mpad, 3, "gemm_skinny: x allocation has fewer row blocks than the batch");
     const bool norm = a.norm_w != nullptr;
+    if (a.epi == 3) Q3_CHECK(a.yMB * 16 >= a.Mpad, 3, "gemm_skinny: h allocation has fewer row blocks than the batch");
+    if (launch_gemm_tall(a, st)) return;  // prefill chunks: same results from LDS-shared tiles (gemm_prefill.hip)
     if (norm) Q3_CHECK(a.ss_in && a.ss_count >= 1 && a.ss_ld >= a.Mpad, 3, "gemm_skinny: norm prologue needs sums of squares");
     switch (a.epi) {
         case 0: norm ? launch_epi<0, true>(a, st) : launch_epi<0, false>(a, st); break;
         case 2: norm ? launch_epi<2, true>(a, st) : launch_epi<2, false>(a, st); break;
-        case 3:
-            Q3_CHECK(a.yMB * 16 >= a.Mpad, 3, "gemm_skinny: h allocation has fewer row blocks than the batch");
-            norm ? launch_epi<3, true>(a, st) : launch_epi<3, false>(a, st);
-            break;
+        case 3: norm ? launch_epi<3, true>(a, st) : launch_epi<3, false>(a, st); break;
         default: throw Error(3, "gemm_skinny: unknown epilogue");
     }
 }

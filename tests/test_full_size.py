@@ -35,7 +35,7 @@ def _reqs(n):
     return bench.build_requests("1.7b", 0, n, 32, 16)
 
 
-def test_full_size_properties(full_dir):
+def test_full_size_properties(full_dir, monkeypatch):
     from qwen3tts import Qwen3TTSModel
     F = 12
     kw = dict(temperature=0.9, top_k=50, top_p=1.0, repetition_penalty=1.05, seed=1234, force_frames=F)
@@ -49,6 +49,13 @@ def test_full_size_properties(full_dir):
             assert x.status == 0 and x.codes.shape == (F, 16)
             assert (x.codes == y.codes).all() and (x.audio == y.audio).all()
         assert len({tuple(r.codes[:, 0]) for r in a}) > 16          # rows differ (own prompts, own RNG streams)
+        # prefill chunks (512 rows per launch here) go through the tall GEMM (gemm_prefill.hip): the same bits as the skinny
+        # kernel's wave partials at K = 2048 and 6144, eight phases
+        monkeypatch.setenv("Q3TTS_NO_TALL_GEMM", "1")
+        a2 = m.generate_batch(reqs, **kw)
+        monkeypatch.delenv("Q3TTS_NO_TALL_GEMM")
+        for x, y in zip(a, a2):
+            assert (x.codes == y.codes).all() and (x.audio == y.audio).all()
         small = m.generate_batch(reqs[:3], **kw)                       # row independence across scheduling modes
         for x, y in zip(small, a[:3]):
             assert (x.codes == y.codes).all() and np.abs(x.audio - y.audio).max() < 1e-6
