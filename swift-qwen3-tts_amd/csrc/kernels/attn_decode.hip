@@ -11,6 +11,7 @@
 // read once. 16 lanes cover one 256-byte K (or V) row with 16-byte loads, so a wave-instruction
 // reads 4 consecutive cache rows = 1 KiB contiguous; the 16 lane-groups of the workgroup stride
 // over T and are merged with a log-sum-exp reduction through LDS.
+#include <algorithm>
 #include <cstdlib>
 
 #include <type_traits>
@@ -62,9 +63,18 @@ __global__ __launch_bounds__(NTH) void attn_chunk_kernel(AttnArgs a) {
     const int qdim = a.n_heads * D, kdim = a.n_kv * D;
     const int32_t* bt = a.block_table + (size_t)b * a.max_pages;
 
+    // The queries of a chunk are independent of one another and one workgroup walks them in turn (two barriers and a
+    // reduction over all lane groups per query). gridDim.z workgroups share them, query p going to workgroup p mod gridDim.z:
+    // each stages the whole chunk's keys / values for itself and only its own queries; the cache is appended by workgroup 0
+    // alone. Nothing a query computes depends on the split. (Measured at sixteen positions x 32 rows, 1.7B: 30.2 us with
+    // one workgroup per (row, kv head), 26.1 with two, 31.6 with four -- the part is full either way. Requesting phase 1's
+    // operands up front and the cached keys / values once per chunk instead of once per query bought 2 us more and cost the
+    // predictor's two-position step 0.25 us per launch: not kept.)
+    const int qs = blockIdx.z, nqs = gridDim.z;
     // ---- phase 1: q/k norm + rope, v copy, cache append for every live element; vectors round-robin over the waves ----
     for (int vtx = wave; vtx < (C - p0) * (REP + 2); vtx += NWV) {
         const int p = p0 + vtx / (REP + 2), j = vtx % (REP + 2);
+        if (j < REP && p % nqs != qs) continue;  // (wave-uniform)
         const int pos = len0 + (p - p0);
         const uint16_t* row = a.qkv + (size_t)(p * a.B + b) * a.ld;
         const uint16_t* cosr = a.rope_cos + (size_t)pos * D;
@@ -83,15 +93,19 @@ __global__ __launch_bounds__(NTH) void attn_chunk_kernel(AttnArgs a) {
             norm_rope(bf2f(kp[lane]), bf2f(kp[lane + 64]), a.kn_w, a.eps, cosr, sinr, lane, o0, o1);
             k_s[p][lane] = kv_put(o0);
             k_s[p][lane + 64] = kv_put(o1);
-            a.kpool[nslot + lane] = f2bf(o0);
-            a.kpool[nslot + lane + 64] = f2bf(o1);
+            if (qs == 0) {
+                a.kpool[nslot + lane] = f2bf(o0);
+                a.kpool[nslot + lane + 64] = f2bf(o1);
+            }
         } else {
             const uint16_t* vp = row + qdim + kdim + (size_t)kvh * D;
             const uint16_t v0 = vp[lane], v1 = vp[lane + 64];
             v_s[p][lane] = kv_put(bf2f(v0));
             v_s[p][lane + 64] = kv_put(bf2f(v1));
-            a.vpool[nslot + lane] = v0;
-            a.vpool[nslot + lane + 64] = v1;
+            if (qs == 0) {
+                a.vpool[nslot + lane] = v0;
+                a.vpool[nslot + lane + 64] = v1;
+            }
         }
     }
     __syncthreads();
@@ -99,6 +113,7 @@ __global__ __launch_bounds__(NTH) void attn_chunk_kernel(AttnArgs a) {
     // ---- phase 2: one query after the other ----
     const int g = tid >> 4, c = tid & 15;
     for (int p = p0; p < C; ++p) {
+        if (p % nqs != qs) continue;  // (uniform: the barriers below are per query)
         float q[REP][8];
 #pragma unroll
         for (int h = 0; h < REP; ++h)
@@ -198,10 +213,14 @@ void launch_attn_decode(const AttnArgs& a, hipStream_t st) {
     const bool wide = a.max_pages > 1 && rep <= 2;
     if (a.chunk > 1) {
         Q3_CHECK(a.chunk <= 16, 3, "attn_decode: at most 16 positions per launch");
+        // two workgroups share the queries of a long chunk (prefill), one takes a short one (the predictor's step 0)
+        const char* qenv = std::getenv("Q3TTS_CHUNK_QSPLIT");
+        const int nqs = qenv ? std::max(1, std::min(a.chunk, std::atoi(qenv))) : (a.chunk > 8 ? 2 : 1);
+        const dim3 cgrid(a.n_kv, a.B, nqs);
 #define Q3_CHUNK(REPv, NTHv)                                                                                        \
     do {                                                                                                            \
-        if (a.chunk > 8) hipLaunchKernelGGL((attn_chunk_kernel<REPv, NTHv, 16>), grid, dim3(NTHv), 0, st, a);        \
-        else hipLaunchKernelGGL((attn_chunk_kernel<REPv, NTHv, 8>), grid, dim3(NTHv), 0, st, a);                     \
+        if (a.chunk > 8) hipLaunchKernelGGL((attn_chunk_kernel<REPv, NTHv, 16>), cgrid, dim3(NTHv), 0, st, a);       \
+        else hipLaunchKernelGGL((attn_chunk_kernel<REPv, NTHv, 8>), cgrid, dim3(NTHv), 0, st, a);                    \
     } while (0)
         switch (rep) {
             case 1: if (wide) Q3_CHUNK(1, 512); else Q3_CHUNK(1, 256); break;

@@ -51,8 +51,18 @@ __device__ __forceinline__ void norm_row_job(const NormRowsArgs& a, int m, int t
     float tot;
     if (a.ss_in) {  // the GEMM prologue's order: eight strided partial sums, then those eight in order
         if (tid < 8) {
+            // all of a thread's partials are requested before the first add (as a loop of load-then-add this was sixteen
+            // memory round trips in a row, 8 of the kernel's 10 us at 512 rows); H <= 4096: at most 32 per thread
+            float t[32];
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                const int j = tid + 8 * u;
+                t[u] = a.ss_in[(size_t)(j < a.ss_count ? j : 0) * a.ss_ld + m];
+            }
             float s = 0.f;
-            for (int j = tid; j < a.ss_count; j += 8) s += a.ss_in[(size_t)j * a.ss_ld + m];
+#pragma unroll
+            for (int u = 0; u < 32; ++u)
+                if (tid + 8 * u < a.ss_count) s += t[u];
             parts[tid] = s;
         }
         __syncthreads();

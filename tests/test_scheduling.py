@@ -65,7 +65,7 @@ def test_replica_filled_through_the_arena_generates_the_same(ckpt_dirs):
 @pytest.mark.parametrize("name", ["tiny-a", "tiny-b"])
 def test_launch_geometry_switches_change_nothing(ckpt_dirs, monkeypatch, name):
     """Rows per launch (256 vs 64: prefill chunk length, one- or two-pass predictor step 0), the row split of narrow GEMMs,
-    the gate/up pairing and the tall prefill GEMM (off / its other tile shape) only regroup work; per-row arithmetic is the
+    the gate/up pairing, the tall prefill GEMM (off / its other tile shape) and the chunk attention's query split only regroup work; per-row arithmetic is the
     same, so codes and PCM must be bit-identical."""
     from qwen3tts import Qwen3TTSModel
     d = ckpt_dirs[name]
@@ -73,8 +73,9 @@ def test_launch_geometry_switches_change_nothing(ckpt_dirs, monkeypatch, name):
     kw = dict(temperature=0.9, top_k=40, top_p=0.95, repetition_penalty=1.05, seed=31, force_frames=16)
     ref = None
     for env in ({}, {"Q3TTS_ROWS_64": "1"}, {"Q3TTS_GEMM_NO_ROW_SPLIT": "1", "Q3TTS_GEMM_ONE_PAIR": "1"}, {"Q3TTS_NO_TALL_GEMM": "1"},
-                {"Q3TTS_TALL_SHAPE": "2"}):
-        for k in ("Q3TTS_ROWS_64", "Q3TTS_GEMM_NO_ROW_SPLIT", "Q3TTS_GEMM_ONE_PAIR", "Q3TTS_NO_TALL_GEMM", "Q3TTS_TALL_SHAPE"):
+                {"Q3TTS_TALL_SHAPE": "2", "Q3TTS_CHUNK_QSPLIT": "1"}, {"Q3TTS_CHUNK_QSPLIT": "4"}):
+        for k in ("Q3TTS_ROWS_64", "Q3TTS_GEMM_NO_ROW_SPLIT", "Q3TTS_GEMM_ONE_PAIR", "Q3TTS_NO_TALL_GEMM", "Q3TTS_TALL_SHAPE",
+                  "Q3TTS_CHUNK_QSPLIT"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
