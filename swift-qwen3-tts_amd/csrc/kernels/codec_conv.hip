@@ -24,6 +24,8 @@
 // (M = out channels), activations the B operand (N = positions), so each lane ends with 4
 // consecutive channels of one position -> 16-byte epilogue loads/stores.
 // LDS rows are padded to 40 floats: conflict-free for ds_read_b128 (MI355X_MICROARCH.md LDS table).
+#include <cstdlib>
+
 #include "../common.h"
 #include "../codec_kernels.h"
 #include "snake.h"
@@ -543,6 +545,152 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_h2_kernel(ConvGemmArgs a) {
     if (a.out2) snake_pass<CT>(a, reinterpret_cast<float*>(smem3), b, t0, n0, wn, T, wave, lane, acc, wm);
 }
 
+// ---- pointwise form of the fp16x2 kernel ---------------------------------------------------------------
+// K = 1 convs (the 768- / 384-channel residual units' second conv, the ConvNeXt linears, the pre-transformer's linears) are
+// steps of 32 input channels with nothing in between: in conv_gemm_h2_kernel both tiles of step s + 1 are requested during
+// step s, i.e. behind 0.3 us of MFMAs against 2-3 us of first-touch latency for the input tile -- 3.7 us per step measured, the
+// matrix pipe 17 % busy. Here a step's two tiles are requested D steps ahead into a register ring. Every load is
+// unconditional (addresses clamped, values masked when they are staged) and whole groups of D steps run without guards, so
+// that hipcc's wait counts stay exact (s_waitcnt vmcnt((D - 1) x loads per step)) instead of draining the ring -- the two
+// lessons of gemm_prefill.hip. Same tiles, same LDS layout, same MFMA order per accumulator and the same epilogue as
+// conv_gemm_h2_kernel: results are bit-identical to it.
+template <int BN, int D>
+__global__ __launch_bounds__(256, 2) void conv_pw_h2_kernel(ConvGemmArgs a) {
+    constexpr int CT = BN / 32;
+    constexpr int WV = BN * 8 / 256, AV = BM * 8 / 256;
+    using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+    using f32x4r = __attribute__((ext_vector_type(4))) float;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem3[];
+    uint32_t* As = smem3;              // [BM][ROWH]
+    uint32_t* Ws = smem3 + BM * ROWH;  // [BN][ROWH]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int b, n_tile, m_tile;
+    {   // XCD-contiguous tile order (conv_gemm_h2_kernel)
+        const uint32_t gx = gridDim.x, gy = gridDim.y, nwg = gx * gy * gridDim.z;
+        const uint32_t bid = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const uint32_t q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u;
+        const uint32_t swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        n_tile = int(swz % gx);
+        const uint32_t rest = swz / gx;
+        m_tile = int(rest % gy);
+        b = int(rest / gy);
+    }
+    const int n0 = n_tile * BN, t0 = m_tile * BM;
+    const int T = a.frames[b] * a.ppf;
+    if (t0 >= T) return;
+    const float* xb = a.x + (size_t)b * a.x_bstride;
+    const int steps = (a.Cin + KC - 1) / KC;
+
+    f32x4 acc[4][CT];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // this thread's pieces: input rows (clamped into the row's valid range; rows outside it are zeroed when staged) and
+    // weight rows (clamped; columns past N are never stored)
+    const float* asrc[AV];
+    bool aok[AV];
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+        const int item = i * 256 + tid, r = item >> 3;
+        const int t = t0 + r;
+        aok[i] = t >= -a.hist && t < T;
+        const int tc = t < T ? t : T - 1;
+        asrc[i] = xb + (int64_t)tc * a.ldx + (item & 7) * 4;
+    }
+    const u32x4* wsrc[WV];
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+        const int item = i * 256 + tid;
+        const int n = n0 + (item >> 3);
+        wsrc[i] = reinterpret_cast<const u32x4*>(a.wh) + (size_t)(n < a.N ? n : a.N - 1) * 8 + (item & 7);
+    }
+    const size_t wstep = (size_t)a.N * 8;  // sixteen-byte pieces per chunk of the weight planes
+    const int cin4 = a.Cin - 4;
+
+    f32x4r ra[D][AV];
+    u32x4 rw[D][WV];
+#define Q3_PW_LOAD(J, S)                                                                          \
+    {                                                                                             \
+        const int c0_ = (S) * KC;                                                                 \
+        _Pragma("unroll") for (int i = 0; i < AV; ++i) {                                          \
+            const int c_ = c0_ + ((i * 256 + tid) & 7) * 4;                                       \
+            ra[J][i] = *reinterpret_cast<const f32x4r*>(asrc[i] + (c_ <= cin4 ? c0_ : cin4 - ((i * 256 + tid) & 7) * 4)); \
+        }                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < WV; ++i) rw[J][i] = wsrc[i][(size_t)(S) * wstep];   \
+    }
+#define Q3_PW_STORE(J, S)                                                                         \
+    {                                                                                             \
+        const int c0_ = (S) * KC;                                                                 \
+        _Pragma("unroll") for (int i = 0; i < AV; ++i) {                                          \
+            const int item = i * 256 + tid, r = item >> 3, c4 = (item & 7) * 4;                   \
+            const bool ok_ = aok[i] && c0_ + c4 <= cin4;                                          \
+            const f32x4r v_ = ra[J][i];                                                           \
+            const float4 f_ = ok_ ? make_float4(v_.x, v_.y, v_.z, v_.w) : make_float4(0.f, 0.f, 0.f, 0.f); \
+            uint2 hi, lo;                                                                         \
+            split_h2(f_, hi, lo);                                                                 \
+            uint32_t* dst = &As[r * ROWH + (c4 >> 1)];                                            \
+            *reinterpret_cast<uint2*>(dst) = hi;                                                  \
+            *reinterpret_cast<uint2*>(dst + 16) = lo;                                             \
+        }                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < WV; ++i) {                                          \
+            const int item = i * 256 + tid;                                                       \
+            *reinterpret_cast<u32x4*>(&Ws[(item >> 3) * ROWH + (item & 7) * 4]) = rw[J][i];       \
+        }                                                                                         \
+    }
+#define Q3_PW_STEP(J, GUARD)                                                                      \
+    if (!(GUARD) || s0 + (J) < steps) {                                                           \
+        __syncthreads(); /* the previous step's MFMAs are done with As / Ws */                    \
+        Q3_PW_STORE(J, s0 + (J))                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        { const int nx_ = s0 + (J) + D; Q3_PW_LOAD(J, nx_ < steps ? nx_ : steps - 1) }            \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        __syncthreads();                                                                          \
+        const uint32_t* arow = &As[(wm * 64 + (lane & 15)) * ROWH + 4 * (lane >> 4)];             \
+        const uint32_t* wrow = &Ws[(wn * (BN / 2) + (lane & 15)) * ROWH + 4 * (lane >> 4)];       \
+        uint4 xa[2][4], wa[2][CT], wb[CT];                                                        \
+        _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) {                                        \
+            _Pragma("unroll") for (int p = 0; p < 4; ++p) xa[pl][p] = *reinterpret_cast<const uint4*>(arow + p * 16 * ROWH + pl * 16); \
+            _Pragma("unroll") for (int c = 0; c < CT; ++c) wa[pl][c] = *reinterpret_cast<const uint4*>(wrow + c * 16 * ROWH + pl * 16); \
+        }                                                                                         \
+        _Pragma("unroll") for (int c = 0; c < CT; ++c) wb[c] = f16x8_scale_m11(wa[0][c]);         \
+        _Pragma("unroll") for (int p = 0; p < 4; ++p)                                             \
+            _Pragma("unroll") for (int c = 0; c < CT; ++c) acc[p][c] = mfma_f16(wb[c], xa[1][p], acc[p][c]);    \
+        _Pragma("unroll") for (int p = 0; p < 4; ++p)                                             \
+            _Pragma("unroll") for (int c = 0; c < CT; ++c) acc[p][c] = mfma_f16(wa[1][c], xa[0][p], acc[p][c]); \
+        _Pragma("unroll") for (int p = 0; p < 4; ++p)                                             \
+            _Pragma("unroll") for (int c = 0; c < CT; ++c) acc[p][c] = mfma_f16(wa[0][c], xa[0][p], acc[p][c]); \
+    }
+#define Q3_PW_GROUP(G)                                       \
+    Q3_PW_STEP(0, G) Q3_PW_STEP(1, G)                        \
+    if constexpr (D > 2) { Q3_PW_STEP(2, G) }                \
+    if constexpr (D > 3) { Q3_PW_STEP(3, G) }
+
+    // (the ring is filled in the order the loop refills it -- slot by slot, input pieces then weight pieces -- and the
+    // scheduler may not interleave the slots: the wait counts at the loop header are the worse of the two orders)
+    Q3_PW_LOAD(0, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    Q3_PW_LOAD(1, 1 < steps ? 1 : steps - 1)
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (D > 2) { Q3_PW_LOAD(2, 2 < steps ? 2 : steps - 1) __builtin_amdgcn_sched_barrier(0); }
+    if constexpr (D > 3) { Q3_PW_LOAD(3, 3 < steps ? 3 : steps - 1) __builtin_amdgcn_sched_barrier(0); }
+    int s0 = 0;
+    for (; s0 + D <= steps; s0 += D) { Q3_PW_GROUP(false) }
+    if (s0 < steps) { Q3_PW_GROUP(true) }
+#undef Q3_PW_GROUP
+#undef Q3_PW_STEP
+#undef Q3_PW_STORE
+#undef Q3_PW_LOAD
+
+    scale_acc<CT>(a.wsc, a.N, n0 + wn * (BN / 2), lane, acc);
+    if (a.act != 0) epilogue_tile<CT, true>(a, b, t0 + wm * 64, n0 + wn * (BN / 2), T, lane, acc);
+    else epilogue_tile<CT, false>(a, b, t0 + wm * 64, n0 + wn * (BN / 2), T, lane, acc);
+    if (a.out2) snake_pass<CT>(a, reinterpret_cast<float*>(smem3), b, t0, n0, wn, T, wave, lane, acc, wm);
+}
+
 // ---- fused residual unit -------------------------------------------------------------------------------
 // out = y + conv2(act2(conv1(act1(y)))) (DecoderResidualUnit, SpeechTokenizer.swift:430-437) for the narrow, long blocks
 // (C <= 192 channels at up to 384 k positions per row), which are HBM-bound when every conv is its own launch: six
@@ -934,6 +1082,16 @@ void launch_conv_gemm(const ConvGemmArgs& a, hipStream_t st) {
         Q3_CHECK(a.wsc != nullptr, 3, "conv_gemm: fp16x2 weights without their row scales");
         const size_t smemh = size_t(BM + (a.K - 1) * a.dil + 2 * BN) * ROWH * sizeof(uint32_t);
         const bool pro = a.x2 || a.pre_act || a.snake_ea || a.shift || a.reflect;
+        if (!pro && a.K == 1 && !std::getenv("Q3TTS_CONV_NO_PW")) {  // pointwise: both tiles requested PWD steps ahead (kernel)
+            constexpr int PWD = 2;
+            const size_t smpw = size_t(BM + BN) * ROWH * sizeof(uint32_t);
+            switch (BN) {
+                case 128: hipLaunchKernelGGL((conv_pw_h2_kernel<128, PWD>), grid, block, smpw, st, a); break;
+                case 96: hipLaunchKernelGGL((conv_pw_h2_kernel<96, PWD>), grid, block, smpw, st, a); break;
+                default: hipLaunchKernelGGL((conv_pw_h2_kernel<64, PWD>), grid, block, smpw, st, a); break;
+            }
+            return;
+        }
         auto go = [&](void (*kern)(ConvGemmArgs)) { hipLaunchKernelGGL(kern, grid, block, smemh, st, a); };
         switch (BN) {
             case 128: pro ? go(&conv_gemm_h2_kernel<128, true>) : go(&conv_gemm_h2_kernel<128, false>); break;

@@ -16,7 +16,7 @@ REPS = 3
 
 
 def is_conv(name):
-    return "conv_gemm" in name or "out_conv" in name or "resunit" in name
+    return "conv_gemm" in name or "conv_pw" in name or "out_conv" in name or "resunit" in name
 
 
 def last_decode(rows, key):

@@ -11,7 +11,7 @@ B = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 F = int(sys.argv[4]) if len(sys.argv) > 4 else 200
 PROD = int(sys.argv[5]) if len(sys.argv) > 5 else 3
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-convs = [r for r in rows if "conv_gemm" in r["Kernel_Name"] or "out_conv" in r["Kernel_Name"] or "resunit" in r["Kernel_Name"]]
+convs = [r for r in rows if "conv_gemm" in r["Kernel_Name"] or "conv_pw" in r["Kernel_Name"] or "out_conv" in r["Kernel_Name"] or "resunit" in r["Kernel_Name"]]
 last = convs[-(len(convs) // reps):]
 
 # (label, Cin, N, K, positions per frame, extra output copies, fused-unit flag)
@@ -44,7 +44,7 @@ for (name, cin, n, k, p), r in zip(seq, last):
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     tot += d
     kn = r["Kernel_Name"]
-    nm = "resu" if "resunit" in kn else "h2" if "h2" in kn else "split" if "split" in kn else "fp32" if "conv_gemm" in kn else "out"
+    nm = "resu" if "resunit" in kn else "pw" if "conv_pw" in kn else "h2" if "h2" in kn else "split" if "split" in kn else "fp32" if "conv_gemm" in kn else "out"
     bn = kn[kn.index("<") + 1:kn.index(">")] if "<" in kn else ""
     pos = B * F * p
     macs = pos * cin * n * k
