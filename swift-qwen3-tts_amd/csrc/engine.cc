@@ -1562,7 +1562,7 @@ void Engine::debug_sample(const uint16_t* logits, int rows, int V, const q3tts_s
 }
 
 void Engine::debug_linear(const uint16_t* x, const uint16_t* W, const uint16_t* bias, int M, int K, int N, uint16_t* y) {
-    Q3_CHECK(M >= 1 && M <= 64 && K % 8 == 0 && N >= 1, 3, "debug_linear: unsupported shape");
+    Q3_CHECK(M >= 1 && M <= 1024 && K % 8 == 0 && N >= 1, 3, "debug_linear: unsupported shape");  // > 64 rows: the tall form
     const int Kp = int(align_up(size_t(K), 128)), Np = int(align_up(size_t(N), 16)), Mp = int(align_up(size_t(M), 16));
     uint16_t *dW = nullptr, *dWt = nullptr, *dx = nullptr, *dy = nullptr, *db = nullptr;
     Q3_HIP(hipMalloc(reinterpret_cast<void**>(&dW), size_t(N) * K * 2));

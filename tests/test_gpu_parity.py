@@ -72,6 +72,35 @@ def test_linear_matches_oracle(engines, M, K, N):
     assert (y != yo).mean() < 0.02
 
 
+@pytest.mark.parametrize("M,K,N", [(65, 128, 16), (100, 384, 80), (200, 1024, 1040), (513, 2048, 2064), (1024, 6144, 256)])
+def test_tall_linear_is_the_skinny_linear_bit_for_bit(engines, monkeypatch, M, K, N):
+    """More than 64 rows go through gemm_prefill.hip (LDS-shared tiles, the skinny kernel's wave partials run as phases):
+    the same bits as gemm_decode.hip on ragged shapes -- a single k chunk, fewer chunks than phases, tile counts that are
+    no multiple of a workgroup's tile, rows that are no multiple of its row blocks -- with both tile shapes, and within
+    the bar against the oracle."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(M + K + N)
+    x = f2b(rng.standard_normal((M, K)))
+    W = f2b(rng.standard_normal((N, K)) * 0.03)
+    m = engines["tiny-a"]
+    for k in ("Q3TTS_NO_TALL_GEMM", "Q3TTS_TALL_SHAPE"):
+        monkeypatch.delenv(k, raising=False)
+    tall = m.debug_linear(x, W)
+    outs = {}
+    for shape in ("2", "3"):
+        monkeypatch.setenv("Q3TTS_TALL_SHAPE", shape)
+        outs[shape] = m.debug_linear(x, W)
+    monkeypatch.delenv("Q3TTS_TALL_SHAPE")
+    monkeypatch.setenv("Q3TTS_NO_TALL_GEMM", "1")
+    skinny = m.debug_linear(x, W)
+    monkeypatch.delenv("Q3TTS_NO_TALL_GEMM")
+    assert (tall == skinny).all() and (outs["2"] == skinny).all() and (outs["3"] == skinny).all()
+    yo = np.empty((M, N), np.uint16)
+    O.lib().o_linear_bf16(O._p16(x), O._p16(W), None, M, K, N, O._p16(yo))
+    a, b = bf16_to_f32(tall), bf16_to_f32(yo)
+    assert (np.abs(a - b) <= ULP * np.maximum(np.abs(b), 2.0 ** -10)).all()
+
+
 def test_linear_bias_and_silu_free(engines):
     from oracle import oracle as O
     rng = np.random.default_rng(3)
