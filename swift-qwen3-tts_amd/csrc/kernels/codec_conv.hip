@@ -778,6 +778,9 @@ __global__ __launch_bounds__(256, 2) void resunit_h2_kernel(ResUnitArgs a) {
 
     constexpr int AV = ((BMU + MAX_HALO) * 8 + 255) / 256;
     float4 areg[AV];
+    // The raw tile of the NEXT chunk is only requested here; act1 is applied when the tile is staged (store_a), a chunk of
+    // MFMAs later. (With SnakeBeta evaluated inside the load loop the compiler waited for every piece right after asking
+    // for it: ten memory round trips in a row per chunk, in front of the chunk's MFMAs -- most of this kernel's time.)
     auto load_a = [&](int chunk) {
         const int c0 = chunk * KC;
 #pragma unroll
@@ -786,26 +789,29 @@ __global__ __launch_bounds__(256, 2) void resunit_h2_kernel(ResUnitArgs a) {
             const int r = item >> 3, c4 = (item & 7) * 4;
             const int t = t0 - halo + r;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < rows && t >= -a.hist && t < T) {
-                v = ld16f(yb + (int64_t)t * C + c0 + c4);
-                const float4 ea = *reinterpret_cast<const float4*>(a.ea1 + c0 + c4);
-                const float4 ib = *reinterpret_cast<const float4*>(a.ib1 + c0 + c4);
+            if (r < rows && t >= -a.hist && t < T) v = ld16f(yb + (int64_t)t * C + c0 + c4);
+            areg[i] = v;
+        }
+    };
+    auto store_a = [&](int chunk) {
+        const int c0 = chunk * KC, c4 = (tid & 7) * 4;  // a thread's pieces all sit in the same four channels
+        const float4 ea = *reinterpret_cast<const float4*>(a.ea1 + c0 + c4);
+        const float4 ib = *reinterpret_cast<const float4*>(a.ib1 + c0 + c4);
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int item = i * 256 + tid;
+            const int r = item >> 3;
+            if (r >= rows) continue;
+            const int t = t0 - halo + r;
+            float4 v = areg[i];
+            if (t >= -a.hist && t < T) {  // (rows outside the sequence stay zero: causal padding is not activated)
                 v.x = v.x + ib.x * snake_sin2(v.x * ea.x);
                 v.y = v.y + ib.y * snake_sin2(v.y * ea.y);
                 v.z = v.z + ib.z * snake_sin2(v.z * ea.z);
                 v.w = v.w + ib.w * snake_sin2(v.w * ea.w);
             }
-            areg[i] = v;
-        }
-    };
-    auto store_a = [&]() {
-#pragma unroll
-        for (int i = 0; i < AV; ++i) {
-            const int item = i * 256 + tid;
-            const int r = item >> 3, c4 = (item & 7) * 4;
-            if (r >= rows) continue;
             uint2 hi, lo;
-            split_h2(areg[i], hi, lo);
+            split_h2(v, hi, lo);
             uint32_t* dst = &As[r * ROWH + (c4 >> 1)];
             *reinterpret_cast<uint2*>(dst) = hi;
             *reinterpret_cast<uint2*>(dst + 16) = lo;
@@ -818,7 +824,7 @@ __global__ __launch_bounds__(256, 2) void resunit_h2_kernel(ResUnitArgs a) {
     int buf = 0;
     for (int chunk = 0; chunk < NCH; ++chunk) {
         __syncthreads();  // the previous chunk's MFMAs are done with As (and, single-buffered, with Ws)
-        store_a();
+        store_a(chunk);
         if (chunk + 1 < NCH) load_a(chunk + 1);
         for (int tap = 0; tap < a.K; ++tap) {
             const int step = chunk * a.K + tap;
