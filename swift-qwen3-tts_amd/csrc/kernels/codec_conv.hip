@@ -215,22 +215,47 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
     // requested while the MFMAs of chunk c run, so only the first chunk exposes the global-memory latency (pointwise
     // convs have a single tap per chunk: their 0.85 us of MFMA work used to sit behind a 1.5 us load every chunk).
     constexpr int AV = ((BM + MAX_HALO) * 8 + 255) / 256;  // float4 per thread per chunk
-    float4 areg[AV];
+    float4 areg[AV], areg2[AV];
+    // load_a only REQUESTS the pieces (and the optional second input's); the prologue (pre-add, ELU, SnakeBeta) is applied
+    // when the tile is staged, a chunk of MFMAs later: with expf / sinf between one piece's load and the next the compiler
+    // waited for every piece right after asking for it -- one memory round trip per piece, ahead of the chunk's MFMAs.
+    auto row_of = [&](int r) {
+        int t = t0 - halo + a.shift + r;
+        if (a.reflect) t = t < 0 ? -t : (t >= T ? 2 * (T - 1) - t : t);
+        return t;
+    };
     auto load_a = [&](int chunk) {
         const int c0 = chunk * KC;
 #pragma unroll
         for (int i = 0; i < AV; ++i) {
             const int item = i * 256 + tid;
             const int r = item >> 3, c4 = (item & 7) * 4;
-            int t = t0 - halo + a.shift + r;
-            if (a.reflect) t = t < 0 ? -t : (t >= T ? 2 * (T - 1) - t : t);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int t = row_of(r);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f), u = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < rows && t >= -a.hist && t < T && c0 + c4 < a.Cin) {
                 v = ld16f(xb + (int64_t)t * a.ldx + c0 + c4);
-                if (x2b) {
-                    const float4 u = *reinterpret_cast<const float4*>(x2b + (int64_t)t * a.ldx2 + c0 + c4);
-                    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-                }
+                if (x2b) u = *reinterpret_cast<const float4*>(x2b + (int64_t)t * a.ldx2 + c0 + c4);
+            }
+            areg[i] = v;
+            areg2[i] = u;
+        }
+    };
+    auto store_a = [&](int chunk) {
+        const int c0 = chunk * KC, c4 = (tid & 7) * 4;  // a thread's pieces all sit in the same four channels
+        float4 ea = make_float4(0.f, 0.f, 0.f, 0.f), ib = ea;
+        if (a.snake_ea && c0 + c4 < a.Cin) {
+            ea = *reinterpret_cast<const float4*>(a.snake_ea + c0 + c4);
+            ib = *reinterpret_cast<const float4*>(a.snake_ib + c0 + c4);
+        }
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int item = i * 256 + tid;
+            const int r = item >> 3;
+            if (r >= rows) continue;
+            const int t = row_of(r);
+            float4 v = areg[i];
+            if (t >= -a.hist && t < T && c0 + c4 < a.Cin) {  // (padding rows and channels stay zero: not activated)
+                if (x2b) { v.x += areg2[i].x; v.y += areg2[i].y; v.z += areg2[i].z; v.w += areg2[i].w; }
                 if (a.pre_act == 1) {  // ELU, alpha 1 (SpeechTokenizerEncoder.swift:1075-1077)
                     v.x = v.x > 0.f ? v.x : expf(v.x) - 1.0f;
                     v.y = v.y > 0.f ? v.y : expf(v.y) - 1.0f;
@@ -238,8 +263,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
                     v.w = v.w > 0.f ? v.w : expf(v.w) - 1.0f;
                 }
                 if (a.snake_ea) {
-                    const float4 ea = *reinterpret_cast<const float4*>(a.snake_ea + c0 + c4);
-                    const float4 ib = *reinterpret_cast<const float4*>(a.snake_ib + c0 + c4);
                     float s;
                     s = sinf(v.x * ea.x); v.x = v.x + ib.x * (s * s);
                     s = sinf(v.y * ea.y); v.y = v.y + ib.y * (s * s);
@@ -247,15 +270,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
                     s = sinf(v.w * ea.w); v.w = v.w + ib.w * (s * s);
                 }
             }
-            areg[i] = v;
-        }
-    };
-    auto store_a = [&]() {
-#pragma unroll
-        for (int i = 0; i < AV; ++i) {
-            const int item = i * 256 + tid;
-            const int r = item >> 3, c4 = (item & 7) * 4;
-            if (r < rows) *reinterpret_cast<float4*>(&As[r * LDS_LD + c4]) = areg[i];
+            *reinterpret_cast<float4*>(&As[r * LDS_LD + c4]) = v;
         }
     };
 
@@ -264,7 +279,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
     int buf = 0;
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         __syncthreads();  // previous chunk's MFMAs are done with As
-        store_a();
+        store_a(chunk);
         if (chunk + 1 < nchunks) load_a(chunk + 1);
         for (int tap = 0; tap < a.K; ++tap) {
             const int step = chunk * a.K + tap;

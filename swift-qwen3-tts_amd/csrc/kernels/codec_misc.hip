@@ -164,26 +164,40 @@ __global__ __launch_bounds__(256) void out_conv_kernel(const float* x, int C, co
     if (t0 >= T) return;
     const float* xb = x + (size_t)b * Tmax * C;
     for (int i = threadIdx.x; i < 7 * C4; i += 256) *reinterpret_cast<float4*>(ws + 4 * i) = *reinterpret_cast<const float4*>(w + 4 * i);
-    {   // (row, 4-channel group) walk without a division per element
+    {   // (row, 4-channel group) walk without a division per element. Eight pieces are requested before the first of them is
+        // activated: with SnakeBeta between one load and the next every piece was a memory round trip of its own.
         int r = threadIdx.x / C4, c4 = threadIdx.x % C4;
         const int dr = 256 / C4, dc = 256 % C4;
         while (r < 70) {
-            const int t = t0 - 6 + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t >= -hist && t < T) {
-                v = *reinterpret_cast<const float4*>(xb + (int64_t)t * C + 4 * c4);
-                const float4 e = *reinterpret_cast<const float4*>(ea + 4 * c4), q = *reinterpret_cast<const float4*>(ib + 4 * c4);
-                v.x = v.x + q.x * snake_sin2(v.x * e.x);
-                v.y = v.y + q.y * snake_sin2(v.y * e.y);
-                v.z = v.z + q.z * snake_sin2(v.z * e.z);
-                v.w = v.w + q.w * snake_sin2(v.w * e.w);
+            float4 raw[8];
+            int rr[8], cc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                rr[u] = r;
+                cc[u] = c4;
+                const int t = t0 - 6 + r;
+                raw[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (r < 70 && t >= -hist && t < T) raw[u] = *reinterpret_cast<const float4*>(xb + (int64_t)t * C + 4 * c4);
+                r += dr;
+                c4 += dc;
+                if (c4 >= C4) {
+                    c4 -= C4;
+                    ++r;
+                }
             }
-            *reinterpret_cast<float4*>(xs + r * ld + 4 * c4) = v;
-            r += dr;
-            c4 += dc;
-            if (c4 >= C4) {
-                c4 -= C4;
-                ++r;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (rr[u] >= 70) continue;
+                const int t = t0 - 6 + rr[u];
+                float4 v = raw[u];
+                if (t >= -hist && t < T) {
+                    const float4 e = *reinterpret_cast<const float4*>(ea + 4 * cc[u]), q = *reinterpret_cast<const float4*>(ib + 4 * cc[u]);
+                    v.x = v.x + q.x * snake_sin2(v.x * e.x);
+                    v.y = v.y + q.y * snake_sin2(v.y * e.y);
+                    v.z = v.z + q.z * snake_sin2(v.z * e.z);
+                    v.w = v.w + q.w * snake_sin2(v.w * e.w);
+                }
+                *reinterpret_cast<float4*>(xs + rr[u] * ld + 4 * cc[u]) = v;
             }
         }
     }
