@@ -182,13 +182,19 @@ __device__ __forceinline__ void sampler_body(const SamplerArgs& a, const FrameEn
 #pragma unroll
     for (int k = 0; k < kElems; ++k) {
         const int i = k * kThreads + tid;
-        raw[k] = i < V ? lrow[i] : (uint16_t)0;
-        was_seen[k] = (want_seen && i < V) ? a.seen[(size_t)b * V + i] : (uint8_t)0;
+        // (addresses clamped, not predicated: behind a predicated load hipcc waits -- s_waitcnt vmcnt(0) -- before it issues
+        // the next one, and the row's two or four logits became as many memory round trips in a row)
+        const int ic = i < V ? i : V - 1;
+        raw[k] = lrow[ic];
+        was_seen[k] = want_seen ? a.seen[(size_t)b * V + ic] : (uint8_t)0;
     }
     const SamplingParams sp = *a.sp;
     const bool row_done = a.finished[b] != 0;
     const int frame = a.n_frames[b];
-    const bool gate = a.advance_gate ? (a.advance_gate[b] != 0) : true;
+    // (read from an address that is always valid, with the other operands: under a branch on the pointer this byte was a
+    // memory round trip of its own behind them)
+    const uint8_t gate_raw = *(a.advance_gate ? a.advance_gate + b : a.finished + b);
+    const bool gate = a.advance_gate ? (gate_raw != 0) : true;
     if (tid < 256) {  // both radix levels' histograms, zeroed under the loads
         hist[0][tid] = 0;
         hist[1][tid] = 0;
