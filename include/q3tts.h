@@ -317,6 +317,11 @@ q3tts_status q3tts_debug_codec_stage(q3tts_model* m, const int32_t* codes, int32
  * take a large batch through in groups of rows. Process-wide. */
 void q3tts_debug_set_codec_scratch(uint64_t bytes);
 
+/* The launchers' diagnostic switches (Q3TTS_GEMM_NO_ROW_SPLIT, Q3TTS_NO_TALL_GEMM, Q3TTS_PF, ...: csrc/kernels.h DebugEnv)
+ * are read from the environment once per q3tts_model_load, not per launch; a test that changes one on a live model calls
+ * this afterwards. Process-wide; not to be called while a generate call is running. */
+void q3tts_debug_reload_env(void);
+
 /* Voice-clone front end with intermediate activations for one waveform. Codec encoder stages
  * (SpeechTokenizerEncoder.swift:1031-1056): "init_conv","layer0".."layer3","seanet","transformer","downsample",
  * "rvq_first_in","rvq_rest_in"; speaker encoder stages (SpeakerEncoder.swift:364-394): "mel","h0".."h3","mfa",

@@ -70,6 +70,7 @@ q3tts_status q3tts_model_load(const char* model_dir, const q3tts_load_opts* opts
     if (out) *out = nullptr;
     return guarded(nullptr, [&] {
         Q3_CHECK(model_dir && out, 3, "Invalid input: null argument");
+        q3::debug_env_reload();  // the launchers' diagnostic switches are read here, once per load (kernels.h DebugEnv)
         q3tts_load_opts o;
         if (opts) o = *opts;
         else q3tts_default_load_opts(&o);
@@ -350,6 +351,8 @@ q3tts_status q3tts_codec_decode_streamed(q3tts_model* m, const int32_t* codes, c
 }
 
 void q3tts_debug_set_codec_scratch(uint64_t bytes) { q3::CodecRunner::set_scratch_budget(size_t(bytes)); }
+
+void q3tts_debug_reload_env(void) { q3::debug_env_reload(); }
 
 q3tts_status q3tts_debug_codec_stage(q3tts_model* m, const int32_t* codes, int32_t n_frames, const char* stage,
                                      float* out, int64_t cap_floats, int32_t* T, int32_t* C) {

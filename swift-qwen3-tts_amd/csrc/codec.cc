@@ -424,6 +424,16 @@ void CodecRunner::stream_open(const StreamCfg& cfg) {
         S.off += floats * sizeof(float);
         return p;
     };
+    // Whatever leaves this function -- the arena allocation failing, a check inside run_tail_stream -- the counting mode
+    // ends with it: conv() launches nothing while `dry` is set, and a runner left in that state would turn every later
+    // decode of the model into launches of the glue kernels alone (finite garbage, status OK).
+    struct DryOff {
+        Stream& s;
+        ~DryOff() {
+            s.dry = false;
+            if (!s.open) s.rolls.clear();
+        }
+    } dry_off{S};
     S.dry = true;
     S.off = 0;
     for (int i = 0; i < 4; ++i) (void)take(S.fbuf_floats);

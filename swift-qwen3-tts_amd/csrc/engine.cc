@@ -303,7 +303,7 @@ void Engine::enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, 
     // 0.22 GB are read fifteen times per step. Non-temporal loads on the former leave the Infinity Cache (256 MB) to the
     // latter: measured 3.53 -> 3.42 ms per 1.7B frame step with both (either one alone: < 1 %; on the predictor's
     // weights as well: 3.62 ms). Q3TTS_NT=0 turns the hint off (diagnostics).
-    static const bool nt_off = std::getenv("Q3TTS_NT") && std::atoi(std::getenv("Q3TTS_NT")) == 0;
+    const bool nt_off = debug_env().nt_off;
     const bool is_talker = &s == &m_->talker;
     const int ntw = is_talker && !nt_off ? 1 : 0;
     const int ntkv = ntw;
@@ -311,7 +311,7 @@ void Engine::enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, 
         NormRowsArgs n{};
         n.h = w.h; n.hMB = MBL; n.w = nw; n.eps = s.eps; n.out = w.xn; n.outMB = MBL; n.M = M; n.H = H;
         if (row_norm && H <= 2048) { n.ss_in = ss; n.ss_count = ss_count; n.ss_ld = Mp_; }
-        launch_norm_rows(n, st_);
+        other([&] { launch_norm_rows(n, st_); });
     };
     for (size_t l = 0; l < s.layers.size(); ++l) {
         const LayerW& L = s.layers[l];
@@ -331,21 +331,21 @@ void Engine::enqueue_layers(const StackW& s, Stream& w, int B, uint16_t* kpool, 
         at.chunk = chunk; at.chunk_n_prompt = chunk_n_prompt; at.chunk_r_base = chunk_r_base;
         at.scale = powf(float(kHeadDim), -0.5f);  // Talker.swift:179
         at.nt_kv = ntkv;
-        launch_gemm_skinny(q, st_);
-        launch_attn_decode(at, st_);
+        gemm(q);
+        attn(at);
         GemmArgs o = gemm_args(L.o, w.ao, M);
         o.epi = 3; o.y = w.h; o.yMB = MBL; o.resid = 1; o.ss_out = w.ss_b; o.nt_weights = ntw;
-        launch_gemm_skinny(o, st_);
+        gemm(o);
         if (!prologue_mlp) norm_into_xn(L.ln2, w.ss_b, tiles);
         GemmArgs g = gemm_args(L.gateup, prologue_mlp ? w.h : w.xn, M);
         g.epi = 2; g.y = w.act; g.yMB = MBL; g.nt_weights = ntw;
         if (prologue_mlp) {
             g.norm_w = L.ln2; g.ss_in = w.ss_b; g.ss_count = tiles; g.norm_dim = H; g.norm_eps = s.eps;
         }
-        launch_gemm_skinny(g, st_);
+        gemm(g);
         GemmArgs d = gemm_args(L.down, w.act, M);
         d.epi = 3; d.y = w.h; d.yMB = MBL; d.resid = 1; d.ss_out = w.ss_a; d.nt_weights = ntw;
-        launch_gemm_skinny(d, st_);
+        gemm(d);
     }
 }
 
@@ -367,7 +367,7 @@ void Engine::enqueue_cp_pass(int B, bool from_talker, int head, int cp_pos, bool
         NormRowsArgs n{};
         n.h = tk_.h; n.hMB = MBL; n.w = m_->talker.final_norm; n.eps = m_->talker.eps;
         n.out = dst; n.outMB = MBL; n.ss_out = ss_out; n.M = B; n.H = H;
-        launch_norm_rows(n, st_);
+        other([&] { launch_norm_rows(n, st_); });
     };
     if (m_->has_cp_proj && projected) {  // the sampler gathered an already projected row and its sums (build_cp_proj_tables)
         ss_count = CH / 16;
@@ -375,7 +375,7 @@ void Engine::enqueue_cp_pass(int B, bool from_talker, int head, int cp_pos, bool
         if (from_talker) talker_norm_into(cp_x2_, nullptr);  // cp_x_ already holds embed(code0) for the second position
         GemmArgs p = gemm_args(m_->cp_proj, from_talker ? cp_x2_ : cp_x_, B);
         p.epi = 3; p.y = cp_.h; p.yMB = MBL; p.resid = 0; p.ss_out = cp_.ss_a;
-        launch_gemm_skinny(p, st_);
+        gemm(p);
         ss_count = CH / 16;
     } else if (from_talker) {
         talker_norm_into(cp_.h, cp_.ss_a);
@@ -384,7 +384,7 @@ void Engine::enqueue_cp_pass(int B, bool from_talker, int head, int cp_pos, bool
     enqueue_layers(m_->cp, cp_, B, cp_kpool_, cp_vpool_, cp_kv_layer_stride_, cp_block_table_, 1, cp_len_, nullptr, ss_count, cp_pos, 1, nullptr, 0);
 }
 
-void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
+void Engine::enqueue_frame_body(int B, const DebugOpts* dbg) {
     const TalkerConfig& t = m_->cfg.talker;
     const int H = t.hidden_size, V = t.vocab_size, Vc = t.cp.vocab_size, CH = t.cp.hidden_size;
     const int groups = t.num_code_groups, MBL = Mp_ / 16;
@@ -409,10 +409,10 @@ void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
             NormRowsArgs n{};
             n.h = tk_.h; n.hMB = MBL; n.w = m_->talker.final_norm; n.eps = m_->talker.eps;
             n.out = next_x; n.outMB = MBL; n.ss_out = next_ss; n.M = B; n.H = H;
-            rode = launch_gemm_skinny_with_norm_rows(hd, n, st_);
-            if (!rode) launch_norm_rows(n, st_);
+            rode = gemm_with_norm_rows(hd, n);
+            if (!rode) other([&] { launch_norm_rows(n, st_); });
         }
-        if (!rode) launch_gemm_skinny(hd, st_);
+        if (!rode) gemm(hd);
     }
     SamplerArgs sa{};
     sa.logits = tk_.logits; sa.ldl = tk_.ld_logits; sa.V = V; sa.sp = sp_dev_; sa.is_talker = 1;
@@ -432,12 +432,12 @@ void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
     }
     sa.logits_dump = (dbg && dbg->talker_logits) ? tl_dump_ : nullptr; sa.dump_ld = V; sa.dump_off = 0;
     if (pair) {
-        launch_sampler(sa, st_);
+        other([&] { launch_sampler(sa, st_); });
         int ss_count = 1;
         if (m_->has_cp_proj) {  // small_to_mtp_projection over both positions (CodePredictor.swift:327-330)
             GemmArgs p = gemm_args(m_->cp_proj, cp_x_, 2 * B);
             p.epi = 3; p.y = cp_.h; p.yMB = MBL; p.resid = 0; p.ss_out = cp_.ss_a;
-            launch_gemm_skinny(p, st_);
+            gemm(p);
             ss_count = CH / 16;
         }
         stamp(2);
@@ -445,12 +445,12 @@ void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
                        nullptr, 0);
         stamp(3);  // (no launch for cp_len_: the predictor's attention takes its cache length from the pass index, fixed_len)
     } else {
-        launch_sampler(sa, st_);
+        other([&] { launch_sampler(sa, st_); });
         // code predictor, step 0 = [hidden, embed(code0)] run as two positions
         enqueue_cp_pass(B, true, -1, 0);
         if (!m_->has_cp_proj) {  // second position: move the staged embedding (and its sum of squares) into place
-            launch_copy_rows(cp_x2_, 0, cp_.h, 0, 1, Mp_ * H, st_);
-            launch_copy_rows(reinterpret_cast<const uint16_t*>(cp_ss2_), 0, reinterpret_cast<uint16_t*>(cp_.ss_a), 0, 1, Mp_ * 2, st_);
+            other([&] { launch_copy_rows(cp_x2_, 0, cp_.h, 0, 1, Mp_ * H, st_); });
+            other([&] { launch_copy_rows(reinterpret_cast<const uint16_t*>(cp_ss2_), 0, reinterpret_cast<uint16_t*>(cp_.ss_a), 0, 1, Mp_ * 2, st_); });
         }
     }
     FrameEndArgs fe{};
@@ -470,7 +470,7 @@ void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
             GemmArgs lh = gemm_args(m_->lm_head[size_t(i)], cp_.h, Mh);
             lh.epi = 0; lh.y = cp_.logits; lh.ldy = cp_.ld_logits;
             lh.norm_w = m_->cp.final_norm; lh.ss_in = cp_.ss_a; lh.ss_count = CH / 16; lh.norm_dim = CH; lh.norm_eps = m_->cp.eps;
-            launch_gemm_skinny(lh, st_);
+            gemm(lh);
         }
         SamplerArgs sc{};
         sc.logits = cp_.logits + (second_of_pair ? size_t(B) * cp_.ld_logits : 0); sc.ldl = cp_.ld_logits; sc.V = Vc; sc.sp = sp_dev_;
@@ -490,15 +490,143 @@ void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
         }
         sc.logits_dump = (dbg && dbg->cp_logits) ? cl_dump_ : nullptr; sc.dump_ld = (groups - 1) * Vc; sc.dump_off = i * Vc;
         if (i == groups - 2 && Vc <= 2048) {  // the frame's last draw carries its row's end-of-frame job (Qwen3.swift:919-935; row_jobs.h)
-            launch_sampler_with_frame_end(sc, fe, st_);
+            other([&] { launch_sampler_with_frame_end(sc, fe, st_); });
             fe_done = true;
         } else {
-            launch_sampler(sc, st_);
+            other([&] { launch_sampler(sc, st_); });
         }
         stamp(second_of_pair ? 4 : 6);
     }
-    if (!fe_done) launch_frame_end(fe, st_);
+    if (!fe_done) other([&] { launch_frame_end(fe, st_); });
     stamp(7);
+}
+
+
+// ---- the plan: which later launch's weight lines each launch of the frame step touches (kernels/prefetch.h) ------------
+namespace {
+PfArgs empty_touch(const void* valid) {
+    PfArgs p{};
+    p.base = static_cast<const uint8_t*>(valid);
+    p.span = 128; p.lines = 1; p.inv_lines = 1.0f;
+    return p;
+}
+}  // namespace
+
+void Engine::gemm(GemmArgs a) {
+    if (plan_mode_ == 1) {
+        PlanItem it{};
+        const SkinnyGeom g = skinny_geometry(a);
+        if (!g.tall) {
+            it.w = reinterpret_cast<const uint8_t*>(a.W);
+            it.span = uint32_t(g.span_bytes(a));
+            it.nspan = uint32_t(g.gx);
+            if (g.touches) it.cap_lines = uint32_t(kPfTouches) * uint32_t((g.gx * g.split + 7) / 8) * uint32_t(g.threads());
+        }
+        plan_.push_back(it);
+        return;
+    }
+    a.pf = plan_mode_ == 2 ? pf_[plan_pos_++] : empty_touch(a.W);
+    launch_gemm_skinny(a, st_);
+}
+
+bool Engine::gemm_with_norm_rows(GemmArgs a, const NormRowsArgs& n) {
+    if (plan_mode_ == 1) {
+        // recorded as the plain launch; whether the riders fit is decided by the launcher's own test in both passes
+        const bool rides = gemm_norm_rows_rides(a, n);
+        if (rides) gemm(a);
+        return rides;
+    }
+    a.pf = plan_mode_ == 2 ? pf_[plan_pos_] : empty_touch(a.W);
+    const bool rode = launch_gemm_skinny_with_norm_rows(a, n, st_);
+    if (rode && plan_mode_ == 2) ++plan_pos_;
+    return rode;
+}
+
+void Engine::attn(AttnArgs a) {
+    if (plan_mode_ == 1) {
+        PlanItem it{};
+        if (Q3_PF_MODE != 0 && a.chunk <= 1) it.cap_lines = uint32_t(kPfTouches) * uint32_t((a.n_kv * a.B + 7) / 8) * uint32_t(attn_decode_threads(a));
+        plan_.push_back(it);
+        return;
+    }
+    a.pf = plan_mode_ == 2 ? pf_[plan_pos_++] : empty_touch(a.qkv);
+    launch_attn_decode(a, st_);
+}
+
+// Greedy, in launch order, over the frame step taken as a cycle (the graph is replayed back to back: the last launches of a
+// step touch the first weights of the next): launch i looks up to `ahead` launches forward for the nearest weight stream
+// that is not yet fully touched and takes as many of its lines as (a) its own threads can touch and (b) the per-XCD budget of
+// lines sitting touched-but-unread in an L2 allows. A stream's lines are counted per XCD: the spans x' = c (mod 8) belong to
+// XCD c, floor(nspan / 8) of them for every c.
+void Engine::plan_touches() {
+    const DebugEnv& env = debug_env();
+    const size_t n = plan_.size();
+    pf_.assign(n, PfArgs{});
+    const int64_t budget = int64_t(env.pf_budget_kb) * 1024 / 128;
+    const int ahead = std::max(1, env.pf_ahead);
+    std::vector<int64_t> touched(3 * n + size_t(ahead) + 1, 0);
+    int64_t resident = 0;
+    for (size_t v = 0; v < 2 * n; ++v) {  // two rounds: the first only sets up what the end of a step leaves for the next
+        const PlanItem& me = plan_[v % n];
+        resident -= touched[v];
+        PfArgs p = empty_touch(ws_);
+        if (env.prefetch && me.cap_lines > 0) {
+            int skip = env.pf_skip;
+            for (size_t j = v + 1; j <= v + size_t(ahead); ++j) {
+                const PlanItem& t = plan_[j % n];
+                if (!t.w || t.nspan < 8 || t.span % 128 != 0) continue;
+                if (skip-- > 0) continue;
+                const int64_t lines = t.span / 128, total = int64_t(t.nspan / 8) * lines;
+                if (total >= (int64_t(1) << 22)) continue;  // pf_issue's exact-division range
+                const int64_t rem = total - touched[j];
+                if (rem <= 0) continue;
+                const int64_t amt = std::min<int64_t>({rem, int64_t(me.cap_lines), budget - resident});
+                if (amt <= 0) break;
+                p.base = t.w;
+                p.span = t.span;
+                p.lines = uint32_t(lines);
+                p.inv_lines = 1.0f / float(lines);
+                p.u0 = uint32_t(touched[j]);
+                p.u1 = uint32_t(touched[j] + amt);
+                touched[j] += amt;
+                resident += amt;
+                break;
+            }
+        }
+        if (v >= n) pf_[v - n] = p;
+    }
+}
+
+void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
+    if (Q3_PF_MODE == 0) {  // the shipped build: no kernel carries the touch code, nothing to plan
+        enqueue_frame_body(B, dbg);
+        return;
+    }
+    auto it = pf_plans_.find(B);
+    if (it == pf_plans_.end()) {
+        plan_mode_ = 1;
+        plan_.clear();
+        try {
+            enqueue_frame_body(B, dbg);
+        } catch (...) {
+            plan_mode_ = 0;
+            throw;
+        }
+        plan_mode_ = 0;
+        plan_touches();
+        it = pf_plans_.emplace(B, pf_).first;
+    }
+    pf_ = it->second;
+    plan_mode_ = 2;
+    plan_pos_ = 0;
+    try {
+        enqueue_frame_body(B, dbg);
+    } catch (...) {
+        plan_mode_ = 0;
+        throw;
+    }
+    plan_mode_ = 0;
+    Q3_CHECK(plan_pos_ == pf_.size(), 7, "internal error: the frame step's launches do not match their plan");
 }
 
 hipGraphExec_t Engine::frame_graph(int B) {

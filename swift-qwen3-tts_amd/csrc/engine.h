@@ -186,7 +186,32 @@ class Engine {
 
     unsigned long long* stamps_ = nullptr;  // Q3TTS_FRAME_STAMPS=1: [0] frame steps, [k] ticks of phase k, [63] last stamp
     void stamp(int k) {
-        if (stamps_) launch_stamp(stamps_, stamps_ + 63, k, st_);
+        if (stamps_) other([&] { launch_stamp(stamps_, stamps_ + 63, k, st_); });
+    }
+    // ---- next-launch weight touch (kernels/prefetch.h) -----------------------------------------------------------------
+    // A frame step is enqueued twice: a recording pass in which every launch site only notes what it would launch (the weight
+    // stream it reads, whether its kernel carries the touch code and how many lines it can touch), then the real pass, in which
+    // launch i receives the descriptor plan_touches() chose for it. plan_mode_ 0: launch sites launch directly (prefill, load).
+    struct PlanItem {
+        const uint8_t* w = nullptr;  // weight stream this launch reads (nullptr: none worth touching ahead)
+        uint32_t span = 0, nspan = 0;
+        uint32_t cap_lines = 0;      // lines per XCD this launch can touch (0: its kernel has no touch code)
+    };
+    int plan_mode_ = 0;  // 0 off, 1 recording, 2 replaying
+    std::vector<PlanItem> plan_;
+    std::vector<PfArgs> pf_;
+    size_t plan_pos_ = 0;
+    std::map<int, std::vector<PfArgs>> pf_plans_;  // keyed by batch size
+    void plan_touches();
+    void enqueue_frame_body(int B, const DebugOpts* dbg);
+    void gemm(GemmArgs a);                     // launch_gemm_skinny through the plan
+    bool gemm_with_norm_rows(GemmArgs a, const NormRowsArgs& n);
+    void attn(AttnArgs a);                     // launch_attn_decode through the plan
+    template <class F>
+    void other(F&& f) {                        // any launch that neither streams weights worth touching nor touches
+        if (plan_mode_ == 1) { plan_.emplace_back(); return; }
+        if (plan_mode_ == 2) ++plan_pos_;
+        f();
     }
     std::map<int, hipGraphExec_t> graphs_;  // keyed by batch size
     std::unique_ptr<CodecRunner> codec_;

@@ -6,7 +6,29 @@
 
 #include <cstdint>
 
+#include "kernels/prefetch.h"
+
 namespace q3 {
+
+// Diagnostic switches of the launchers, read from the environment ONCE (first use) and again only on request
+// (q3tts_debug_reload_env; the Python mirror calls it at every model load): a frame step is ~550 launches, and getenv per
+// launch both costs host time on the eager path and races with a test's setenv on another lane's thread.
+struct DebugEnv {
+    bool gemm_no_row_split;  // Q3TTS_GEMM_NO_ROW_SPLIT: row blocks of narrow layers stay in one workgroup
+    bool gemm_one_pair;      // Q3TTS_GEMM_ONE_PAIR: one weight tile per workgroup everywhere
+    bool no_tall_gemm;       // Q3TTS_NO_TALL_GEMM: prefill chunks through the skinny kernels
+    int tall_shape;          // Q3TTS_TALL_SHAPE = 2 | 3: force one tile shape of the tall GEMM (0: automatic)
+    int chunk_qsplit;        // Q3TTS_CHUNK_QSPLIT: workgroups sharing a chunk's queries (0: automatic)
+    bool conv_no_pw;         // Q3TTS_CONV_NO_PW: pointwise convs through the general conv kernel
+    bool nt_off;             // Q3TTS_NT=0: no non-temporal loads on the talker's weights / cache
+    int prefetch;            // Q3TTS_PF: 0 = launches touch nothing ahead, 1 (default) = next-launch weight touch (prefetch.h;
+                             // only builds with Q3_PF_MODE != 0 carry the touch code -- the shipped one does not)
+    int pf_budget_kb;        // Q3TTS_PF_BUDGET_KB: bytes per XCD that may sit touched-ahead in its L2
+    int pf_ahead;            // Q3TTS_PF_AHEAD: how many launches ahead a launch may look for a stream to touch
+    int pf_skip;             // Q3TTS_PF_SKIP: pass over this many candidate streams first (experiments: which stream pays)
+};
+const DebugEnv& debug_env();
+void debug_env_reload();
 
 constexpr int kPageTokens = 64;  // tokens per KV page
 constexpr int kHeadDim = 128;    // Qwen3-TTS talker / code predictor head_dim (Config.swift:154,301)
@@ -52,8 +74,24 @@ struct GemmArgs {
     int nt_weights;          // 1: load the weight tiles non-temporally (read once per step, working set >> Infinity Cache)
     int resid;               // 1: y = bf16(y_old + bf16(acc+bias)); 0: y = bf16(acc+bias)
     float* ss_out;           // [N/16][ss_ld] this tile's share of sum(y^2) per row, or nullptr
+    PfArgs pf;               // weight tiles of a later launch to touch (prefetch.h); decode-shaped launches only
 };
 void launch_gemm_skinny(const GemmArgs& a, hipStream_t st);
+// The launch launch_gemm_skinny makes for these arguments -- ONE place decides it (the plain launch, the launch with riders
+// and the engine's prefetch planner all read it here).
+struct SkinnyGeom {
+    bool tall;         // the tall (prefill) kernel takes it: none of the rest applies
+    int split, mbw;    // grid.y, row blocks per workgroup
+    int nw, ch, np;    // waves, k chunks per wave (0: streamed), weight tiles per workgroup
+    int gx;            // grid.x
+    bool ntw;          // non-temporal weight loads
+    bool touches;      // the kernel carries the touch-ahead code (decode shapes: at most two row blocks, chunks in registers)
+    int threads() const { return nw * 64; }
+    // bytes of W that workgroup x streams, contiguous from x * span_bytes
+    size_t span_bytes(const GemmArgs& a) const { return size_t(np) * size_t(a.K / 128) * (a.Wsb ? 1024 : 4096); }
+};
+SkinnyGeom skinny_geometry(const GemmArgs& a);
+constexpr bool gemm_touches(int mb, int ch) { return Q3_PF_MODE != 0 && Q3_PF_GEMM && mb <= 2 && ch > 0; }  // which instantiations carry the touch-ahead code
 // The same launch with riders (kernels/row_jobs.h): n.M extra workgroups, each the RMSNorm of one row -- a job that reads what
 // this GEMM reads and nothing it writes, so it shares the launch instead of paying its own. Only the shapes of the talker's
 // codec_head (EPI 0 with norm prologue, K = 1024 or 2048, at most 32 rows per workgroup); returns false (nothing launched)
@@ -62,7 +100,9 @@ void launch_gemm_skinny(const GemmArgs& a, hipStream_t st);
 // More than 64 rows, plain bf16 weights, no prologue / bias: the tall form (gemm_prefill.hip), bit-identical to the skinny one.
 // launch_gemm_skinny tries it first; false = nothing launched (shape or options it does not take).
 bool launch_gemm_tall(const GemmArgs& a, hipStream_t st);
+bool gemm_tall_takes(const GemmArgs& a);  // whether launch_gemm_tall would launch (same test, nothing enqueued)
 bool launch_gemm_skinny_with_norm_rows(const GemmArgs& a, const NormRowsArgs& n, hipStream_t st);
+bool gemm_norm_rows_rides(const GemmArgs& a, const NormRowsArgs& n);  // whether the call above would launch
 
 
 // ---- QK-norm + RoPE + KV append + paged decode attention (attn_decode.hip) ---------------------
@@ -94,8 +134,10 @@ struct AttnArgs {
     const int32_t* chunk_n_prompt;
     int chunk_r_base;
     int nt_kv;           // 1: cache rows are loaded non-temporally (long caches read once per step)
+    PfArgs pf;           // weight tiles of a later launch to touch (prefetch.h); one-position launches only
 };
 void launch_attn_decode(const AttnArgs& a, hipStream_t st);
+int attn_decode_threads(const AttnArgs& a);  // threads per workgroup of the one-position launch for these arguments
 
 struct FrameEndArgs {  // Qwen3.swift:919-935 + loop bookkeeping
     const int32_t* cur_codes;     // [B][16]

@@ -201,7 +201,20 @@ __global__ __launch_bounds__(NTH) void attn_chunk_kernel(AttnArgs a) {
 
 }  // namespace
 
-void launch_attn_decode(const AttnArgs& a, hipStream_t st) {
+int attn_decode_threads(const AttnArgs& a) {
+    const int rep = a.n_heads / a.n_kv;
+    return (a.max_pages > 1 && rep <= 2) ? 512 : 256;
+}
+
+void launch_attn_decode(const AttnArgs& a0, hipStream_t st) {
+    AttnArgs a = a0;
+    if (!a.pf.base) {  // a caller outside the frame step's plan: an empty range on a valid address
+        a.pf = PfArgs{};
+        a.pf.base = reinterpret_cast<const uint8_t*>(a.qkv);
+        a.pf.span = 128; a.pf.lines = 1; a.pf.inv_lines = 1.0f;
+    }
+    a.pf.gx = uint32_t(a.n_kv);  // this launch's own geometry for its touch descriptor (prefetch.h)
+    a.pf.wg_per_xcd = uint32_t((a.n_kv * a.B + 7) / 8);
     const int rep = a.n_heads / a.n_kv;
     Q3_CHECK(rep * a.n_kv == a.n_heads && rep >= 1 && rep <= kMaxRep, 3, "attn_decode: unsupported GQA ratio");
     dim3 grid(a.n_kv, a.B);
@@ -214,8 +227,8 @@ void launch_attn_decode(const AttnArgs& a, hipStream_t st) {
     if (a.chunk > 1) {
         Q3_CHECK(a.chunk <= 16, 3, "attn_decode: at most 16 positions per launch");
         // two workgroups share the queries of a long chunk (prefill), one takes a short one (the predictor's step 0)
-        const char* qenv = std::getenv("Q3TTS_CHUNK_QSPLIT");
-        const int nqs = qenv ? std::max(1, std::min(a.chunk, std::atoi(qenv))) : (a.chunk > 8 ? 2 : 1);
+        const int qenv = debug_env().chunk_qsplit;
+        const int nqs = qenv > 0 ? std::max(1, std::min(a.chunk, qenv)) : (a.chunk > 8 ? 2 : 1);
         const dim3 cgrid(a.n_kv, a.B, nqs);
 #define Q3_CHUNK(REPv, NTHv)                                                                                        \
     do {                                                                                                            \

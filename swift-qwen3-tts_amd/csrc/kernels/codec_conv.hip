@@ -25,9 +25,11 @@
 // consecutive channels of one position -> 16-byte epilogue loads/stores.
 // LDS rows are padded to 40 floats: conflict-free for ds_read_b128 (MI355X_MICROARCH.md LDS table).
 #include <cstdlib>
+#include <mutex>
 
 #include "../common.h"
 #include "../codec_kernels.h"
+#include "../kernels.h"
 #include "snake.h"
 
 namespace q3 {
@@ -1054,13 +1056,12 @@ void launch_resunit(const ResUnitArgs& a0, hipStream_t st) {
     Q3_CHECK(resunit_supported(a.C, a.K, a.dil) && a.out != a.y, 3, "resunit: unsupported geometry");
     Q3_CHECK(a.w1h && a.w2ph && a.wsc1 && a.wsc2, 3, "resunit: incomplete fp16x2 weights");
     if (a.Tmax <= 0 || a.B <= 0) return;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;  // (lanes launch from their own threads)
+    std::call_once(attr_once, [] {
         void (*ks[4])(ResUnitArgs) = {&resunit_h2_kernel<2, 2>, &resunit_h2_kernel<4, 2>, &resunit_h2_kernel<6, 4>, &resunit_h2_kernel<12, 2>};
         for (auto k : ks)
             Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        attr_set = true;
-    }
+    });
     const int bmu = a.C == 96 ? 256 : 128;  // positions per workgroup (64 PT)
     const int rows = bmu + (a.K - 1) * a.dil;
     // conv1's weight tiles are double-buffered (one barrier per tap instead of two) where two workgroups still share a CU
@@ -1087,8 +1088,8 @@ void launch_conv_gemm(const ConvGemmArgs& a, hipStream_t st) {
     else if (a.N % 96 == 0) BN = 96;
     else if (a.N > 128 && (a.N % 64) != 0) BN = 128;
     dim3 grid((a.N + BN - 1) / BN, mt, a.B), block(256);
-    static bool attr_set = false;
-    if (!attr_set) {  // 160 KiB of LDS per CU on gfx950; the default static cap is 64 KiB
+    static std::once_flag attr_once;  // (lanes launch from their own threads)
+    std::call_once(attr_once, [] {  // 160 KiB of LDS per CU on gfx950; the default static cap is 64 KiB
         Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<96>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
@@ -1097,13 +1098,12 @@ void launch_conv_gemm(const ConvGemmArgs& a, hipStream_t st) {
                                                 &conv_gemm_h2_kernel<64, true>,  &conv_gemm_h2_kernel<64, false>};
         for (auto k : h2_kernels)
             Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-        attr_set = true;
-    }
+    });
     if (a.wh) {
         Q3_CHECK(a.wsc != nullptr, 3, "conv_gemm: fp16x2 weights without their row scales");
         const size_t smemh = size_t(BM + (a.K - 1) * a.dil + 2 * BN) * ROWH * sizeof(uint32_t);
         const bool pro = a.x2 || a.pre_act || a.snake_ea || a.shift || a.reflect;
-        if (!pro && a.K == 1 && !std::getenv("Q3TTS_CONV_NO_PW")) {  // pointwise: both tiles requested PWD steps ahead (kernel)
+        if (!pro && a.K == 1 && !debug_env().conv_no_pw) {  // pointwise: both tiles requested PWD steps ahead (kernel)
             constexpr int PWD = 2;
             const size_t smpw = size_t(BM + BN) * ROWH * sizeof(uint32_t);
             switch (BN) {

@@ -26,8 +26,6 @@
 //     through LDS in fixed wave order -> results do not depend on batch size or launch geometry
 //     (row independence is the batching contract). CH (chunks per wave) is a template
 //     parameter so every weight load of a wave is issued before its first MFMA.
-#include <cstdlib>
-
 #include "../common.h"
 #include "../kernels.h"
 #include "row_jobs.h"
@@ -62,46 +60,47 @@ __global__ __launch_bounds__(512) void gemm_skinny_side_kernel(GemmSideArgs s) {
     gemm_skinny_body<MB, 0, 8, CH, true, QUANT, 1, false>(s.g, blockIdx.x, blockIdx.y * MB);
 }
 
+// a with the launch's own geometry written into its touch descriptor (prefetch.h: gx, wg_per_xcd)
+inline GemmArgs with_geometry(const GemmArgs& a, const dim3& grid) {
+    GemmArgs b = a;
+    if (!b.pf.base) {  // a caller outside the frame step's plan: an empty range on a valid address (the touch loads are unconditional)
+        b.pf = PfArgs{};
+        b.pf.base = reinterpret_cast<const uint8_t*>(a.W);
+        b.pf.span = 128; b.pf.lines = 1; b.pf.inv_lines = 1.0f;
+    }
+    b.pf.gx = grid.x;
+    b.pf.wg_per_xcd = (grid.x * grid.y + 7) / 8;
+    return b;
+}
+
 template <int MB, int EPI, bool NORM, bool QUANT, bool NTW>
-void launch_mb(const GemmArgs& a, int split, hipStream_t st) {
-    const int KC = a.K / 128;
-    const int nw = KC <= 4 ? 4 : 8;  // no idle waves on short K
-    const int ch = (KC + nw - 1) / nw;
-    const int tiles = EPI == 2 ? a.N / 8 : a.N / 16;  // EPI 2: eight columns per (gate | up) tile
+void launch_mb(const GemmArgs& a0, const SkinnyGeom& g, hipStream_t st) {
+    const dim3 grid(g.gx, g.split);
+    const GemmArgs a = with_geometry(a0, grid);
 #define Q3_GEMM(NWv, CHv) \
-    hipLaunchKernelGGL((gemm_skinny_kernel<MB, EPI, NWv, CHv, NORM, QUANT, 1, NTW>), dim3(tiles, split), dim3(NWv * 64), 0, st, a)
+    hipLaunchKernelGGL((gemm_skinny_kernel<MB, EPI, NWv, CHv, NORM, QUANT, 1, NTW>), grid, dim3(NWv * 64), 0, st, a)
     if constexpr (MB == 4 && !NORM && !NTW) {
-        // prefill chunks: four tiles per workgroup through the chunk-streaming form (CH = 0)
-        const bool one_tile = std::getenv("Q3TTS_GEMM_ONE_PAIR") != nullptr;
-        if (!one_tile && nw == 8 && tiles >= 64) {
-            // four tiles per workgroup quarter the x traffic (every workgroup reads all K of its 64 rows), but a narrow layer
-            // (o_proj / down_proj: 128 tiles) is then 128 workgroups on 256 CUs: two tiles each there (prefill 17.0 -> 14.2 ms
-            // at 1.7B / batch 32; one tile each: 15.5)
-            if (((tiles + 3) / 4) * split <= 128)
-                hipLaunchKernelGGL((gemm_skinny_kernel<4, EPI, 8, 0, false, QUANT, 2, false>), dim3((tiles + 1) / 2, split), dim3(512), 0, st, a);
-            else
-                hipLaunchKernelGGL((gemm_skinny_kernel<4, EPI, 8, 0, false, QUANT, 4, false>), dim3((tiles + 3) / 4, split), dim3(512), 0, st, a);
-            return;
-        }
+        // prefill chunks: several tiles per workgroup through the chunk-streaming form (CH = 0): they quarter the x traffic
+        // (every workgroup reads all K of its 64 rows), but a narrow layer (o_proj / down_proj: 128 tiles) is then 128
+        // workgroups on 256 CUs: two tiles each there (prefill 17.0 -> 14.2 ms at 1.7B / batch 32; one tile each: 15.5)
+        if (g.ch == 0 && g.np == 2) { hipLaunchKernelGGL((gemm_skinny_kernel<4, EPI, 8, 0, false, QUANT, 2, false>), grid, dim3(512), 0, st, a); return; }
+        if (g.ch == 0 && g.np == 4) { hipLaunchKernelGGL((gemm_skinny_kernel<4, EPI, 8, 0, false, QUANT, 4, false>), grid, dim3(512), 0, st, a); return; }
     }
     if constexpr (EPI == 2 && MB <= 2) {
         // gate/up tiles are self-contained, so a workgroup takes as many as it needs for the launch to be ONE round of at
         // most 256 workgroups: 768 tiles (6144 columns) -> 3 each, 384 (3072) -> 2 each
-        const bool one_tile = std::getenv("Q3TTS_GEMM_ONE_PAIR") != nullptr;
-        const int np = one_tile ? 1 : (tiles > 512 ? 3 : (tiles > 256 ? 2 : 1));
-        if (nw == 8 && (ch == 1 || ch == 2) && np > 1) {
-            const dim3 grid((tiles + np - 1) / np, split);
+        if (g.np > 1) {
 #define Q3_GEMM_NP(CHv, NPv) hipLaunchKernelGGL((gemm_skinny_kernel<MB, 2, 8, CHv, NORM, QUANT, NPv, NTW>), grid, dim3(512), 0, st, a)
-            if (ch == 1) { if (np == 2) Q3_GEMM_NP(1, 2); else Q3_GEMM_NP(1, 3); }
-            else { if (np == 2) Q3_GEMM_NP(2, 2); else Q3_GEMM_NP(2, 3); }
+            if (g.ch == 1) { if (g.np == 2) Q3_GEMM_NP(1, 2); else Q3_GEMM_NP(1, 3); }
+            else { if (g.np == 2) Q3_GEMM_NP(2, 2); else Q3_GEMM_NP(2, 3); }
 #undef Q3_GEMM_NP
             return;
         }
     }
-    if (nw == 4) {
+    if (g.nw == 4) {
         Q3_GEMM(4, 1);
     } else {
-        switch (ch) {
+        switch (g.ch) {
             case 1: Q3_GEMM(8, 1); break;
             case 2: Q3_GEMM(8, 2); break;
             case 3: Q3_GEMM(8, 3); break;
@@ -114,41 +113,18 @@ void launch_mb(const GemmArgs& a, int split, hipStream_t st) {
 
 template <int EPI, bool NORM, bool QUANT>
 void launch_q(const GemmArgs& a, hipStream_t st) {
-    const int MBt = (a.Mpad + 15) / 16;
-    // Narrow layers (o_proj, down_proj: N / 16 <= 128 column tiles) leave CUs idle with one workgroup per tile, and a
-    // workgroup that carries two row blocks cannot keep every x fragment of a long K in registers. Their row blocks go
-    // to separate workgroups instead (grid.y); tile x of both lands on the same XCD (128 = 0 mod 8), so the second
-    // read of the weight tile is an L2 hit. Per-row arithmetic does not depend on the grouping: results are unchanged.
-    const bool no_split = std::getenv("Q3TTS_GEMM_NO_ROW_SPLIT") != nullptr;  // (per launch: tests switch it)
-    int tiles = a.N / 16;  // workgroups along x
-    if constexpr (EPI == 2) {  // eight columns per tile, up to three tiles per workgroup (launch_mb)
-        const int t8 = a.N / 8;
-        tiles = t8 > 512 ? (t8 + 2) / 3 : (t8 > 256 ? (t8 + 1) / 2 : t8);
-    }
-    int split = 1;
-    if (!no_split) {
-        if (MBt % 4 == 0 && tiles * 4 <= 256) split = 4;
-        else if (MBt % 2 == 0 && tiles * 2 <= 256) split = 2;
-    }
-    // More than 64 rows (prefill chunks, the predictor's two-position step): at most 4 row blocks per workgroup -- 2 with
-    // the norm prologue, whose VALU work on the x fragments (critical path, per workgroup) grows with the row blocks.
-    if (!no_split) {
-        const int cap = NORM ? 2 : 4;
-        while (MBt / split > cap || MBt % split != 0) ++split;
-    }
-    while (MBt / split > 4 || MBt % split != 0) ++split;
+    const SkinnyGeom g = skinny_geometry(a);
     // non-temporal weight loads: only the one- and two-row-block forms the talker's decode step uses are instantiated
-    const int mbw = MBt / split;
-    if (a.nt_weights && mbw <= 2) {
-        if (mbw == 1) launch_mb<1, EPI, NORM, QUANT, true>(a, split, st);
-        else launch_mb<2, EPI, NORM, QUANT, true>(a, split, st);
+    if (g.ntw) {
+        if (g.mbw == 1) launch_mb<1, EPI, NORM, QUANT, true>(a, g, st);
+        else launch_mb<2, EPI, NORM, QUANT, true>(a, g, st);
         return;
     }
-    switch (mbw) {
-        case 1: launch_mb<1, EPI, NORM, QUANT, false>(a, split, st); break;
-        case 2: launch_mb<2, EPI, NORM, QUANT, false>(a, split, st); break;
-        case 3: launch_mb<3, EPI, NORM, QUANT, false>(a, split, st); break;
-        case 4: launch_mb<4, EPI, NORM, QUANT, false>(a, split, st); break;
+    switch (g.mbw) {
+        case 1: launch_mb<1, EPI, NORM, QUANT, false>(a, g, st); break;
+        case 2: launch_mb<2, EPI, NORM, QUANT, false>(a, g, st); break;
+        case 3: launch_mb<3, EPI, NORM, QUANT, false>(a, g, st); break;
+        case 4: launch_mb<4, EPI, NORM, QUANT, false>(a, g, st); break;
         default: throw Error(3, "gemm_skinny: more than 4 row blocks per workgroup");
     }
 }
@@ -161,29 +137,92 @@ void launch_epi(const GemmArgs& a, hipStream_t st) {
 
 }  // namespace
 
-bool launch_gemm_skinny_with_norm_rows(const GemmArgs& a, const NormRowsArgs& n, hipStream_t st) {
-    // exactly the launch launch_gemm_skinny would make for these arguments (launch_q / launch_mb), or nothing
-    if (a.epi != 0 || !a.norm_w || a.nt_weights || n.M <= 0 || n.H > 4096) return false;
-    const int KC = a.K / 128, tiles = a.N / 16, MBt = (a.Mpad + 15) / 16;
-    if (KC <= 4 || (KC + 7) / 8 > 2 || a.K % 128 != 0 || a.N % 16 != 0) return false;
-    const int ch = (KC + 7) / 8;
+// The ONE place that decides a skinny GEMM's launch (kernels.h SkinnyGeom).
+SkinnyGeom skinny_geometry(const GemmArgs& a) {
+    SkinnyGeom g{};
+    if (gemm_tall_takes(a)) {
+        g.tall = true;
+        return g;
+    }
+    const DebugEnv& env = debug_env();
+    const bool norm = a.norm_w != nullptr;
+    const int MBt = (a.Mpad + 15) / 16;
+    // Narrow layers (o_proj, down_proj: N / 16 <= 128 column tiles) leave CUs idle with one workgroup per tile, and a
+    // workgroup that carries two row blocks cannot keep every x fragment of a long K in registers. Their row blocks go
+    // to separate workgroups instead (grid.y); tile x of both lands on the same XCD (128 = 0 mod 8), so the second
+    // read of the weight tile is an L2 hit. Per-row arithmetic does not depend on the grouping: results are unchanged.
+    const bool no_split = env.gemm_no_row_split;
+    int tiles = a.N / 16;  // workgroups along x
+    if (a.epi == 2) {      // eight columns per tile, up to three tiles per workgroup
+        const int t8 = a.N / 8;
+        tiles = t8 > 512 ? (t8 + 2) / 3 : (t8 > 256 ? (t8 + 1) / 2 : t8);
+    }
     int split = 1;
-    if (MBt % 4 == 0 && tiles * 4 <= 256) split = 4;
-    else if (MBt % 2 == 0 && tiles * 2 <= 256) split = 2;
-    while (MBt / split > 2 || MBt % split != 0) ++split;
-    const int mbw = MBt / split;
-    if (mbw < 1 || mbw > 2 || std::getenv("Q3TTS_GEMM_NO_ROW_SPLIT")) return false;
+    if (!no_split) {
+        if (MBt % 4 == 0 && tiles * 4 <= 256) split = 4;
+        else if (MBt % 2 == 0 && tiles * 2 <= 256) split = 2;
+        // More than 64 rows (prefill chunks, the predictor's two-position step): at most 4 row blocks per workgroup -- 2 with
+        // the norm prologue, whose VALU work on the x fragments (critical path, per workgroup) grows with the row blocks.
+        const int cap = norm ? 2 : 4;
+        while (MBt / split > cap || MBt % split != 0) ++split;
+    }
+    while (MBt / split > 4 || MBt % split != 0) ++split;
+    g.split = split;
+    g.mbw = MBt / split;
+    g.ntw = a.nt_weights && g.mbw <= 2;
+    const int KC = a.K / 128;
+    g.nw = KC <= 4 ? 4 : 8;  // no idle waves on short K
+    g.ch = (KC + g.nw - 1) / g.nw;
+    g.np = 1;
+    const int t = a.epi == 2 ? a.N / 8 : a.N / 16;  // EPI 2: eight columns per (gate | up) tile
+    g.gx = t;
+    bool shaped = false;
+    if (g.mbw == 4 && !norm && !g.ntw && !env.gemm_one_pair && g.nw == 8 && t >= 64) {  // prefill chunks (launch_mb)
+        g.np = (((t + 3) / 4) * split <= 128) ? 2 : 4;
+        g.ch = 0;
+        g.gx = (t + g.np - 1) / g.np;
+        shaped = true;
+    }
+    if (!shaped && a.epi == 2 && g.mbw <= 2) {
+        const int np = env.gemm_one_pair ? 1 : (t > 512 ? 3 : (t > 256 ? 2 : 1));
+        if (g.nw == 8 && (g.ch == 1 || g.ch == 2) && np > 1) {
+            g.np = np;
+            g.gx = (t + np - 1) / np;
+            shaped = true;
+        }
+    }
+    if (!shaped) {
+        if (g.nw == 4) g.ch = 1;
+        else if (g.ch != 1 && g.ch != 2 && g.ch != 3 && g.ch != 6) g.ch = 0;
+    }
+    g.touches = gemm_touches(g.mbw, g.ch);
+    return g;
+}
+
+bool gemm_norm_rows_rides(const GemmArgs& a, const NormRowsArgs& n) {
+    if (a.epi != 0 || !a.norm_w || a.nt_weights || n.M <= 0 || n.H > 4096) return false;
+    if (a.K % 128 != 0 || a.N % 16 != 0) return false;
+    const SkinnyGeom g = skinny_geometry(a);
+    return !(g.tall || g.nw != 8 || g.np != 1 || (g.ch != 1 && g.ch != 2) || g.mbw < 1 || g.mbw > 2 || g.ntw);
+}
+
+bool launch_gemm_skinny_with_norm_rows(const GemmArgs& a, const NormRowsArgs& n, hipStream_t st) {
+    // exactly the launch launch_gemm_skinny would make for these arguments, plus n.M workgroups along x -- or nothing
+    if (!gemm_norm_rows_rides(a, n)) return false;
+    const SkinnyGeom g = skinny_geometry(a);
     Q3_CHECK(a.ss_in && a.ss_count >= 1 && a.ss_ld >= a.Mpad && a.xMB * 16 >= a.Mpad, 3, "gemm_skinny: norm prologue needs sums of squares");
-    GemmSideArgs s{a, n, tiles};
-    const dim3 grid(tiles + n.M, split), block(512);
+    const int tiles = g.gx;
+    const dim3 grid(tiles + n.M, g.split), block(512);
+    GemmSideArgs s{with_geometry(a, dim3(tiles, g.split)), n, tiles};
+    s.g.pf.gx = grid.x;  // the riders sit behind the tiles along x; they touch nothing themselves
     const bool q = a.Wsb != nullptr;
 #define Q3_SIDE(MBv, CHv)                                                                              \
     do {                                                                                               \
         if (q) hipLaunchKernelGGL((gemm_skinny_side_kernel<MBv, CHv, true>), grid, block, 0, st, s);   \
         else hipLaunchKernelGGL((gemm_skinny_side_kernel<MBv, CHv, false>), grid, block, 0, st, s);    \
     } while (0)
-    if (mbw == 1) { if (ch == 1) Q3_SIDE(1, 1); else Q3_SIDE(1, 2); }
-    else { if (ch == 1) Q3_SIDE(2, 1); else Q3_SIDE(2, 2); }
+    if (g.mbw == 1) { if (g.ch == 1) Q3_SIDE(1, 1); else Q3_SIDE(1, 2); }
+    else { if (g.ch == 1) Q3_SIDE(2, 1); else Q3_SIDE(2, 2); }
 #undef Q3_SIDE
     return true;
 }

@@ -234,11 +234,15 @@ void launch_shape(const GemmArgs& a, int n_tiles, int nphase, hipStream_t st) {
 
 }  // namespace
 
-bool launch_gemm_tall(const GemmArgs& a, hipStream_t st) {
-    const bool off = std::getenv("Q3TTS_NO_TALL_GEMM") != nullptr;  // (read per launch: tests switch it on a live model)
-    if (off || a.Mpad <= 64 || a.Wsb || a.norm_w || a.bias || a.act_silu) return false;
+bool gemm_tall_takes(const GemmArgs& a) {
+    if (debug_env().no_tall_gemm || a.Mpad <= 64 || a.Wsb || a.norm_w || a.bias || a.act_silu) return false;
     if (a.epi != 0 && a.epi != 2 && a.epi != 3) return false;
     if (a.epi == 0 && a.N % 16 != 0) return false;
+    return true;
+}
+
+bool launch_gemm_tall(const GemmArgs& a, hipStream_t st) {
+    if (!gemm_tall_takes(a)) return false;
     const int KC = a.K / 128;
     const int nphase = KC <= 4 ? 4 : 8;  // gemm_decode.hip launch_mb: waves that split K
     const int n_tiles = a.epi == 2 ? a.N / 8 : a.N / 16;
@@ -248,8 +252,7 @@ bool launch_gemm_tall(const GemmArgs& a, hipStream_t st) {
     // 64 x 64 ring 8: - / 16.1 / - / 35.1; 128 x 128 ring 2: 38 / 40 / 55 / 83; eight-wave workgroups and deeper rings
     // (128 x 64 ring 8: 66 / 56 / 171 / 149) lose: past ~32 wave-wide loads in flight per wave the CU's own miss queue is the
     // limit and further loads stall the wave at issue. Q3TTS_TALL_SHAPE = 2 | 3 forces one (diagnostics).
-    const char* fs = std::getenv("Q3TTS_TALL_SHAPE");
-    const int force = fs ? std::atoi(fs) : 0;
+    const int force = debug_env().tall_shape;
     auto wgs = [&](int tm, int tn) { return ((MBt + tm - 1) / tm) * ((n_tiles + tn - 1) / tn); };
     int shape = wgs(8, 4) >= 192 ? 2 : 3;
     if (force == 2 || force == 3) shape = force;

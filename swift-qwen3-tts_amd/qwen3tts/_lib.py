@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libq3tts_hip.so")
+# Q3TTS_LIB: another build of the same library (A/B measurements of a kernel change inside one gpurun call)
+LIB_PATH = os.environ.get("Q3TTS_LIB") or os.path.join(_HERE, "libq3tts_hip.so")
 
 u16p = C.POINTER(C.c_uint16)
 i32p = C.POINTER(C.c_int32)
@@ -108,6 +109,8 @@ def lib() -> C.CDLL:
     L.q3tts_codec_decode_streamed.argtypes = [vp, i32p, i32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, f32p]
     L.q3tts_debug_set_codec_scratch.argtypes = [C.c_uint64]
     L.q3tts_debug_set_codec_scratch.restype = None
+    L.q3tts_debug_reload_env.argtypes = []
+    L.q3tts_debug_reload_env.restype = None
     L.q3tts_last_timing.argtypes = [vp, C.POINTER(Timing)]
     L.q3tts_codec_encode.argtypes = [vp, f32p, C.c_int64, i32p, C.c_int32, i32p]
     L.q3tts_codec_encoded_frames.argtypes = [vp, C.c_int64]
@@ -127,3 +130,8 @@ def lib() -> C.CDLL:
     L.q3tts_debug_codec_stage.argtypes = [vp, i32p, C.c_int32, C.c_char_p, f32p, C.c_int64, i32p, i32p]
     _lib = L
     return L
+
+
+def reload_debug_env() -> None:
+    """The launchers read their diagnostic switches (Q3TTS_*) once per model load; after changing one on a live model call this."""
+    lib().q3tts_debug_reload_env()

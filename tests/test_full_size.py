@@ -51,9 +51,12 @@ def test_full_size_properties(full_dir, monkeypatch):
         assert len({tuple(r.codes[:, 0]) for r in a}) > 16          # rows differ (own prompts, own RNG streams)
         # prefill chunks (512 rows per launch here) go through the tall GEMM (gemm_prefill.hip): the same bits as the skinny
         # kernel's wave partials at K = 2048 and 6144, eight phases
+        from qwen3tts import _lib
         monkeypatch.setenv("Q3TTS_NO_TALL_GEMM", "1")
+        _lib.reload_debug_env()  # (the switches are read once per model load)
         a2 = m.generate_batch(reqs, **kw)
         monkeypatch.delenv("Q3TTS_NO_TALL_GEMM")
+        _lib.reload_debug_env()
         for x, y in zip(a, a2):
             assert (x.codes == y.codes).all() and (x.audio == y.audio).all()
         small = m.generate_batch(reqs[:3], **kw)                       # row independence across scheduling modes

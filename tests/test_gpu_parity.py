@@ -83,17 +83,22 @@ def test_tall_linear_is_the_skinny_linear_bit_for_bit(engines, monkeypatch, M, K
     x = f2b(rng.standard_normal((M, K)))
     W = f2b(rng.standard_normal((N, K)) * 0.03)
     m = engines["tiny-a"]
+    from qwen3tts import _lib
     for k in ("Q3TTS_NO_TALL_GEMM", "Q3TTS_TALL_SHAPE"):
         monkeypatch.delenv(k, raising=False)
+    _lib.reload_debug_env()  # (the launchers read their switches once per model load: re-read after every change)
     tall = m.debug_linear(x, W)
     outs = {}
     for shape in ("2", "3"):
         monkeypatch.setenv("Q3TTS_TALL_SHAPE", shape)
+        _lib.reload_debug_env()
         outs[shape] = m.debug_linear(x, W)
     monkeypatch.delenv("Q3TTS_TALL_SHAPE")
     monkeypatch.setenv("Q3TTS_NO_TALL_GEMM", "1")
+    _lib.reload_debug_env()
     skinny = m.debug_linear(x, W)
     monkeypatch.delenv("Q3TTS_NO_TALL_GEMM")
+    _lib.reload_debug_env()
     assert (tall == skinny).all() and (outs["2"] == skinny).all() and (outs["3"] == skinny).all()
     yo = np.empty((M, N), np.uint16)
     O.lib().o_linear_bf16(O._p16(x), O._p16(W), None, M, K, N, O._p16(yo))

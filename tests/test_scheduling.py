@@ -72,10 +72,13 @@ def test_launch_geometry_switches_change_nothing(ckpt_dirs, monkeypatch, name):
     reqs = [_req(row=i, n_text=5 + 4 * i) for i in range(6)]
     kw = dict(temperature=0.9, top_k=40, top_p=0.95, repetition_penalty=1.05, seed=31, force_frames=16)
     ref = None
+    all_switches = ("Q3TTS_ROWS_64", "Q3TTS_GEMM_NO_ROW_SPLIT", "Q3TTS_GEMM_ONE_PAIR", "Q3TTS_NO_TALL_GEMM", "Q3TTS_TALL_SHAPE",
+                    "Q3TTS_CHUNK_QSPLIT", "Q3TTS_PF", "Q3TTS_PF_BUDGET_KB", "Q3TTS_PF_AHEAD")
     for env in ({}, {"Q3TTS_ROWS_64": "1"}, {"Q3TTS_GEMM_NO_ROW_SPLIT": "1", "Q3TTS_GEMM_ONE_PAIR": "1"}, {"Q3TTS_NO_TALL_GEMM": "1"},
-                {"Q3TTS_TALL_SHAPE": "2", "Q3TTS_CHUNK_QSPLIT": "1"}, {"Q3TTS_CHUNK_QSPLIT": "4"}):
-        for k in ("Q3TTS_ROWS_64", "Q3TTS_GEMM_NO_ROW_SPLIT", "Q3TTS_GEMM_ONE_PAIR", "Q3TTS_NO_TALL_GEMM", "Q3TTS_TALL_SHAPE",
-                  "Q3TTS_CHUNK_QSPLIT"):
+                {"Q3TTS_TALL_SHAPE": "2", "Q3TTS_CHUNK_QSPLIT": "1"}, {"Q3TTS_CHUNK_QSPLIT": "4"},
+                # next-launch weight touch (kernels/prefetch.h): off, and with a plan that looks far ahead on a tiny budget
+                {"Q3TTS_PF": "0"}, {"Q3TTS_PF_BUDGET_KB": "64", "Q3TTS_PF_AHEAD": "7"}, {"Q3TTS_PF_BUDGET_KB": "100000", "Q3TTS_PF_AHEAD": "1"}):
+        for k in all_switches:
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -89,6 +92,10 @@ def test_launch_geometry_switches_change_nothing(ckpt_dirs, monkeypatch, name):
         else:
             for x, y in zip(ref, out):
                 assert (x.codes == y.codes).all() and (x.audio == y.audio).all(), env
+    from qwen3tts import _lib
+    for k in all_switches:
+        monkeypatch.delenv(k, raising=False)
+    _lib.reload_debug_env()  # the switches are process-wide and read at model load: leave the defaults behind
 
 
 def test_pipelined_jobs_equal_sequential_calls(ckpt_dirs):
