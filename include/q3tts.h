@@ -144,9 +144,17 @@ typedef struct {
                                    decoder's pre-transformer is bidirectional over the whole utterance (SpeechTokenizer.swift:763),
                                    so a chunk is then computed from the frames that exist: this many frames of left context and
                                    audio_lookahead_frames to the right; everything behind the pre-transformer is causal and
-                                   carries its state from chunk to chunk (exact). The waveform differs from the one-shot decode
-                                   by a bounded amount (tests/test_streaming.py); AUDIO then carries the
-                                   concatenation of the chunks. Not combined with voice-clone rows (those fall back to 0) */
+                                   carries its state from chunk to chunk (exact). The arithmetic is pinned against the oracle's
+                                   restatement of exactly this definition (OracleModel.codec_decode_streamed, PCM within 1e-4:
+                                   tests/test_streaming.py). Its distance from the ONE-SHOT waveform is a property of the
+                                   checkpoint -- how much of the signal the pre-transformer's attention carries -- and is
+                                   not guaranteed: 1.6e-2 max / 1 % of the signal r.m.s. at window 32 / lookahead 4 on the synthetic
+                                   full-width checkpoint (reported by the test), zero with a window over
+                                   everything. AUDIO then carries the concatenation of the chunks -- all generated frames: the
+                                   reference's end trim to count(code0 > 0) frames (SpeechTokenizer.swift:831-833) cannot apply
+                                   to samples that have already left. audio_chunk_frames must be at
+                                   least the causal tail's history (3 frames for the shipped decoder geometry; checked before any
+                                   GPU work). Not combined with voice-clone rows (those fall back to 0) */
     int32_t audio_lookahead_frames; /* frames to the right of a chunk that must exist before it is decoded (default 4) */
     uint32_t row_base;    /* new: global index of reqs[0] in a job whose rows are sharded over several processes (one
                              replica per GPU). A row's random stream is keyed by (seed, row_base + row index), so a sharded

@@ -745,10 +745,10 @@ class OracleModel:
             h = self._resunit(h, f"{p}.res{j}", dil)
         return h
 
-    def codec_decode(self, codes: np.ndarray, stages: Optional[dict] = None):
-        """Qwen3TTSSpeechTokenizer.decode for one utterance (SpeechTokenizer.swift:823-836 ->
-        754-784). codes [F][16] int. Returns (pcm float32 [1920*F], valid_len). Intermediate
-        activations ([T][C] channels-last) are stored into `stages` when given."""
+    def _codec_front(self, codes: np.ndarray, stages: Optional[dict] = None) -> np.ndarray:
+        """Steps 1-4 of Qwen3TTSSpeechTokenizerDecoder.callAsFunction (SpeechTokenizer.swift:757-765): split-RVQ
+        dequantisation, pre_conv (causal k3), pre_transformer over ALL the frames it is given (no mask, no positions:
+        :512-528, :763). codes [F][16] -> [F][latent]."""
         dc, cw = self.dc, self.codec
         codes = np.asarray(codes, np.int64)
         F = codes.shape[0]
@@ -783,6 +783,12 @@ class OracleModel:
         h = self._lin(x, pt + ".output_proj", True)
         if stages is not None:
             stages["pre_transformer"] = h
+        return h
+
+    def _codec_tail(self, h: np.ndarray, stages: Optional[dict] = None) -> np.ndarray:
+        """Steps 5-7 (:767-781): upsample stages, MainDecoder, clip. Every layer here is causal (:298-301, :346-351).
+        [F][latent] -> pcm [F * upsample]."""
+        dc = self.dc
         for i, r in enumerate(dc["upsampling_ratios"]):  # :767-775
             h = self._convtr(h, f"decoder.upsample.{i}.0.conv", r, r)
             h = self._convnext(h, f"decoder.upsample.{i}.1")
@@ -797,10 +803,37 @@ class OracleModel:
                 stages[f"block{b}"] = h
         h = self._snake(h, "decoder.decoder.outSnake")
         h = self._conv(h, "decoder.decoder.outConv.conv", 7)
-        pcm = np.clip(h[:, 0], -1.0, 1.0).astype(np.float32)  # :781
+        return np.clip(h[:, 0], -1.0, 1.0).astype(np.float32)  # :781
+
+    def codec_decode(self, codes: np.ndarray, stages: Optional[dict] = None):
+        """Qwen3TTSSpeechTokenizer.decode for one utterance (SpeechTokenizer.swift:823-836 ->
+        754-784). codes [F][16] int. Returns (pcm float32 [1920*F], valid_len). Intermediate
+        activations ([T][C] channels-last) are stored into `stages` when given."""
+        dc = self.dc
+        codes = np.asarray(codes, np.int64)
+        pcm = self._codec_tail(self._codec_front(codes, stages), stages)
         up = int(np.prod(dc["upsample_rates"]) * np.prod(dc["upsampling_ratios"]))
         valid = int((codes[:, 0] > 0).sum()) * up  # :831-833
         return pcm, valid
+
+    def codec_decode_streamed(self, codes: np.ndarray, chunk: int, window: int, lookahead: int) -> np.ndarray:
+        """What a STREAM can compute of the decode above (row f1 of SURVEY 8f; the reference has no streaming decode -- gap noted
+        at README.md:140 -- so this restates the engine's definition, include/q3tts.h `audio_window_frames`, as a composition
+        of the reference's own functions). The tail (steps 5-7) is causal, so feeding it frame by frame with carried conv
+        state IS the one-shot tail over the concatenated latents. The pre_transformer is bidirectional over whatever it is
+        given (:763): for chunk [f0, f1) a stream gives it the frames [max(0, f0 - window), min(F, f1 + lookahead)) -- pre_conv's
+        causal padding starts at the window's first frame -- and keeps rows [f0, f1) of the result. window < 0: everything
+        (the one-shot decode). codes [F][16] -> pcm [F * upsample]."""
+        codes = np.asarray(codes, np.int64)
+        F = codes.shape[0]
+        if window < 0:
+            return self._codec_tail(self._codec_front(codes))
+        lat = []
+        for f0 in range(0, F, chunk):
+            f1 = min(F, f0 + chunk)
+            w0, w1 = max(0, f0 - window), min(F, f1 + lookahead)
+            lat.append(self._codec_front(codes[w0:w1])[f0 - w0: f1 - w0])
+        return self._codec_tail(np.ascontiguousarray(np.concatenate(lat, 0)))
 
     def generate(self, req: Request, s: Sampling, row: int = 0):
         """generateCustomVoice end to end (Qwen3.swift:783-962): codes -> PCM, trimmed (:954-959)."""

@@ -256,7 +256,14 @@ void CodecRunner::run_tail(const Pass& ps, int Tframes, float* const* bufs, floa
 }
 
 int CodecRunner::decode(const int32_t* codes_dev, int code_stride_frames, const std::vector<int>& frames, float** pcm_dev,
-                        const std::string& stage, std::vector<float>* stage_out, int* stage_T, int* stage_C, int32_t* nonfinite_host) {
+                        const std::string& stage, std::vector<float>* stage_out, int* stage_T, int* stage_C, int32_t* nonfinite_host,
+                        bool force_fp32) {
+    struct Fp32Scope {  // the override ends with the call, however it ends
+        bool& flag;
+        bool old;
+        ~Fp32Scope() { flag = old; }
+    } fp32_scope{fp32_mfma_, fp32_mfma_};
+    if (force_fp32) fp32_mfma_ = true;
     const int B = int(frames.size());
     Q3_CHECK(B <= kMaxRows, 3, "Invalid input: too many rows in one codec decode");
     Q3_HIP(hipMemsetAsync(nf_dev_, 0, size_t(B) * 4, st_));
@@ -294,7 +301,7 @@ int CodecRunner::decode(const int32_t* codes_dev, int code_stride_frames, const 
 // (tests/test_streaming.py). Each chunk's samples are copied to pcm_host ([B][Fmax * upsample], pinned) at their final
 // place and chunk_done[k] is recorded behind the copy.
 int CodecRunner::decode_chunked(const int32_t* codes_dev, int code_stride_frames, const std::vector<int>& frames, int chunk_frames,
-                                float* pcm_host, std::vector<hipEvent_t>& chunk_done, int32_t* nonfinite_host) {
+                                float* pcm_host, std::vector<hipEvent_t>& chunk_done, int32_t* nonfinite_host, int32_t* nf_chunks_host) {
     const CodecDecoderConfig& dc = m_.cfg.codec;
     const int B = int(frames.size());
     int Fmax = 0;
@@ -356,6 +363,7 @@ int CodecRunner::decode_chunked(const int32_t* codes_dev, int code_stride_frames
                                     size_t(T) * up_ * sizeof(float), size_t(f1 - f0) * up_ * sizeof(float), size_t(ps.nb),
                                     hipMemcpyDeviceToHost, st_));
         }
+        if (nf_chunks_host) Q3_HIP(hipMemcpyAsync(nf_chunks_host + size_t(k) * B, nf_dev_, size_t(B) * 4, hipMemcpyDeviceToHost, st_));
         Q3_HIP(hipEventRecord(chunk_done[size_t(k)], st_));
     }
     if (nonfinite_host) Q3_HIP(hipMemcpyAsync(nonfinite_host, nf_dev_, size_t(B) * 4, hipMemcpyDeviceToHost, st_));
@@ -487,7 +495,7 @@ void CodecRunner::stream_close(int32_t* nonfinite_host) {
 }
 
 int CodecRunner::stream_push(const int32_t* codes_dev, int code_stride_frames, const int* avail, const uint8_t* final_rows, float* pcm_host,
-                             size_t pcm_row_stride, std::vector<hipEvent_t>& chunk_done) {
+                             size_t pcm_row_stride, std::vector<hipEvent_t>& chunk_done, int32_t* nf_chunks_host) {
     Stream& S = stream_;
     Q3_CHECK(S.open, 3, "Invalid input: no streamed decode is open");
     const CodecDecoderConfig& dc = m_.cfg.codec;
@@ -576,6 +584,7 @@ int CodecRunner::stream_push(const int32_t* codes_dev, int code_stride_frames, c
             Q3_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             chunk_done.push_back(e);
         }
+        if (nf_chunks_host) Q3_HIP(hipMemcpyAsync(nf_chunks_host + size_t(k) * B, nf_dev_, size_t(B) * 4, hipMemcpyDeviceToHost, st_));
         Q3_HIP(hipEventRecord(chunk_done[size_t(k)], st_));
         ++S.next_chunk;
     }

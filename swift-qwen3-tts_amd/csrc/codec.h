@@ -19,15 +19,19 @@ class CodecRunner {
     // nonfinite_host (pinned, one int per row, optional): set to 1 behind the decode for rows whose waveform came out
     // non-finite -- with the default fp16 two-plane convs that is what an activation beyond 65504 turns into (codec_conv.hip);
     // the fp32 matrix-core path (q3tts_load_opts.codec_fp32) has the reference's range.
+    // force_fp32: this call contracts on the fp32 matrix cores whatever the runner's default (the engine re-decodes rows
+    // that left the fp16 range this way, so that a checkpoint with large activations still gets the reference's waveform).
     int decode(const int32_t* codes_dev, int code_stride_frames, const std::vector<int>& frames, float** pcm_dev,
                const std::string& stage = std::string(), std::vector<float>* stage_out = nullptr, int* stage_T = nullptr,
-               int* stage_C = nullptr, int32_t* nonfinite_host = nullptr);
+               int* stage_C = nullptr, int32_t* nonfinite_host = nullptr, bool force_fp32 = false);
+    bool fp32_convs() const { return fp32_mfma_; }
     // The same decode with the causal tail (everything behind the pre-transformer) evaluated `chunk_frames` frames at a
     // time (row f1 of SURVEY 8f): each chunk's samples land in pcm_host ([B][Fmax * upsample], pinned host memory) at
     // their final place and chunk_done[k] is recorded behind chunk k's copy. Bit-identical to decode(). Returns the
     // number of chunks; chunk k covers frames [k * chunk_frames, min(Fmax, (k + 1) * chunk_frames)).
     int decode_chunked(const int32_t* codes_dev, int code_stride_frames, const std::vector<int>& frames, int chunk_frames,
-                       float* pcm_host, std::vector<hipEvent_t>& chunk_done, int32_t* nonfinite_host = nullptr);
+                       float* pcm_host, std::vector<hipEvent_t>& chunk_done, int32_t* nonfinite_host = nullptr,
+                       int32_t* nf_chunks_host = nullptr);  // (per-chunk flags as in stream_push)
     int tail_context_frames() const;
     static void set_scratch_budget(size_t bytes);  // test hook: forces the row-group paths of decode / decode_chunked (0: default)
 
@@ -47,8 +51,10 @@ class CodecRunner {
     // chunk k's samples go to pcm_host + b * pcm_row_stride + k * chunk_frames * upsample() and chunk_done[k] is recorded
     // behind the copy (events are created as needed). Returns the number of chunks issued so far. codes: device
     // [rows][code_stride_frames][16], frames below avail[b] final. No host synchronisation.
+    // nf_chunks_host (pinned, optional): [chunk][rows] -- the rows' non-finite flags as they stand behind chunk k, copied in
+    // front of chunk_done[k], so that a caller can hold a row's pieces back from the first chunk that left the fp16 range.
     int stream_push(const int32_t* codes_dev, int code_stride_frames, const int* avail, const uint8_t* final_rows, float* pcm_host,
-                    size_t pcm_row_stride, std::vector<hipEvent_t>& chunk_done);
+                    size_t pcm_row_stride, std::vector<hipEvent_t>& chunk_done, int32_t* nf_chunks_host = nullptr);
     void stream_close(int32_t* nonfinite_host = nullptr);
     bool streaming() const { return stream_.open; }
     int hist_frames() const;

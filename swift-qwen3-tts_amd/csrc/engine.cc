@@ -20,8 +20,8 @@ std::string lower(const std::string& s) {
     return o;
 }
 const char* const kCodecRangeMsg =
-    "Audio decoding failed: a codec decoder activation left the fp16 range of the two-plane convolutions; load the model with "
-    "q3tts_load_opts.codec_fp32 = 1 (fp32 matrix-core convolutions, the reference's range)";
+    "Audio decoding failed: the codec decoder produced a non-finite waveform -- also on the fp32 matrix-core convolutions (the "
+    "reference's range), which a row is re-decoded on when it leaves the fp16 range of the default two-plane kernels";
 double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -132,6 +132,7 @@ Engine::~Engine() {
         for (auto& e : J.ev_codec)
             if (e) (void)hipEventDestroy(e);
         if (J.nf_host) (void)hipHostFree(J.nf_host);
+        if (J.nf_chunk_host) (void)hipHostFree(J.nf_chunk_host);
         if (J.ev_begin) (void)hipEventDestroy(J.ev_begin);
         if (J.ev_first_audio) (void)hipEventDestroy(J.ev_first_audio);
     }
@@ -1077,6 +1078,9 @@ int Engine::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3
     Q3_CHECK(n >= 1 && n <= Bm_, 3, "Invalid input: batch size must be between 1 and max_batch");
     Q3_CHECK(groups == 16, 3, "Invalid input: num_code_groups must be 16");
     Q3_CHECK(sp.audio_chunk_frames >= 0, 3, "Invalid input: audio_chunk_frames must not be negative");
+    if (sp.audio_chunk_frames > 0 && sp.audio_window_frames > 0 && m_->has_codec)  // before any GPU work (the stream would refuse it later)
+        Q3_CHECK(sp.audio_chunk_frames >= codec_->hist_frames(), 3,
+                 "Invalid input: audio_chunk_frames of a streamed decode must be at least " + std::to_string(codec_->hist_frames()));
     int slot = -1;  // any free slot: jobs may be ended in any order
     for (int i = 0; i < kJobSlots; ++i)
         if (!jobs_[i].busy && slot < 0) slot = i;
@@ -1186,6 +1190,19 @@ int Engine::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3
     std::vector<uint8_t> s_final((size_t)(n), 0);
     std::memset(J.nf_host, 0, size_t(Bm_) * 4);
     J.streamed = false;
+    // the rows' non-finite flags behind every chunk of a decode in pieces (fire_chunks holds a row back from its first flagged chunk)
+    auto chunk_flags = [&](int frames_cap) {
+        const size_t slots = size_t(ceil_div(frames_cap, sp.audio_chunk_frames) + 1) * size_t(n);
+        if (slots > J.nf_chunk_cap) {
+            if (J.nf_chunk_host) Q3_HIP(hipHostFree(J.nf_chunk_host));
+            J.nf_chunk_host = nullptr;
+            J.nf_chunk_cap = 0;
+            Q3_HIP(hipHostMalloc(reinterpret_cast<void**>(&J.nf_chunk_host), slots * 4, hipHostMallocDefault));
+            J.nf_chunk_cap = slots;
+        }
+        std::memset(J.nf_chunk_host, 0, slots * 4);
+    };
+    J.held_from.assign(size_t(n), -1);
     J.chunks_fired = 0;
     J.t_first_audio = 0;
     J.n_chunks = 0;
@@ -1210,6 +1227,7 @@ int Engine::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3
             Q3_HIP(hipHostMalloc(reinterpret_cast<void**>(&J.pcm_host), floats * 4, hipHostMallocDefault));
             J.pcm_host_cap = floats;
         }
+        chunk_flags(Fcap_);
         // the decode runs beside this batch's own frame loop: the confined stream, like a decode beside the next batch's
         sst = codec_stream(true);
         CodecRunner::StreamCfg cfg;
@@ -1237,7 +1255,8 @@ int Engine::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3
             Q3_HIP(hipStreamWaitEvent(sst, ev_[3], 0));
         }
         const int before = J.n_chunks;
-        J.n_chunks = codec_->stream_push(J.dec_codes, Fcap_, s_avail.data(), s_final.data(), J.pcm_host, size_t(Fcap_) * J.up, J.chunk_done);
+        J.n_chunks = codec_->stream_push(J.dec_codes, Fcap_, s_avail.data(), s_final.data(), J.pcm_host, size_t(Fcap_) * J.up, J.chunk_done,
+                                         J.nf_chunk_host);
         if (before == 0 && J.n_chunks > 0) Q3_HIP(hipEventRecord(J.ev_first_audio, sst));  // behind chunk 0's copy to the host
     };
 
@@ -1400,7 +1419,8 @@ int Engine::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3
         }
         if (J.chunk_frames > 0) {
             // pre-transformer once over all frames, then the causal tail chunk by chunk (codec.h decode_chunked)
-            J.n_chunks = codec_->decode_chunked(J.dec_codes, Fdec, dframes, J.chunk_frames, J.pcm_host, J.chunk_done, J.nf_host);
+            chunk_flags(Fdec);
+            J.n_chunks = codec_->decode_chunked(J.dec_codes, Fdec, dframes, J.chunk_frames, J.pcm_host, J.chunk_done, J.nf_host, J.nf_chunk_host);
         } else {
             float* pcm_dev = nullptr;
             codec_->decode(J.dec_codes, Fdec, dframes, &pcm_dev, std::string(), nullptr, nullptr, nullptr, J.nf_host);
@@ -1464,7 +1484,9 @@ void Engine::compute_cuts(Job& J) {
         const int ref_T = J.ref_T[size_t(b)], total_f = ref_T + F;
         int64_t ns = int64_t(total_f) * up;
         const int64_t valid = int64_t(valid_tok) * up;
-        if (valid > 0 && valid < ns) ns = valid;
+        // (a streamed row has already delivered its chunks frame by frame when the count becomes known: its AUDIO is their
+        // concatenation, untrimmed -- include/q3tts.h)
+        if (!J.streamed && valid > 0 && valid < ns) ns = valid;
         int64_t cut = 0;
         if (ref_T > 0) {
             cut = int64_t(float(ref_T) / float(std::max(total_f, 1)) * float(ns));
@@ -1489,11 +1511,15 @@ void Engine::fire_chunks(Job& J, int upto, const std::vector<int>* known, bool w
             Q3_HIP(q);
         }
         J.chunks_fired = k + 1;
+        if (J.nf_chunk_host)  // a row that has left the fp16 range delivers nothing more until end() has decoded it again
+            for (int b = 0; b < n; ++b)
+                if (J.held_from[size_t(b)] < 0 && J.nf_chunk_host[size_t(k) * n + b]) J.held_from[size_t(b)] = k;
         if (!J.cb) continue;
         const int64_t c0 = int64_t(k) * J.chunk_frames * up, c1 = std::min<int64_t>(int64_t(J.Fdec), int64_t(k + 1) * J.chunk_frames) * up;
         std::unique_lock<std::mutex> lk;
         if (cb_mutex) lk = std::unique_lock<std::mutex>(*cb_mutex);
         for (int b = 0; b < n; ++b) {
+            if (J.held_from[size_t(b)] >= 0) continue;
             const int64_t cut = known ? 0 : J.row_cut[size_t(b)];
             const int64_t len = known ? int64_t((*known)[size_t(b)]) * up : J.row_ns[size_t(b)];
             const int64_t lo = std::max(c0, cut), hi = std::min(c1, cut + len);
@@ -1556,6 +1582,86 @@ void Engine::staging_loop() {
     }
 }
 
+// The default codec kernels contract on the fp16 matrix cores (two planes per fp32 operand, codec_conv.hip): an activation
+// beyond 65504 turns into inf / NaN, which out_conv flags per row. The reference computes in fp32 and decodes such inputs, so a
+// flagged row is decoded AGAIN here on the fp32 matrix cores (the fp32 weights stay resident; 2.4x the time, for those rows
+// only) and handed out like any other. A streamed row (audio_window_frames > 0) stopped delivering chunks at its first flagged
+// one (fire_chunks): its remaining AUDIO_CHUNK events come from this decode -- the exact one-shot arithmetic -- and its AUDIO
+// is what was delivered. Returns the rows that are non-finite even in fp32 (they fail with AUDIO_DECODING_FAILED).
+std::vector<int> Engine::redo_rows_fp32(Job& J) {
+    std::vector<int> rows, bad;
+    if (!J.decoded) return bad;
+    for (int b = 0; b < J.n; ++b)
+        if (J.nf_host[b] && J.frames[size_t(b)] > 0 && J.st_pcm[size_t(b)]) rows.push_back(b);
+    if (rows.empty()) return bad;
+    if (codec_->fp32_convs()) return rows;  // already the fp32 kernels: nothing wider to fall back to
+    const int R = int(rows.size()), up = J.up;
+    std::vector<int> dframes((size_t)(R));
+    int Fd = 0;
+    for (int i = 0; i < R; ++i) {
+        const int b = rows[size_t(i)];
+        dframes[size_t(i)] = J.frames[size_t(b)] + J.ref_T[size_t(b)];
+        Fd = std::max(Fd, dframes[size_t(i)]);
+    }
+    hipStream_t cst = codec_stream(false);
+    int32_t* dcodes = nullptr;
+    int32_t* nf = nullptr;
+    float* hpcm = nullptr;
+    auto cleanup = [&] {
+        if (dcodes) (void)hipFree(dcodes);
+        if (nf) (void)hipHostFree(nf);
+        if (hpcm) (void)hipHostFree(hpcm);
+    };
+    try {
+        Q3_HIP(hipMalloc(reinterpret_cast<void**>(&dcodes), size_t(R) * Fd * 64));
+        Q3_HIP(hipHostMalloc(reinterpret_cast<void**>(&nf), size_t(R) * 4, hipHostMallocDefault));
+        Q3_HIP(hipHostMalloc(reinterpret_cast<void**>(&hpcm), size_t(R) * Fd * up * 4, hipHostMallocDefault));
+        std::memset(nf, 0, size_t(R) * 4);
+        // the codes the first decode read: the job's own device copy ([reference ++] generated; row stride J.Fdec frames)
+        for (int i = 0; i < R; ++i)
+            Q3_HIP(hipMemcpyAsync(dcodes + size_t(i) * Fd * 16, J.dec_codes + size_t(rows[size_t(i)]) * J.Fdec * 16,
+                                  size_t(dframes[size_t(i)]) * 64, hipMemcpyDeviceToDevice, cst));
+        float* pcm_dev = nullptr;
+        codec_->decode(dcodes, Fd, dframes, &pcm_dev, std::string(), nullptr, nullptr, nullptr, nf, true);
+        Q3_HIP(hipMemcpyAsync(hpcm, pcm_dev, size_t(R) * Fd * up * 4, hipMemcpyDeviceToHost, cst));
+        Q3_HIP(hipStreamSynchronize(cst));
+        for (int i = 0; i < R; ++i) {
+            const int b = rows[size_t(i)];
+            if (nf[i]) {
+                bad.push_back(b);
+                continue;
+            }
+            // decoded-stream coordinates: sample p of the decode is sample p - cut of the row's audio; chunk k covers
+            // [k * step, (k + 1) * step). Chunks below `held` have been delivered from the first decode and stay as they are.
+            const int64_t cut = J.row_cut[size_t(b)], ns = J.row_ns[size_t(b)], step = int64_t(std::max(J.chunk_frames, 1)) * up;
+            const int held = J.n_chunks > 0 ? std::max(0, J.held_from[size_t(b)]) : 0;
+            const int64_t from = J.n_chunks > 0 ? std::min(ns, std::max<int64_t>(0, int64_t(held) * step - cut)) : 0;
+            std::memcpy(J.st_pcm[size_t(b)] + from, hpcm + size_t(i) * Fd * up + cut + from, size_t(ns - from) * 4);
+            if (J.cb && J.n_chunks > 0) {  // the pieces fire_chunks held back
+                std::unique_lock<std::mutex> lk;
+                if (cb_mutex) lk = std::unique_lock<std::mutex>(*cb_mutex);
+                for (int k = held; k < J.n_chunks; ++k) {
+                    const int64_t lo = std::max(int64_t(k) * step, cut), hi = std::min(int64_t(k + 1) * step, cut + ns);
+                    if (hi <= lo) continue;
+                    q3tts_event ev{};
+                    ev.kind = Q3TTS_EVENT_AUDIO_CHUNK;
+                    ev.request_index = J.request_base + b;
+                    ev.pcm = J.st_pcm[size_t(b)] + (lo - cut);
+                    ev.n_samples = hi - lo;
+                    ev.sample_offset = lo - cut;
+                    J.cb(J.user, &ev);
+                }
+            }
+        }
+    } catch (...) {
+        cleanup();
+        throw;
+    }
+    cleanup();
+    return bad;
+}
+
+
 void Engine::end(int job, q3tts_result* results) {
     Q3_CHECK(job >= 0 && job < kJobSlots && jobs_[job].busy, 3, "Invalid input: no such outstanding job");
     Job& J = jobs_[job];
@@ -1597,6 +1703,8 @@ void Engine::end(int job, q3tts_result* results) {
         }
     }
     if (J.stage == 3) throw Error(5, J.stage_err);
+    // rows whose activations left the fp16 range of the default codec kernels: once more on the fp32 matrix cores
+    const std::vector<int> still_bad = redo_rows_fp32(J);
     float ms = 0;
     Q3_HIP(hipEventElapsedTime(&ms, J.ev_codec[0], J.ev_codec[1]));
     J.timing.codec_ms = ms;  // on the codec stream: includes whatever the next batch's AR loop took away from it
@@ -1622,7 +1730,7 @@ void Engine::end(int job, q3tts_result* results) {
             r.status = Q3TTS_ERR_GENERATION_FAILED;
             continue;
         }
-        if (J.nf_host[b]) {  // never hand out a waveform with holes in it
+        if (std::find(still_bad.begin(), still_bad.end(), b) != still_bad.end()) {  // never hand out a waveform with holes in it
             r.status = Q3TTS_ERR_AUDIO_DECODING_FAILED;
             last_error = kCodecRangeMsg;
             std::free(J.st_pcm[size_t(b)]);
@@ -1754,6 +1862,22 @@ void Engine::codec_decode(const int32_t* codes, const int32_t* n_frames, int bat
     {
         bool bad = false;
         for (int b = 0; b < batch; ++b) bad = bad || nf[b] != 0;
+        if (bad && !codec_->fp32_convs()) {
+            // an activation left the fp16 range of the default kernels: the whole call once more on the fp32 matrix cores (the
+            // reference's range; redo_rows_fp32 does the same for rows of a generate call)
+            std::memset(nf, 0, size_t(batch) * 4);
+            try {
+                codec_->decode(dcodes, max_frames, frames, &pcm_dev, std::string(), nullptr, nullptr, nullptr, nf, true);
+                Q3_HIP(hipEventRecord(ev_[3], cst));
+                Q3_HIP(hipStreamSynchronize(cst));
+            } catch (...) {
+                (void)hipFree(dcodes);
+                (void)hipHostFree(nf);
+                throw;
+            }
+            bad = false;
+            for (int b = 0; b < batch; ++b) bad = bad || nf[b] != 0;
+        }
         (void)hipHostFree(nf);
         if (bad) {
             (void)hipFree(dcodes);

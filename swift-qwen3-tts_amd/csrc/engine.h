@@ -152,6 +152,9 @@ class Engine {
         size_t pcm_host_cap = 0;
         hipEvent_t ev_codec[2] = {nullptr, nullptr};
         int32_t* nf_host = nullptr;  // pinned [max_batch]: rows whose waveform came out non-finite (CodecRunner::decode)
+        int32_t* nf_chunk_host = nullptr;  // pinned [chunks][n]: the same flags behind every chunk of a streamed job
+        size_t nf_chunk_cap = 0;
+        std::vector<int> held_from;  // streamed job: first chunk of row b that is held back for the fp32 re-decode (-1: none)
         hipEvent_t ev_begin = nullptr, ev_first_audio = nullptr;  // request in / first streamed chunk on the host
         std::vector<hipEvent_t> chunk_done;  // chunked decode (audio_chunk_frames > 0): one per chunk, behind its copy
         int n_chunks = 0, chunk_frames = 0;
@@ -177,6 +180,9 @@ class Engine {
     // AUDIO_CHUNK events of chunks [J.chunks_fired, upto); rows are clipped to known[b] frames (their final length when known)
     void fire_chunks(Job& J, int upto, const std::vector<int>* known, bool wait);
     void stage_rows(Job& J);   // waits for the decode, then copies; throws
+    // rows whose waveform left the fp16 range of the default codec kernels are decoded again on the fp32 matrix cores
+    // (the reference's range) before end() hands them out; returns the rows that are non-finite even then
+    std::vector<int> redo_rows_fp32(Job& J);
     void staging_loop();
     std::thread stager_;
     std::mutex stage_mu_;

@@ -344,8 +344,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
 // r.m.s., 2^-22 worst case) and the dropped term -- per-product noise at the level of ONE fp32 rounding, which adds up
 // as sqrt(K) while an fp32 fmaf chain's own rounding adds up as K: on a K = 5376 contraction the simulated error against
 // double is 0.3x the fmaf chain's (tools/split_sim.py). Range: |x| must stay below 65504 (fp16); a decoder activation
-// beyond that turns into inf/NaN and reaches the PCM as a non-finite sample, which out_conv reports (codec.cc re-runs the
-// decode on the fp32 matrix-core kernels then).
+// beyond that turns into inf/NaN and reaches the PCM as a non-finite sample, which out_conv reports per row; the engine then
+// decodes the flagged rows once more on the fp32 matrix-core kernel below (Engine::redo_rows_fp32, Engine::codec_decode).
 // An LDS row holds the two planes of 32 input channels (2 x 64 B) + 32 B of padding = 10 sixteen-byte units (10 = 2 mod 4:
 // conflict-free ds_read_b128); weight tiles are double-buffered (one barrier per tap): (128 + halo + 2 BN) x 160 B <= 70 KiB.
 constexpr int ROWH = 40;  // dwords per LDS row

@@ -1,17 +1,19 @@
 """The decoder's default convolutions split every fp32 operand into two fp16 planes (csrc/kernels/codec_conv.hip): same
-accuracy as the fp32 matrix cores, but an activation beyond 65504 cannot be represented. Such a decode must not hand out a
-waveform with holes in it: the row reports Q3TTS_ERR_AUDIO_DECODING_FAILED and names the load option that has the
-reference's range (codec_fp32), under which the same checkpoint decodes."""
+accuracy as the fp32 matrix cores, but an activation beyond 65504 cannot be represented. The reference computes in fp32 and
+decodes such a checkpoint, so the engine must too: a row whose waveform comes out non-finite is decoded again on the fp32
+matrix cores (Engine::redo_rows_fp32 / Engine::codec_decode) and handed out with status OK -- the same samples the
+codec_fp32 load option gives -- in every delivery mode: one-shot, in pieces after the last token, streamed."""
 import os
 
 import numpy as np
 import pytest
 
+from conftest import tiny_request
 
-@pytest.mark.gpu
-def test_out_of_range_activation_is_reported_and_the_fp32_path_decodes(tmp_path):
+
+def _big_bias_checkpoint(tmp_path):
     from safetensors.numpy import load_file, save_file
-    from qwen3tts import Qwen3TTSError, Qwen3TTSModel, synth
+    from qwen3tts import synth
     d = str(tmp_path / "m")
     synth.write_checkpoint(d, "tiny-a", seed=1234)
     f = os.path.join(d, "speech_tokenizer", "model.safetensors")
@@ -20,17 +22,51 @@ def test_out_of_range_activation_is_reported_and_the_fp32_path_decodes(tmp_path)
     assert key, sorted(t)[:40]
     t[key[0]] = (t[key[0]].astype(np.float32) + np.float32(3.0e5)).astype(t[key[0]].dtype)   # far beyond fp16's 65504
     save_file(t, f)
+    return d
+
+
+@pytest.mark.gpu
+def test_out_of_range_activations_fall_back_to_the_fp32_matrix_cores(tmp_path):
+    from qwen3tts import GenerationRequest, Qwen3TTSModel
+    d = _big_bias_checkpoint(tmp_path)
     codes = np.random.default_rng(0).integers(1, 32, size=(2, 6, 16)).astype(np.int32)
-    m = Qwen3TTSModel.from_pretrained(d, max_batch=2, max_frames=16, max_prompt=64)
+    r = tiny_request(row=0, n_text=6)
+    reqs = [GenerationRequest(r["text_ids"], 1, None, "aiden", "english")] * 2
+    kw = dict(temperature=0.0, force_frames=24)
+    m = Qwen3TTSModel.from_pretrained(d, max_batch=2, max_frames=32, max_prompt=64, codec_fp32=True)
     try:
-        with pytest.raises(Qwen3TTSError) as e:
-            m.codec_decode(codes)
-        assert e.value.status == 4 and "codec_fp32" in str(e.value)
+        want, lens = m.codec_decode(codes)
+        assert np.isfinite(want).all() and (lens == 6 * 1920).all()
+        gen_want = m.generate_batch(reqs, **kw)
+        assert all(x.status == 0 and np.isfinite(x.audio).all() and np.abs(x.audio).max() > 0 for x in gen_want)
     finally:
         m.close()
-    m = Qwen3TTSModel.from_pretrained(d, max_batch=2, max_frames=16, max_prompt=64, codec_fp32=True)
+    m = Qwen3TTSModel.from_pretrained(d, max_batch=2, max_frames=32, max_prompt=64)   # the default (fp16 two-plane) kernels
     try:
-        pcm, lens = m.codec_decode(codes)
-        assert np.isfinite(pcm).all() and (lens == 6 * 1920).all()
+        got, lens = m.codec_decode(codes)                     # q3tts_codec_decode: the whole call again in fp32
+        assert (lens == 6 * 1920).all() and (got == want).all()
+        for mode in (dict(), dict(audio_chunk_frames=8), dict(audio_chunk_frames=8, audio_window_frames=64, audio_lookahead_frames=64)):
+            pieces = {0: [], 1: []}
+            kinds = {0: [], 1: []}
+
+            def on_event(i, kind, payload):
+                kinds[i].append(kind)
+                if kind == "audio_chunk":
+                    pieces[i].append(payload)
+
+            out = m.generate_batch(reqs, on_event=on_event, **kw, **mode)
+            for i, (a, b) in enumerate(zip(out, gen_want)):
+                assert a.status == 0 and (a.codes == b.codes).all(), mode
+                assert np.isfinite(a.audio).all() and a.audio.shape == b.audio.shape
+                if "audio_window_frames" not in mode:           # exact modes: the fp32 kernels' samples
+                    assert (a.audio == b.audio).all(), mode
+                else:                                           # (a window over everything: the one-shot arithmetic again)
+                    assert np.abs(a.audio - b.audio).max() <= 1e-5, mode
+                if mode:
+                    offs = [o for o, _ in pieces[i]]
+                    assert offs == sorted(offs) and offs[0] == 0 and len(pieces[i]) == 3
+                    cat = np.concatenate([p for _, p in pieces[i]])
+                    assert np.isfinite(cat).all() and (cat == a.audio).all(), mode   # nothing non-finite ever left in a chunk
+                assert kinds[i][-2:] == ["info", "audio"]
     finally:
         m.close()

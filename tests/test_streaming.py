@@ -120,7 +120,9 @@ def _full_codec_dir(tmp_path_factory, name):
 @pytest.fixture(scope="module")
 def full_codec_model(tmp_path_factory):
     from qwen3tts import Qwen3TTSModel
-    m = Qwen3TTSModel.from_pretrained(_full_codec_dir(tmp_path_factory, "full_codec_streamed"), max_batch=4, max_frames=96, max_prompt=64)
+    d = _full_codec_dir(tmp_path_factory, "full_codec_streamed")
+    m = Qwen3TTSModel.from_pretrained(d, max_batch=4, max_frames=96, max_prompt=64)
+    m.ckpt_dir = d  # (the oracle loads the same files)
     yield m
     m.close()
 
@@ -150,6 +152,51 @@ def test_carried_state_tail_is_bit_identical(ckpt_dirs, full_codec_model, chunk)
                 m.close()
 
 
+def test_a_failed_stream_open_leaves_the_runner_usable(ckpt_dirs):
+    """stream_open sizes its arena in a counting pass during which the conv launcher launches nothing; an allocation that
+    fails behind that pass (here: a chunk of fifty million frames) must not leave the runner counting -- every later decode of
+    the model would then skip its convolutions and return finite garbage with status OK."""
+    from qwen3tts import Qwen3TTSError, Qwen3TTSModel
+    m = Qwen3TTSModel.from_pretrained(ckpt_dirs["tiny-b"], max_batch=4, max_frames=96, max_prompt=64)
+    try:
+        codes = np.random.default_rng(4).integers(1, 32, size=(2, 12, 16)).astype(np.int32)
+        want, _ = m.codec_decode(codes)
+        with pytest.raises(Qwen3TTSError):
+            m.codec_decode_streamed(codes, 50_000_000, 4, 0)
+        again, _ = m.codec_decode(codes)
+        assert np.abs(want).max() > 1e-4 and (again == want).all()
+        assert (m.codec_decode_streamed(codes, 4, -1) == want).all()   # and streams still open
+    finally:
+        m.close()
+
+
+def test_windowed_stream_matches_the_oracles_windowed_decode(ckpt_dirs, full_codec_model):
+    """The windowed mode against a second implementation: OracleModel.codec_decode_streamed composes the reference's own
+    functions the way a stream can run them (pre_transformer over [f0 - window, f1 + lookahead) per chunk, causal tail over the
+    concatenated latents). The bar is the one-shot decode's: PCM within 1e-4 absolute on every sample -- tiny and real layer
+    widths, ragged rows, chunk sizes that do and do not divide the rows' lengths."""
+    from oracle import oracle as O
+    from qwen3tts import Qwen3TTSModel
+    tiny = Qwen3TTSModel.from_pretrained(ckpt_dirs["tiny-b"], max_batch=4, max_frames=96, max_prompt=64)
+    tiny.ckpt_dir = ckpt_dirs["tiny-b"]
+    try:
+        for m, F, geoms in ((tiny, [37, 5, 22], ((8, 16, 2), (5, 4, 0), (7, 3, 9), (16, 64, 64))),
+                            (full_codec_model, [19, 8], ((8, 16, 2), (5, 4, 0)))):
+            om = O.OracleModel(m.ckpt_dir)
+            rng = np.random.default_rng(len(F))
+            codes = np.zeros((len(F), max(F), 16), np.int32)
+            for b, f in enumerate(F):
+                codes[b, :f] = rng.integers(1, min(m.info.cp_vocab_size, 2048), size=(f, 16))
+            for C_, W, L_ in geoms:
+                got = m.codec_decode_streamed(codes, C_, W, L_, n_frames=F)
+                for b, f in enumerate(F):
+                    want = om.codec_decode_streamed(codes[b, :f], C_, W, L_)
+                    err = float(np.abs(got[b, :f * 1920] - want).max())
+                    assert want.size == f * 1920 and err <= 1e-4, (C_, W, L_, b, err)
+    finally:
+        tiny.close()
+
+
 def test_sliding_window_distance_from_the_one_shot_decode(full_codec_model):
     """What a stream gives up: the pre-transformer is bidirectional over the whole utterance (SpeechTokenizer.swift:763); a
     chunk decoded while later tokens do not exist yet sees `window` frames to the left and `lookahead` to the right. The
@@ -172,7 +219,8 @@ def test_sliding_window_distance_from_the_one_shot_decode(full_codec_model):
     for k, v in table.items():
         print("  W=%3d L=%3d   max %.3e   rms %.3e" % (k + v))
     assert table[(F, F)][0] <= 1e-6                 # a window that covers everything: the one-shot decode again
-    assert table[(32, 4)][0] <= 2e-2 and table[(32, 4)][1] <= 0.05 * rms   # the default streaming geometry (stated tolerance)
+    # The distances themselves are REPORTED, not promised: they are a property of the checkpoint (include/q3tts.h). What the
+    # arithmetic guarantees is pinned against the oracle in test_windowed_stream_matches_the_oracles_windowed_decode.
     assert table[(64, 8)][1] <= table[(4, 0)][1] + 1e-9
 
 
@@ -206,7 +254,6 @@ def test_audio_leaves_before_the_last_token(ckpt_dirs):
             assert offs == [k * 8 * 1920 for k in range(8)]
             cat = np.concatenate([p for _, p in pieces[i]])
             assert (cat == a.audio).all() and (a.audio == ref[i]).all()
-            assert np.abs(a.audio - b.audio).max() <= 2e-2          # the window's price on this checkpoint
         assert 0 < tm.first_audio_ms < tm.prefill_ms + tm.decode_ms, (tm.first_audio_ms, tm.decode_ms)
     finally:
         m.close()
