@@ -123,6 +123,48 @@ def ensure_checkpoint(preset: str, rank: int, dist) -> str:
     return d
 
 
+class _DryModel:
+    """Stand-in for the engine when there is no GPU (Q3TTS_BENCH_DRY=1, tests/test_distributed_cpu.py): it decodes nothing --
+    rows come back with the requested number of frames -- so that the N > 1 CONTROL path of this file (shard, broadcast,
+    checksum, pipelined begin/end, MAX / SUM reduction, the JSON line) runs end to end under gloo on CPU. Never used on a GPU
+    box: the product path fails loudly when the HIP engine is missing."""
+
+    class _Info:
+        weight_bytes = 1 << 20
+
+    class _Res:
+        def __init__(self, frames):
+            self.codes = np.zeros((frames, 16), np.int32)
+
+    def __init__(self, rank, empty):
+        import torch
+        g = torch.Generator().manual_seed(5)
+        ref = torch.randint(0, 256, (1 << 16,), dtype=torch.uint8, generator=g)
+        self.arena_t = torch.zeros_like(ref) if empty else ref
+        self.info = self._Info()
+        self._frames = 0
+
+    def arena_checksum(self):
+        return int(self.arena_t.view(dtype=__import__("torch").int32).to(__import__("torch").int64).sum().item())
+
+    def generate_batch(self, reqs, force_frames=0, **kw):
+        self._frames = force_frames
+        time.sleep(0.01)
+        return [self._Res(force_frames) for _ in reqs]
+
+    def generate_batch_begin(self, reqs, force_frames=0, **kw):
+        return (len(reqs), force_frames)
+
+    def generate_batch_end(self, job):
+        time.sleep(0.01)
+        return [self._Res(job[1]) for _ in range(job[0])]
+
+    def last_timing(self):
+        from types import SimpleNamespace
+        return SimpleNamespace(prefill_ms=1.0, decode_ms=8.0, codec_ms=2.0, frontend_ms=0.0, frame_steps=max(self._frames, 1),
+                               kv_bytes_read=0, first_audio_ms=0.0)
+
+
 def cpu_baseline(ckpt: str, preset: str, n_text: int, n_instruct: int, frames: int) -> dict:
     """Oracle (CPU restatement, OpenMP) on a bounded sample: batch 1, same prompt shape, `frames`
     frames, greedy, end to end (prompt assembly + prefill + AR loop + codec decode)."""
@@ -176,10 +218,12 @@ def main():
         local = 0
     backend = os.environ.get("Q3TTS_BENCH_BACKEND", "nccl")
     dist = None
+    dry = os.environ.get("Q3TTS_BENCH_DRY") == "1"  # no GPU: the control path only (_DryModel)
     if world > 1:
         import torch
         import torch.distributed as dist_mod
-        torch.cuda.set_device(local)
+        if not dry:
+            torch.cuda.set_device(local)
         if backend == "nccl":
             dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -190,25 +234,60 @@ def main():
     from qwen3tts import Qwen3TTSModel
     n_instruct = 16 if args.preset == "1.7b" else 0
     clone = args.preset.endswith("-base")
-    ckpt = ensure_checkpoint(args.preset, rank, dist)
     B = args.batch or (16 if clone else 64 if args.preset == "0.6b-q4" else 32)
     rep = 1.5 if clone else 1.05  # generateVoiceClone's default (Qwen3.swift:1017)
-    # rank 0 reads the checkpoint; replicas receive the weight arena by one RCCL broadcast over xGMI
-    model = Qwen3TTSModel.from_pretrained(ckpt, device=local, max_batch=B, max_frames=args.frames + 8, max_prompt=192 if clone else 128,
-                                          use_graph=not args.no_graph, n_streams=args.streams, codec_overlap_cus=args.codec_cus,
-                                          weights_from_broadcast=(world > 1 and rank != 0))
+    if dry:
+        ckpt = None
+        model = _DryModel(rank, empty=(world > 1 and rank != 0))
+    else:
+        ckpt = ensure_checkpoint(args.preset, rank, dist)
+        # rank 0 reads the checkpoint; replicas receive the weight arena by one RCCL broadcast over xGMI
+        model = Qwen3TTSModel.from_pretrained(ckpt, device=local, max_batch=B, max_frames=args.frames + 8, max_prompt=192 if clone else 128,
+                                              use_graph=not args.no_graph, n_streams=args.streams, codec_overlap_cus=args.codec_cus,
+                                              weights_from_broadcast=(world > 1 and rank != 0))
+    weight_broadcast = None
     if world > 1:
         import torch
-        ptr, nbytes = model.arena()
+        dev = torch.device("cpu") if dry else torch.device("cuda", local)  # where the small tensors of the collectives live
+        # The job's only collective. Default: the library's own broadcast (q3tts_model_broadcast: RCCL straight from
+        # the C ABI, the path a Swift or C host takes -- torch only carries the 128-byte communicator id). Fallback, and the
+        # one-device gloo rehearsal: torch.distributed over a zero-copy view of the arena.
+        want_native = os.environ.get("Q3TTS_BENCH_BROADCAST", "native") == "native" and backend == "nccl" and not dry
+        ok = 0
+        if want_native:
+            ids = [None]
+            if rank == 0:
+                try:
+                    ids[0] = Qwen3TTSModel.comm_unique_id()
+                except Exception as e:  # RCCL missing: every rank takes the torch path
+                    print(f"[bench] native broadcast unavailable: {e}", file=sys.stderr)
+            dist.broadcast_object_list(ids, src=0)
+            if ids[0] is not None:
+                try:
+                    model.broadcast_weights(ids[0], rank, world, 0)
+                    ok = 1
+                except Exception as e:
+                    print(f"[bench] rank {rank}: native broadcast failed: {e}", file=sys.stderr)
+            agreed = torch.tensor([ok], device=dev, dtype=torch.int32)
+            dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+            ok = int(agreed.item())
+        if ok:
+            weight_broadcast = "q3tts_model_broadcast (RCCL from the C ABI)"
+        elif dry:
+            broadcast_weights(dist, model.arena_t, src=0)
+            weight_broadcast = f"torch.distributed ({backend}), dry run"
+        else:
+            ptr, nbytes = model.arena()
 
-        class _Arena:  # zero-copy view of the engine's weight arena for torch.distributed
-            __cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+            class _Arena:  # zero-copy view of the engine's weight arena for torch.distributed
+                __cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
-        arena = torch.as_tensor(_Arena(), device=torch.device("cuda", local))
-        broadcast_weights(dist, arena, src=0)
-        torch.cuda.synchronize()
+            arena = torch.as_tensor(_Arena(), device=torch.device("cuda", local))
+            broadcast_weights(dist, arena, src=0)
+            torch.cuda.synchronize()
+            weight_broadcast = f"torch.distributed ({backend})"
         # every replica now holds rank 0's bytes: compare a checksum of the arena across ranks
-        ck = arena.view(torch.int32)[: arena.numel() // 4].to(torch.int64).sum().reshape(1)
+        ck = torch.tensor([model.arena_checksum() & ((1 << 62) - 1)], device=dev, dtype=torch.int64)
         lo_ck, hi_ck = ck.clone(), ck.clone()
         dist.all_reduce(lo_ck, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi_ck, op=dist.ReduceOp.MAX)
@@ -227,7 +306,8 @@ def main():
         if dist is not None:
             import torch
             dist.barrier()
-            torch.cuda.synchronize()
+            if not dry:
+                torch.cuda.synchronize()
 
     solo = None  # phase times of one batch running alone (last warm-up step): nothing overlaps there
     for _ in range(args.warmup):
@@ -277,7 +357,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        elapsed, frames_done = reduce_job_stats(dist, elapsed, frames_done, torch.device("cuda", local))
+        elapsed, frames_done = reduce_job_stats(dist, elapsed, frames_done, torch.device("cpu") if dry else torch.device("cuda", local))
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -325,7 +405,8 @@ def main():
                                   if clone else "")
                                + "prompt assembly + prefill + hipGraph AR decode + fp32-equivalent (two-plane fp16 split) codec decode -> 24 kHz PCM"
                                + ("; steps pipelined two deep (a step's codec decode overlaps the next step's AR loop)" if pipelined else ""),
-                   "batch_per_gpu": B, "frames_per_utterance": args.frames, "parallelism": f"batch-shard x{world}"},
+                   "batch_per_gpu": B, "frames_per_utterance": args.frames, "parallelism": f"batch-shard x{world}",
+                   "weight_broadcast": weight_broadcast},
         "rtf_audio_s_per_wall_s": value * FRAME_SECONDS, "rtf_wall_s_per_audio_s": 1.0 / (value * FRAME_SECONDS),
         # throughput reading: audio seconds per wall second, per utterance of the batch
         "rtf_per_utterance": value * FRAME_SECONDS / (B * world),
@@ -354,7 +435,7 @@ def main():
                            "narrow_stages_hbm": codec_hbm, "hbm_peak_gbs": HBM_PEAK_GBS,
                            "ms": codec_solo_ms, "measured": "one batch alone (last warm-up step)" if solo else "overlapped steps"},
     }
-    if world == 1 and not clone and not args.no_streaming:
+    if world == 1 and not clone and not args.no_streaming and not dry:
         # row f1, outside the timed region: one batch with the waveform streamed while the tokens are generated (16-frame
         # chunks, 32 frames of left context, 4 of look-ahead) -- when does the first audio reach the host?
         sk = dict(gen_kw, audio_chunk_frames=16, audio_window_frames=32, audio_lookahead_frames=4)
@@ -367,7 +448,7 @@ def main():
                             "one_shot_latency_ms": latency_ms, "chunk_frames": 16, "window_frames": 32, "lookahead_frames": 4,
                             "note": "time from the request to the first 16 frames (1.28 s) of audio of all rows on the host; "
                                     "the exact (one-shot) mode delivers everything after one_shot_latency_ms"}
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not dry:
         out["cpu_baseline"] = cpu_baseline(ckpt, args.preset, args.n_text, n_instruct, args.cpu_frames)
     if dist is not None:
         dist.destroy_process_group()

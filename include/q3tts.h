@@ -92,6 +92,21 @@ typedef struct {
 } q3tts_model_info;
 q3tts_status q3tts_model_get_info(const q3tts_model* m, q3tts_model_info* out);
 
+/* ---- multi-GPU (new: the reference is single-device, Qwen3.swift:1382-1470) ----------------------------------------------------
+ * Utterances are independent, so a job shards by rows: one process (or handle) and one full replica per GPU, NO collective on
+ * the data path. The only exchange is at load: rank `root` reads the checkpoint, every other rank loads with
+ * q3tts_load_opts.weights_from_broadcast = 1 (config only, empty arena) and receives the arena -- whose layout is a pure
+ * function of the config -- in one RCCL broadcast over xGMI. Recipe for a host without Python:
+ *   rank 0: q3tts_comm_get_unique_id(&id); ship the 128 bytes to the other ranks (file, socket, MPI, environment ...)
+ *   all   : q3tts_model_broadcast(model, &id, rank, world, 0);   // collective: every rank must call it
+ *   rank r: q3tts_generate(rows [r * B, (r + 1) * B), q3tts_sampling.row_base = r * B)   // draws what one big call would
+ * RCCL is opened at run time (librccl.so.1); single-GPU callers never need it. Status DEVICE (7) carries RCCL's message. */
+typedef struct { char bytes[128]; } q3tts_comm_id; /* == ncclUniqueId */
+q3tts_status q3tts_comm_get_unique_id(q3tts_comm_id* out);
+q3tts_status q3tts_model_broadcast(q3tts_model* m, const q3tts_comm_id* id, int32_t rank, int32_t world, int32_t root);
+/* 64-bit sum of the arena's 32-bit words (device-side reduction): equal on every rank after the broadcast. */
+q3tts_status q3tts_model_arena_checksum(q3tts_model* m, uint64_t* out);
+
 /* Qwen3TTSModel.supportedSpeakers, sorted (Qwen3.swift:965-971). */
 int32_t q3tts_model_num_speakers(const q3tts_model* m);
 const char* q3tts_model_speaker_name(const q3tts_model* m, int32_t i);

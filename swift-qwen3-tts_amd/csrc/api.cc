@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "codec.h"
+#include "comm.h"
 #include "engine.h"
 #include "tokenizer.h"
 
@@ -103,6 +104,29 @@ q3tts_status q3tts_model_arena(q3tts_model* m, void** device_ptr, size_t* bytes)
         Q3_CHECK(m && device_ptr && bytes, 3, "Invalid input: null argument");
         *device_ptr = m->eng->model().arena;
         *bytes = m->eng->model().arena_bytes;
+    });
+}
+
+q3tts_status q3tts_comm_get_unique_id(q3tts_comm_id* out) {
+    return guarded(nullptr, [&] {
+        Q3_CHECK(out, 3, "Invalid input: null argument");
+        q3::comm_unique_id(out);
+    });
+}
+
+q3tts_status q3tts_model_broadcast(q3tts_model* m, const q3tts_comm_id* id, int32_t rank, int32_t world, int32_t root) {
+    return guarded(m, [&] {
+        Q3_CHECK(m && id, 3, "Invalid input: null argument");
+        q3::Model& md = m->eng->model();
+        q3::comm_broadcast_arena(md.device, md.arena, md.arena_bytes, *id, rank, world, root);
+    });
+}
+
+q3tts_status q3tts_model_arena_checksum(q3tts_model* m, uint64_t* out) {
+    return guarded(m, [&] {
+        Q3_CHECK(m && out, 3, "Invalid input: null argument");
+        q3::Model& md = m->eng->model();
+        *out = q3::arena_checksum(md.device, md.arena, md.arena_bytes);
     });
 }
 

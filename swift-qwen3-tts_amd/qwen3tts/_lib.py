@@ -22,6 +22,10 @@ class LoadOpts(C.Structure):
                 ("n_streams", C.c_int32), ("codec_overlap_cus", C.c_int32), ("codec_fp32", C.c_int32)]
 
 
+class CommId(C.Structure):  # q3tts_comm_id == ncclUniqueId
+    _fields_ = [("bytes", C.c_char * 128)]
+
+
 class ModelInfo(C.Structure):
     _fields_ = [("tts_model_type", C.c_char * 32), ("sample_rate", C.c_int32),
                 ("supports_voice_cloning", C.c_int32), ("has_voice_cloning", C.c_int32),
@@ -93,6 +97,9 @@ def lib() -> C.CDLL:
     L.q3tts_last_error.restype = C.c_char_p
     L.q3tts_model_arena.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.q3tts_model_get_info.argtypes = [vp, C.POINTER(ModelInfo)]
+    L.q3tts_comm_get_unique_id.argtypes = [C.POINTER(CommId)]
+    L.q3tts_model_broadcast.argtypes = [vp, C.POINTER(CommId), C.c_int32, C.c_int32, C.c_int32]
+    L.q3tts_model_arena_checksum.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.q3tts_model_num_speakers.argtypes = [vp]
     L.q3tts_model_speaker_name.argtypes = [vp, C.c_int32]
     L.q3tts_model_speaker_name.restype = C.c_char_p

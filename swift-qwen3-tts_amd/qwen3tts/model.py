@@ -173,6 +173,27 @@ class Qwen3TTSModel:
         self._check(self._lib.q3tts_model_arena(self._h, C.byref(p), C.byref(n)))
         return int(p.value), int(n.value)
 
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """q3tts_comm_get_unique_id: 128 bytes that rank 0 ships to the other ranks of a sharded job (any channel)."""
+        cid = L.CommId()
+        st = L.lib().q3tts_comm_get_unique_id(C.byref(cid))
+        if st != 0:
+            raise Qwen3TTSError(st, (L.lib().q3tts_last_error(None) or b"").decode())
+        return C.string_at(C.addressof(cid), 128)  # (c_char arrays stop at the first NUL when read as .bytes)
+
+    def broadcast_weights(self, comm_id: bytes, rank: int, world: int, root: int = 0) -> None:
+        """q3tts_model_broadcast: the load-time RCCL broadcast of the weight arena (collective: every rank calls it)."""
+        assert len(comm_id) == 128
+        cid = L.CommId()
+        C.memmove(C.addressof(cid), comm_id, 128)
+        self._check(self._lib.q3tts_model_broadcast(self._h, C.byref(cid), rank, world, root))
+
+    def arena_checksum(self) -> int:
+        v = C.c_uint64()
+        self._check(self._lib.q3tts_model_arena_checksum(self._h, C.byref(v)))
+        return int(v.value)
+
     def last_timing(self) -> L.Timing:
         t = L.Timing()
         self._lib.q3tts_last_timing(self._h, C.byref(t))

@@ -35,6 +35,9 @@ def main():
         bench.broadcast_weights(dist, arena, src=0)
         torch.cuda.synchronize()
         after = int(arena.view(torch.int32)[: nbytes // 4].to(torch.int64).sum().item())
+        # the library's own device-side checksum (q3tts_model_arena_checksum: 64-bit sum of the unsigned words) against the host's
+        usum = int(arena.view(torch.int32)[: nbytes // 4].to(torch.int64).bitwise_and(0xffffffff).sum().item())
+        assert m.arena_checksum() == usum % (1 << 64), "q3tts_model_arena_checksum differs from the host-side sum"
         ck = torch.tensor([after], dtype=torch.int64)
         lo_ck, hi_ck = ck.clone(), ck.clone()
         dist.all_reduce(lo_ck, op=dist.ReduceOp.MIN)

@@ -54,3 +54,29 @@ def test_two_rank_gloo(tmp_path):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     spans = [np.load(tmp_path / f"ok{r}.npy") for r in range(world)]
     assert spans[0][1] == spans[1][0] == 32
+
+
+def test_bench_world2_control_path_end_to_end(tmp_path):
+    """bench.py launched the way the driver launches it for N = 2 (torch.distributed.run, one process per rank) under gloo,
+    BASELINE configs[4]'s preset (64 rows per rank): the whole N > 1 branch -- shard, weight broadcast + checksum, pipelined
+    begin / end, MAX-over-ranks elapsed, SUM-over-ranks frames, ONE JSON line from rank 0 -- with the engine replaced by a
+    stand-in that decodes nothing (Q3TTS_BENCH_DRY=1: there is no GPU here; the GPU box runs the real thing)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, Q3TTS_BENCH_DRY="1", Q3TTS_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--preset", "0.6b-q4", "--frames", "8"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]          # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["unit"] == "frames/s"
+    assert d["config"]["batch_per_gpu"] == 64 and d["config"]["parallelism"] == "batch-shard x2"
+    assert "gloo" in d["config"]["weight_broadcast"]
+    frames = 2 * 64 * 8 * 3                               # SUM over ranks of rows x frames x steps
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 * d["steps"] - frames) < 1e-6 * frames
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True

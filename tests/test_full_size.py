@@ -260,6 +260,28 @@ def test_config2_1p7b_batch32_logits_match_the_oracle(full_dir):
         m.close()
 
 
+def test_config2_1p7b_batch32_long_cache_matches_the_oracle(full_dir):
+    """The bench regime of BASELINE configs[2]: the headline run decodes 200 frames behind a 48-position prompt, so its attention
+    walks caches of up to 248 tokens = four KV pages through attn_decode_kernel<2, 512, true> (non-temporal, 32 lane groups,
+    page lookups through the block table) -- a regime the 4-frame tests above never reach. Here the prompts are 194 positions
+    long (180 instruct tokens), so the cache already spans four pages when the first frame is decoded and the chunked prefill
+    crosses three page boundaries; one row per 16-row block edge (0, 15, 16, 31) against the oracle, same bars as above
+    (Talker.swift:532-574)."""
+    import bench
+    from oracle import oracle as O
+    from qwen3tts import Qwen3TTSModel
+    m = Qwen3TTSModel.from_pretrained(full_dir, max_batch=32, max_frames=16, max_prompt=208)
+    try:
+        reqs = bench.build_requests("1.7b", 0, 32, 32, 180)
+        om = O.OracleModel(full_dir)
+        inp, _, _ = om.prepare_generation_inputs(_oracle_request(reqs[0]))
+        assert inp.shape[0] > 3 * 64, inp.shape    # the prompt alone fills more than three pages of 64 tokens
+        worst = _forced_parity(m, om, reqs, rows=(0, 15, 16, 31), F=4, seed=107)
+        print("1.7B batch 32, %d-position prompts: worst logit error %.2f bf16 ulp of the row scale" % (inp.shape[0], worst))
+    finally:
+        m.close()
+
+
 @pytest.fixture(scope="module")
 def small_dir():
     return _ckpt("0.6b")

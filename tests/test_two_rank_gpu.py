@@ -64,3 +64,31 @@ def test_two_ranks_one_device_equal_the_single_process_rows(ckpt_dirs, tmp_path)
     for i, w in enumerate(want):
         assert (got_codes[i] == w.codes).all() and (got_audio[i] == w.audio).all(), i
     assert len({tuple(c[:, 0]) for c in got_codes}) == total   # and the rows are not copies of each other
+
+
+@pytest.mark.gpu
+def test_native_broadcast_on_a_single_rank_communicator(ckpt_dirs):
+    """q3tts_comm_get_unique_id / q3tts_model_broadcast / q3tts_model_arena_checksum (csrc/comm.cc): RCCL opened at run time from
+    the C ABI, a communicator of one rank on this box's one GPU, the arena broadcast onto itself. What this pins on hardware:
+    the library finds RCCL, the call sequence (ncclCommInitRank -> ncclBroadcast on the arena -> sync -> ncclCommDestroy) is
+    accepted and the arena is unchanged by it (checksum, and the rows a generate call produces). The checksum itself is
+    compared with a host-side sum of the same bytes in _two_rank_worker.py, where torch owns the process's GPU runtime."""
+    from qwen3tts import GenerationRequest, Qwen3TTSModel
+    m = Qwen3TTSModel.from_pretrained(ckpt_dirs["tiny-b"], max_batch=2, max_frames=16, max_prompt=64)
+    e = Qwen3TTSModel.from_pretrained(ckpt_dirs["tiny-b"], max_batch=2, max_frames=16, max_prompt=64, weights_from_broadcast=True)
+    try:
+        r = tiny_request(row=0, n_text=7)
+        reqs = [GenerationRequest(r["text_ids"], r["target_token_count"], r["instruct_ids"], r["speaker"], r["language"])]
+        kw = dict(temperature=0.9, top_k=40, seed=3, force_frames=6)
+        want = m.generate_batch(reqs, **kw)[0]
+        before = m.arena_checksum()
+        assert before != 0 and e.arena_checksum() != before      # a replica starts without the weights
+        cid = Qwen3TTSModel.comm_unique_id()
+        assert len(cid) == 128 and any(cid)
+        m.broadcast_weights(cid, 0, 1, 0)
+        assert m.arena_checksum() == before
+        got = m.generate_batch(reqs, **kw)[0]
+        assert (got.codes == want.codes).all() and (got.audio == want.audio).all()
+    finally:
+        m.close()
+        e.close()
