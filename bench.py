@@ -199,7 +199,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="utterances per GPU (default 32; 16 for *-base; 64 for 0.6b-q4)")
     ap.add_argument("--frames", type=int, default=200)
     ap.add_argument("--n-text", type=int, default=32)
-    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the bounded CPU-oracle sample (about 10-15 s of CPU work)")
+    ap.add_argument("--cpu-frames", type=int, default=75, help="frames of the bounded CPU-oracle sample: 75 = the reference's floor (SURVEY 8d), about 20 s of CPU work on the box's 16-core share")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--greedy", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (profiling)")

@@ -333,7 +333,7 @@ struct MainTensors {
     const SafetensorsDir& st;
     const TensorView& bf16(const std::string& k, std::vector<int64_t> shape) const {
         const TensorView& tv = st.at(k);
-        Q3_CHECK(tv.dtype == DType::BF16, 6, "tensor '" + k + "' must be bf16 (quantised checkpoints: int4 path not built yet)");
+        Q3_CHECK(tv.dtype == DType::BF16, 6, "tensor '" + k + "' must be bf16 (only Linear weights and embedding tables may be int4-quantised: .weight uint32 + .scales / .biases)");
         Q3_CHECK(tv.shape == shape, 6, "tensor '" + k + "' has an unexpected shape");
         return tv;
     }
