@@ -383,7 +383,10 @@ def main():
     # (two-plane split, codec_conv.hip) -- `achieved` counts exactly those, `fp32_equivalent_tflops` the useful work
     n_frames_step = B * args.frames
     codec_solo_ms = solo["codec_decode"] if solo else codec_ms / args.steps
-    codec_products = 3
+    # a float16 ("lite") speech tokenizer decodes in float16 like the reference's: ONE fp16 product per block from initConv on
+    # (codec_conv_h1.hip; 96 % of the decoder's MACs), three in front of it
+    codec_f16 = args.preset == "0.6b-q4"
+    codec_products = 1 if codec_f16 else 3
     codec_flops_bf16 = codec_products * 2 * 2.484e9 * n_frames_step
     latency_ms = (solo["voice_frontend"] + solo["prefill"] + solo["ar_decode"] + solo["codec_decode"]) if solo else None
     # HBM GB/s of the decoder's two narrow stages from the PMC passes committed under profiles/ (FETCH_SIZE x 2 +
@@ -403,7 +406,9 @@ def main():
                                f"{args.n_text} text + {n_instruct} instruct tokens, T={temp} top-k 50, "
                                + ("voice clone: 3.0 s reference clip per row -> codec encoder + speaker encoder + ICL prompt, "
                                   if clone else "")
-                               + "prompt assembly + prefill + hipGraph AR decode + fp32-equivalent (two-plane fp16 split) codec decode -> 24 kHz PCM"
+                               + "prompt assembly + prefill + hipGraph AR decode + "
+                               + ("float16 codec decode (float16 speech tokenizer, as the reference computes it)" if codec_f16
+                                  else "fp32-equivalent (two-plane fp16 split) codec decode") + " -> 24 kHz PCM"
                                + ("; steps pipelined two deep (a step's codec decode overlaps the next step's AR loop)" if pipelined else ""),
                    "batch_per_gpu": B, "frames_per_utterance": args.frames, "parallelism": f"batch-shard x{world}",
                    "weight_broadcast": weight_broadcast},
@@ -427,8 +432,8 @@ def main():
                      # the same kernel with nothing beside it (last warm-up step): in the pipelined region the frame loop
                      # shares the chip with the previous batch's codec decode, which is what `frac` above includes
                      "frac_alone": (algo_bytes / (solo["frame_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if solo and solo["frame_step"] else None},
-        "roofline_codec": {"bound": "mfma", "kernel": "codec decoder (conv_gemm_h2 / resunit_h2: fp16 MFMA, %d executed products per "
-                           "fp32 product block)" % codec_products, "executed_products_per_fp32_product": codec_products, "achieved": codec_flops_bf16 / (codec_solo_ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
+        "roofline_codec": {"bound": "mfma", "kernel": ("codec decoder (conv_gemm_h1: float16 tensors, one fp16 MFMA product per block)" if codec_f16 else
+                                                        "codec decoder (conv_gemm_h2 / resunit_h2: fp16 MFMA, %d executed products per fp32 product block)" % codec_products), "executed_products_per_fp32_product": codec_products, "achieved": codec_flops_bf16 / (codec_solo_ms * 1e-3) / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
                            "unit": "TFLOP/s", "frac": codec_flops_bf16 / (codec_solo_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS,
                            "fp32_equivalent_tflops": 2 * 2.484e9 * n_frames_step / (codec_solo_ms * 1e-3) / 1e12,
                            "algorithmic_gmac_per_frame": 2.484, "frames_per_launch_sequence": n_frames_step,

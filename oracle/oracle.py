@@ -453,7 +453,12 @@ class OracleModel:
                 sraw = json.load(f)
             self.dc = _with_defaults(sraw.get("decoder_config"), _DEC_DEF)
             self.ec = _with_defaults(sraw["encoder_config"], _ENC_DEF) if sraw.get("encoder_config") else None
-            self.codec = sanitize_speech_tokenizer(load_safetensors_dir(st_dir))
+            raw_codec = load_safetensors_dir(st_dir)
+            # "lite" checkpoints store the speech tokenizer in float16 (docs/paper.tex:207): the reference then computes the decoder
+            # in float16 (MLX promotes nothing: fp16 weights x fp16 activations). codec_decode(..., f16=True) restates that.
+            self.codec_f16 = any(k.startswith("decoder.decoder.") and v.dtype == np.float16 for k, v in raw_codec.items())
+            self.codec = {k: (v.astype(np.float32) if v.dtype == np.float16 else v)
+                          for k, v in sanitize_speech_tokenizer(raw_codec).items()}
         self.sc = _with_defaults(raw["speaker_encoder_config"], _SPK_DEF) if raw.get("speaker_encoder_config") else None
         _ = L
 
@@ -651,8 +656,8 @@ class OracleModel:
         return tr
 
     # -- codec decoder ------------------------------------------------------------------------
-    def _conv(self, x, prefix, K, dil=1, groups=1):
-        W, b = self.codec[prefix + ".weight"], self.codec.get(prefix + ".bias")
+    def _conv(self, x, prefix, K, dil=1, groups=1, with_bias=True):
+        W, b = self.codec[prefix + ".weight"], (self.codec.get(prefix + ".bias") if with_bias else None)
         T, Cin = x.shape
         Cout = W.shape[0]
         assert W.shape[1] == K and W.shape[2] == Cin // groups, (prefix, W.shape, K, Cin)
@@ -661,8 +666,8 @@ class OracleModel:
                               C.c_int(Cout), C.c_int(K), C.c_int(dil), C.c_int(groups), _pf(out))
         return out
 
-    def _convtr(self, x, prefix, K, stride):
-        W, b = self.codec[prefix + ".weight"], self.codec.get(prefix + ".bias")
+    def _convtr(self, x, prefix, K, stride, with_bias=True):
+        W, b = self.codec[prefix + ".weight"], (self.codec.get(prefix + ".bias") if with_bias else None)
         T, Cin = x.shape
         Cout = W.shape[0]
         assert W.shape[1] == K and W.shape[2] == Cin, (prefix, W.shape)
@@ -805,12 +810,76 @@ class OracleModel:
         h = self._conv(h, "decoder.decoder.outConv.conv", 7)
         return np.clip(h[:, 0], -1.0, 1.0).astype(np.float32)  # :781
 
-    def codec_decode(self, codes: np.ndarray, stages: Optional[dict] = None):
+    # -- the MainDecoder the way the reference computes it on a float16 checkpoint --------------------------------------------
+    # MLX evaluates every op in the arrays' dtype: with float16 weights the decoder's tensors are float16 and EVERY op result is
+    # rounded to float16 (conv, + bias, x * alpha, sin, s * s, (1 / beta) * q, x + r, residual + h: SpeechTokenizer.swift:246-253,
+    # 298-306, 346-352, 430-437). What MLX does INSIDE an op is not visible from the Swift: contractions are taken with fp32
+    # accumulation and sin in fp32 before the rounding (documented choice, like the bf16 stacks'). Restated from initConv on
+    # (96 % of the decoder's arithmetic): the front end and the two ConvNeXt stages stay in fp32, as in the engine -- wider than
+    # the reference there, by less than one float16 rounding of the tensor that enters initConv.
+    @staticmethod
+    def _r16(a):
+        return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+
+    def _snake16(self, x, prefix):
+        r16 = self._r16
+        ea = r16(np.exp(r16(self.codec[prefix + ".alpha"])))
+        be = r16(np.exp(r16(self.codec[prefix + ".beta"])))            # (+ eps: Float 1e-9 is 0 in float16)
+        ib = r16(np.float32(1.0) / be)
+        t = r16(x * ea)
+        s = r16(np.sin(t.astype(np.float32)))
+        q = r16(s * s)
+        return r16(x + r16(ib * q))
+
+    def _conv16(self, x, prefix, K, dil=1):
+        o = self._r16(self._conv(x, prefix, K, dil=dil, with_bias=False))
+        b = self.codec.get(prefix + ".bias")
+        return o if b is None else self._r16(o + self._r16(b))
+
+    def _convtr16(self, x, prefix, K, stride):
+        o = self._r16(self._convtr(x, prefix, K, stride, with_bias=False))
+        b = self.codec.get(prefix + ".bias")
+        return o if b is None else self._r16(o + self._r16(b))
+
+    def _main_decoder16(self, h, stages=None):
+        dc, r16 = self.dc, self._r16
+        h = self._conv16(r16(h), "decoder.decoder.initConv.conv", 7)
+        if stages is not None:
+            stages["init_conv"] = h
+        for b, rate in enumerate(dc["upsample_rates"]):
+            p = f"decoder.decoder.block{b}"
+            h = self._snake16(h, p + ".snake")
+            h = self._convtr16(h, p + ".upsample.conv", 2 * rate, rate)
+            for j, dil in ((1, 1), (2, 3), (3, 9)):
+                rp = f"{p}.res{j}"
+                y = self._snake16(h, rp + ".act1")
+                y = self._conv16(y, rp + ".conv1.conv", 7, dil=dil)
+                y = self._snake16(y, rp + ".act2")
+                y = self._conv16(y, rp + ".conv2.conv", 1)
+                h = r16(h + y)
+            if stages is not None:
+                stages[f"block{b}"] = h
+        h = self._snake16(h, "decoder.decoder.outSnake")
+        h = self._conv16(h, "decoder.decoder.outConv.conv", 7)
+        return np.clip(h[:, 0], -1.0, 1.0).astype(np.float32)
+
+    def codec_decode(self, codes: np.ndarray, stages: Optional[dict] = None, f16: bool = False):
         """Qwen3TTSSpeechTokenizer.decode for one utterance (SpeechTokenizer.swift:823-836 ->
         754-784). codes [F][16] int. Returns (pcm float32 [1920*F], valid_len). Intermediate
-        activations ([T][C] channels-last) are stored into `stages` when given."""
+        activations ([T][C] channels-last) are stored into `stages` when given. f16: the MainDecoder in float16 as the reference
+        runs a float16 ("lite") speech tokenizer (_main_decoder16)."""
         dc = self.dc
         codes = np.asarray(codes, np.int64)
+        if f16:
+            h = self._codec_front(codes, stages)
+            for i, r in enumerate(dc["upsampling_ratios"]):
+                h = self._convtr(h, f"decoder.upsample.{i}.0.conv", r, r)
+                h = self._convnext(h, f"decoder.upsample.{i}.1")
+                if stages is not None:
+                    stages[f"upsample{i}"] = h
+            pcm = self._main_decoder16(h, stages)
+            up = int(np.prod(dc["upsample_rates"]) * np.prod(dc["upsampling_ratios"]))
+            return pcm, int((codes[:, 0] > 0).sum()) * up
         pcm = self._codec_tail(self._codec_front(codes, stages), stages)
         up = int(np.prod(dc["upsample_rates"]) * np.prod(dc["upsampling_ratios"]))
         valid = int((codes[:, 0] > 0).sum()) * up  # :831-833

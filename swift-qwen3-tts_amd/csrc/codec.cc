@@ -24,6 +24,8 @@ CodecRunner::CodecRunner(const Model& m, hipStream_t st, bool fp32_convs) : m_(m
     Q3_HIP(hipMemset(nf_dev_, 0, size_t(kMaxRows) * 4));
     const char* nf = std::getenv("Q3TTS_CODEC_NO_FUSE");
     no_fuse_ = nf && nf[0] == '1';
+    const char* nh = std::getenv("Q3TTS_CODEC_NO_F16");  // float16 checkpoints through the up-cast two-plane path (comparisons)
+    no_h1_ = nh && nh[0] == '1';
 }
 
 CodecRunner::~CodecRunner() {
@@ -200,6 +202,10 @@ void CodecRunner::run_tail(const Pass& ps, int Tframes, float* const* bufs, floa
     // 6. MainDecoder (:681-690). Every SnakeBeta sits in front of a conv; it is evaluated in the epilogue of the
     // conv that PRODUCES the tensor (one sinf per element) and the activated copy is what the next conv stages.
     const size_t nblk = w.blocks.size();
+    if (w.f16_main && !fp32_mfma_ && !no_h1_) {  // a float16 speech tokenizer: the reference computes this part in float16
+        run_main_h1(ps, T, ppf, cur, bufs, pcm);
+        return;
+    }
     {
         float *y = bufs[(cur + 1) & 3], *ys = bufs[(cur + 2) & 3];
         conv(ps, w.init_conv, bufs[cur], T, ppf, y, nullptr, nullptr, 0, nblk ? &w.blocks[0].snake : nullptr, ys);
@@ -253,6 +259,68 @@ void CodecRunner::run_tail(const Pass& ps, int Tframes, float* const* bufs, floa
                     pcm, st_, 0, nf_dev_ + ps.row0);
     Q3_CHECK(T == Tframes * up_, 7, "internal error: codec upsampling mismatch");
     (void)dc;
+}
+
+// ---- float16 speech tokenizers ("lite" checkpoints, docs/paper.tex:207): the MainDecoder as the reference computes it ----
+void CodecRunner::conv_h1(const Pass& ps, const ConvW& cw, const void* x, bool x_f32, int Tmax, int ppf, uint16_t* out, const uint16_t* res,
+                          const SnakeW* post, uint16_t* out2) {
+    Q3_CHECK(cw.w1 != nullptr, 7, "internal error: float16 decoder without its one-plane weights");
+    ConvH1Args a{};
+    a.x = x; a.x_f32 = x_f32 ? 1 : 0; a.ldx = cw.Cin; a.x_bstride = int64_t(Tmax) * cw.Cin;
+    a.w1 = cw.w1; a.bias = cw.bias;
+    a.res = res; a.ldr = cw.N; a.res_bstride = int64_t(Tmax) * cw.N;
+    a.out = out; a.ldo = cw.N; a.out_bstride = int64_t(Tmax) * cw.N;
+    if (post) { a.out2 = out2; a.post_ea = post->ea16; a.post_ib = post->ib16; a.post_C = post->C; }
+    a.frames = ps.fr; a.ppf = ppf; a.Tmax = Tmax; a.B = ps.nb;
+    a.Cin = cw.Cin; a.N = cw.N; a.K = cw.K; a.dil = cw.dil;
+    launch_conv_gemm_h1(a, st_);
+}
+
+void CodecRunner::capture_h(const Pass& ps, const char* name, const uint16_t* t, int T, int C) {
+    if (!ps.stage_out || *ps.stage != name) return;
+    Q3_HIP(hipStreamSynchronize(st_));
+    std::vector<uint16_t> h(size_t(ps.nb) * T * C);
+    Q3_HIP(hipMemcpy(h.data(), t, h.size() * 2, hipMemcpyDeviceToHost));
+    ps.stage_out->resize(h.size());
+    for (size_t i = 0; i < h.size(); ++i) {
+        _Float16 v;
+        std::memcpy(&v, &h[i], 2);
+        (*ps.stage_out)[i] = float(v);
+    }
+    if (ps.stage_T) *ps.stage_T = T;
+    if (ps.stage_C) *ps.stage_C = C;
+}
+
+// initConv -> four DecoderBlocks -> outSnake -> outConv -> clip (SpeechTokenizer.swift:681-690, 781) on float16 tensors. The launch
+// structure is the unfused two-plane path's (run_tail): every SnakeBeta is evaluated in the epilogue of the conv that produces
+// the tensor; y is the residual stream, ya / t1 / hs the activated copies the next conv reads.
+void CodecRunner::run_main_h1(const Pass& ps, int T, int ppf, int cur, float* const* bufs, float* pcm) {
+    const CodecW& w = m_.codec;
+    const size_t nblk = w.blocks.size();
+    auto H = [&](int i) { return reinterpret_cast<uint16_t*>(bufs[i & 3]); };
+    {
+        uint16_t *y = H(cur + 1), *ys = H(cur + 2);
+        conv_h1(ps, w.init_conv, bufs[cur], true, T, ppf, y, nullptr, nblk ? &w.blocks[0].snake : nullptr, ys);
+        cur = (cur + 1) & 3;  // H(cur) = initConv output, H(cur + 1) = snake_0 of it
+        capture_h(ps, "init_conv", H(cur), T, w.init_conv.N);
+    }
+    for (size_t i = 0; i < nblk; ++i) {
+        const auto& Bk = w.blocks[i];
+        uint16_t *hs = H(cur + 1), *y = H(cur + 2), *ya = H(cur + 3), *t1 = H(cur);
+        const SnakeW* after = i + 1 < nblk ? &w.blocks[i + 1].snake : nullptr;
+        conv_h1(ps, Bk.tconv, hs, false, T, ppf, y, nullptr, &Bk.res[0].act1, ya);  // snake -> transposed conv (:474-475)
+        T *= Bk.stride;
+        ppf *= Bk.stride;
+        for (int j = 0; j < 3; ++j) {  // DecoderResidualUnit (:430-437): y += conv2(act2(conv1(act1(y))))
+            conv_h1(ps, Bk.res[j].conv1, ya, false, T, ppf, nullptr, nullptr, &Bk.res[j].act2, t1);
+            const SnakeW* next = j < 2 ? &Bk.res[j + 1].act1 : after;
+            conv_h1(ps, Bk.res[j].conv2, t1, false, T, ppf, y, y, next, ya);  // (the last unit leaves the NEXT block's snake in ya)
+        }
+        cur = (cur + 2) & 3;  // H(cur) = y, H(cur + 1) = the next block's snake of it
+        capture_h(ps, ("block" + std::to_string(i)).c_str(), H(cur), T, Bk.Cout);
+    }
+    launch_out_conv_h1(H(cur), w.out_C, w.out_snake.ea16, w.out_snake.ib16, w.out_w, w.out_b, ps.fr, ppf, T, ps.nb, pcm, st_, nf_dev_ + ps.row0);
+    Q3_CHECK(ppf == up_, 7, "internal error: codec upsampling mismatch");
 }
 
 int CodecRunner::decode(const int32_t* codes_dev, int code_stride_frames, const std::vector<int>& frames, float** pcm_dev,

@@ -78,6 +78,12 @@ class CodecRunner {
     void capture(const Pass& ps, const char* name, const float* t, int T, int C);
     void run_front(const Pass& ps, const int32_t* codes, int code_stride_frames, int Fmax, float* const* bufs);
     void run_tail(const Pass& ps, int Tframes, float* const* bufs, float* pcm);
+    // the MainDecoder (initConv .. outConv) of a float16 speech tokenizer on codec_conv_h1.hip: float16 tensors in the same
+    // four scratch buffers; in: bufs[cur] = the last ConvNeXt stage's fp32 output at T positions
+    void run_main_h1(const Pass& ps, int T, int ppf, int cur, float* const* bufs, float* pcm);
+    void conv_h1(const Pass& ps, const struct ConvW& cw, const void* x, bool x_f32, int Tmax, int ppf, uint16_t* out, const uint16_t* res,
+                 const struct SnakeW* post, uint16_t* out2);
+    void capture_h(const Pass& ps, const char* name, const uint16_t* t, int T, int C);
     // the tail over one chunk of a stream: `lat` = the chunk's pre-transformer frames (stream layout), pcm out (stream layout)
     void run_tail_stream(const Pass& ps, float* lat, float* pcm);
     float* sbuf(size_t frame_floats, bool keeps_history);  // next persistent tensor of the stream (same order every chunk)
@@ -105,6 +111,7 @@ class CodecRunner {
     const Model& m_;
     hipStream_t st_;
     int up_ = 1920;
+    bool no_h1_ = false;      // Q3TTS_CODEC_NO_F16=1: a float16 speech tokenizer through the up-cast (fp32-equivalent) path
     bool no_fuse_ = false;    // Q3TTS_CODEC_NO_FUSE=1: residual units of the narrow blocks as two launches each
     bool fp32_mfma_ = false;  // Q3TTS_CODEC_FP32=1: contract on the fp32 matrix-core path instead of the split one
     uint8_t* buf_ = nullptr;

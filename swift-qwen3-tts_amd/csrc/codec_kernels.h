@@ -44,6 +44,33 @@ struct ConvGemmArgs {
 };
 void launch_conv_gemm(const ConvGemmArgs& a, hipStream_t st);
 
+// The MainDecoder's convs on a float16 speech tokenizer (kernels/codec_conv_h1.hip): float16 activations in HBM, one matrix-core
+// product per block, one float16 rounding per op of the reference (conv, + bias, residual +, SnakeBeta's five).
+struct ConvH1Args {
+    const void* x;         // channels-last [b][t][Cin]: float16, or fp32 when x_f32 (rounded to float16 while staged)
+    int x_f32;
+    int ldx;               // elements
+    int64_t x_bstride;     // elements
+    const uint16_t* w1;    // [K][ceil(Cin/32)][N][32] fp16 (model.cc attach_h1)
+    const float* bias;     // [N] (float16-exact values) or nullptr
+    const uint16_t* res;   // float16 residual or nullptr
+    int ldr;
+    int64_t res_bstride;
+    uint16_t* out;         // float16, may be nullptr when only out2 is wanted
+    int ldo;
+    int64_t out_bstride;
+    uint16_t* out2;        // optional: SnakeBeta(post_ea, post_ib) of the result, same geometry as out
+    const float* post_ea;  // SnakeW::ea16 / ib16, indexed by n % post_C
+    const float* post_ib;
+    int post_C;
+    const int32_t* frames;
+    int ppf, Tmax, B, Cin, N, K, dil;
+};
+void launch_conv_gemm_h1(const ConvH1Args& a, hipStream_t st);
+// SnakeBeta -> k7 conv C -> 1 -> clip on a float16 tensor (kernels/codec_conv_h1.hip)
+void launch_out_conv_h1(const uint16_t* x, int C, const float* ea16, const float* ib16, const float* w, const float* bias,
+                        const int32_t* frames, int ppf, int Tmax, int B, float* pcm, hipStream_t st, int32_t* nonfinite);
+
 // DecoderResidualUnit (SpeechTokenizer.swift:430-437) in one launch: out = y + conv2(act2(conv1(act1(y)))) with conv1
 // k taps / dilation `dil`, conv2 pointwise, C channels on both (C = 32, 64 or 96). Neither act1(y) nor conv1's
 // output touch HBM: y is read once (+ halo) and the sum written once, to a different buffer than y.

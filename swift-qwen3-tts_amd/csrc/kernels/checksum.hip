@@ -36,6 +36,7 @@ uint64_t arena_checksum(int device, const void* arena, size_t bytes) {
         Q3_HIP(hipMemset(d, 0, 8));
         const size_t words = bytes / 4, n_vec = words / 4;
         const int n_tail = int(words - n_vec * 4);
+        (void)hipGetLastError();  // the runtime's last-error slot is sticky: an earlier, handled failure must not be read as this launch's
         hipLaunchKernelGGL(checksum_kernel, dim3(2048), dim3(256), 0, nullptr, static_cast<const uint4*>(arena), n_vec,
                            static_cast<const uint32_t*>(arena) + n_vec * 4, n_tail, d);
         Q3_HIP(hipGetLastError());

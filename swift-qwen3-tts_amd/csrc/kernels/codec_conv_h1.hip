@@ -1,0 +1,385 @@
+// codec_conv_h1.hip -- the MainDecoder's convolutions for FLOAT16 speech tokenizers ("lite" checkpoints store every
+// speech-tokenizer tensor in float16, /root/reference/docs/paper.tex:207).
+//
+// What the reference computes there: MLX evaluates every op in the arrays' dtype, so with float16 weights the decoder's
+// tensors ARE float16 and every op result is rounded to float16 (SpeechTokenizer.swift: CausalConv1d :298-306 = conv, then
+// + bias; CausalTransposeConv1d :346-352; SnakeBeta :246-253 = x * alpha, sin, s * s, (1 / beta) * q, x + r;
+// DecoderResidualUnit :430-437 = residual + h). Up-casting such a checkpoint to fp32 and running the two-plane kernels
+// (codec_conv.hip) is both wider than the reference and three matrix-core products where one does: here activations stay
+// float16 in HBM (half the bytes), a product block is ONE v_mfma_f32_16x16x32_f16 (exact fp16 x fp16 products, fp32
+// accumulation), and the epilogue rounds where MLX rounds: fp16(acc), fp16(+ bias), fp16(res + .), and the five roundings of
+// SnakeBeta for the activated copy the next conv reads. Oracle: OracleModel._main_decoder16.
+//
+// Same tiling as conv_gemm_h2_kernel: 128 positions x {128, 96, 64} channels per workgroup of four waves, input tile + causal
+// halo staged once per 32-channel chunk, all K taps read shifted windows of it, weight tiles double-buffered (one barrier per
+// tap), XCD-contiguous tile order. An LDS row is 32 halfs (64 B) + 16 B of padding = 5 sixteen-byte units: the 16 rows x 4
+// units of a ds_read_b128 wave access fall on distinct bank groups. X32: the input tensor is still fp32 (initConv reads
+// the last ConvNeXt stage's output) and is rounded to float16 while it is staged -- the tensor the reference holds.
+// Roofline: fp16 MFMA (2.5 PFLOP/s dense) for the K = 7 convs, HBM for the pointwise and transposed ones.
+#include <algorithm>
+
+#include "../codec_kernels.h"
+#include "../common.h"
+#include "snake.h"
+
+namespace q3 {
+namespace {
+
+constexpr int BM = 128;       // positions per workgroup
+constexpr int KC = 32;        // input channels per chunk
+constexpr int RH = 20;        // dwords per LDS row: 64 B of data + 16 B padding
+constexpr int MAX_HALO = 56;  // (K - 1) * dil <= 54 in the decoder
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float r16(float v) { return static_cast<float>(static_cast<_Float16>(v)); }
+
+__device__ __forceinline__ f32x4 mfma_h(const uint4& a, const uint4& b, f32x4 c) {
+    f16x8 av, bv;
+    __builtin_memcpy(&av, &a, 16);
+    __builtin_memcpy(&bv, &b, 16);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ uint2 pack_h4(float a, float b, float c, float d) {
+    const f32x4v x = {a, b, c, d};
+    const f16x4 h = __builtin_convertvector(x, f16x4);
+    uint2 r;
+    __builtin_memcpy(&r, &h, 8);
+    return r;
+}
+__device__ __forceinline__ void unpack_h4(const uint2& u, float (&o)[4]) {
+    f16x4 h;
+    __builtin_memcpy(&h, &u, 8);
+    const f32x4v x = __builtin_convertvector(h, f32x4v);
+    o[0] = x[0]; o[1] = x[1]; o[2] = x[2]; o[3] = x[3];
+}
+
+// SnakeBeta the way MLX evaluates it on float16 arrays (SpeechTokenizer.swift:251-252), one rounding per op; ea / ib are
+// the float16-rounded exp(alpha) and 1 / exp(beta) (model.cc put_snake)
+__device__ __forceinline__ float snake_h(float x, float ea, float ib) {
+    const float t = r16(x * ea);
+    // sin(t) in fp32 (Cody-Waite + degree-7 polynomial, < 1 ulp of fp32), then the op's own rounding
+    const float k = __builtin_rintf(t * 0.636619772367581343f);
+    float r = __builtin_fmaf(k, -1.57079637050628662109375f, t);
+    r = __builtin_fmaf(k, 4.37113900018624283e-8f, r);
+    const float r2 = r * r;
+    // sine on [-pi/4, pi/4]
+    float ps = __builtin_fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = __builtin_fmaf(r2, ps, -1.6666654611e-1f);
+    const float sn = __builtin_fmaf(r * r2, ps, r);
+    // cosine on [-pi/4, pi/4] (Cephes cosf): the odd quadrants
+    float pc = __builtin_fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = __builtin_fmaf(r2, pc, 4.166664568298827e-2f);
+    const float cs = __builtin_fmaf(r2 * r2, pc, __builtin_fmaf(r2, -0.5f, 1.0f));
+    const int q = static_cast<int>(k) & 3;
+    float s = (q & 1) ? cs : sn;
+    s = (q & 2) ? -s : s;
+    const float s16 = r16(s);
+    const float qq = r16(s16 * s16);
+    return r16(x + r16(ib * qq));
+}
+
+template <int BN, bool X32>
+__global__ __launch_bounds__(256, 2) void conv_gemm_h1_kernel(ConvH1Args a) {
+    constexpr int CT = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem1[];
+    const int halo = (a.K - 1) * a.dil;
+    uint32_t* As = smem1;                       // [(BM + halo)][RH]
+    uint32_t* Ws = smem1 + (BM + halo) * RH;    // [2][BN][RH]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int b, n_tile, m_tile;
+    {   // XCD-contiguous tile order (codec_conv.hip conv_gemm_h2_kernel): bijective for any grid, a speed matter only
+        const uint32_t gx = gridDim.x, gy = gridDim.y, nwg = gx * gy * gridDim.z;
+        const uint32_t bid = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const uint32_t q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u;
+        const uint32_t swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        n_tile = int(swz % gx);
+        const uint32_t rest = swz / gx;
+        m_tile = int(rest % gy);
+        b = int(rest / gy);
+    }
+    const int n0 = n_tile * BN, t0 = m_tile * BM;
+    const int T = a.frames[b] * a.ppf;
+    if (t0 >= T) return;
+    const int rows = BM + halo;
+    const int nchunks = (a.Cin + KC - 1) / KC;
+    const int steps = nchunks * a.K;
+
+    f32x4 acc[4][CT];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // weight tile of one (tap, chunk) step: BN rows x 4 sixteen-byte pieces, contiguous in global memory
+    constexpr int WITEMS = BN * 4;
+    constexpr int WV = (WITEMS + 255) / 256;
+    uint4 wreg[WV];
+    auto load_w = [&](int step) {
+        const int chunk = step / a.K, tap = step % a.K;
+        const uint4* src = reinterpret_cast<const uint4*>(a.w1 + ((size_t)(tap * nchunks + chunk) * a.N + n0) * 32);
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int item = i * 256 + tid;
+            const int ic = item < WITEMS ? item : WITEMS - 1;  // (clamped, not predicated: a predicated load is waited for on the spot)
+            const int nr = n0 + (ic >> 2);
+            wreg[i] = src[nr < a.N ? ic : 0];
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < WV; ++i) {
+            const int item = i * 256 + tid;
+            if (item < WITEMS && n0 + (item >> 2) < a.N)
+                *reinterpret_cast<uint4*>(&Ws[(buf * BN + (item >> 2)) * RH + (item & 3) * 4]) = wreg[i];
+            else if (item < WITEMS)
+                *reinterpret_cast<uint4*>(&Ws[(buf * BN + (item >> 2)) * RH + (item & 3) * 4]) = make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+
+    // input tile: (BM + halo) rows x 4 pieces of 8 channels
+    constexpr int AV = ((BM + MAX_HALO) * 4 + 255) / 256;
+    uint4 areg[AV];
+    float4 areg32[X32 ? AV : 1][2];
+    const uint16_t* xh = reinterpret_cast<const uint16_t*>(a.x) + (size_t)b * a.x_bstride;
+    const float* xf = reinterpret_cast<const float*>(a.x) + (size_t)b * a.x_bstride;
+    auto load_a = [&](int chunk) {
+        const int c0 = chunk * KC;
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int item = i * 256 + tid;
+            const int r = item >> 2, c8 = (item & 3) * 8;
+            const int t = t0 - halo + r;
+            // clamped address, value masked when it is staged (hipcc waits on the spot for a load it has to predicate)
+            const int tc = t < 0 ? 0 : (t < T ? t : T - 1);
+            const int cc = c0 + c8 < a.Cin ? c0 + c8 : 0;
+            if constexpr (X32) {
+                const float* p = xf + (int64_t)tc * a.ldx + cc;
+                areg32[i][0] = *reinterpret_cast<const float4*>(p);
+                areg32[i][1] = *reinterpret_cast<const float4*>(p + 4);
+            } else {
+                areg[i] = *reinterpret_cast<const uint4*>(xh + (int64_t)tc * a.ldx + cc);
+            }
+        }
+    };
+    auto store_a = [&](int chunk) {
+        const int c0 = chunk * KC;
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int item = i * 256 + tid;
+            const int r = item >> 2, c8 = (item & 3) * 8;
+            if (r >= rows) continue;
+            const int t = t0 - halo + r;
+            uint4 v;
+            if constexpr (X32) {
+                const uint2 lo = pack_h4(areg32[i][0].x, areg32[i][0].y, areg32[i][0].z, areg32[i][0].w);
+                const uint2 hi = pack_h4(areg32[i][1].x, areg32[i][1].y, areg32[i][1].z, areg32[i][1].w);
+                v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            } else {
+                v = areg[i];
+            }
+            if (t < 0 || t >= T || c0 + c8 >= a.Cin) v = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(&As[r * RH + (item & 3) * 4]) = v;
+        }
+    };
+
+    load_w(0);
+    load_a(0);
+    int buf = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        __syncthreads();  // the previous chunk's MFMAs are done with As
+        store_a(chunk);
+        if (chunk + 1 < nchunks) load_a(chunk + 1);
+        for (int tap = 0; tap < a.K; ++tap) {
+            const int step = chunk * a.K + tap;
+            store_w(buf);  // the other buffer may still be read by a wave that is behind: double-buffered
+            __syncthreads();
+            if (step + 1 < steps) load_w(step + 1);
+            const uint32_t* arow = &As[(wm * 64 + tap * a.dil + (lane & 15)) * RH + 4 * (lane >> 4)];
+            const uint32_t* wrow = &Ws[(buf * BN + wn * (BN / 2) + (lane & 15)) * RH + 4 * (lane >> 4)];
+            uint4 xa[4], wa[CT];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) xa[p] = *reinterpret_cast<const uint4*>(arow + p * 16 * RH);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) wa[c] = *reinterpret_cast<const uint4*>(wrow + c * 16 * RH);
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[p][c] = mfma_h(wa[c], xa[p], acc[p][c]);
+            buf ^= 1;
+        }
+    }
+
+    // ---- epilogue: the reference's op sequence, one float16 rounding per op. Lane: channels n .. n + 3 of position t ----
+    const int n_w = n0 + wn * (BN / 2), t_w = t0 + wm * 64;
+    const int nq = n_w + 4 * (lane >> 4);
+    float4 bv[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const int n = nq + 16 * c;
+        bv[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias && n < a.N) bv[c] = *reinterpret_cast<const float4*>(a.bias + n);
+    }
+    uint2 rv[4][CT];
+    if (a.res) {
+        const uint16_t* rb = a.res + (size_t)b * a.res_bstride;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int t = t_w + 16 * p + (lane & 15);
+            const int tc = t < T ? t : T - 1;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const int n = nq + 16 * c;
+                rv[p][c] = *reinterpret_cast<const uint2*>(rb + (size_t)tc * a.ldr + (n < a.N ? n : 0));
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int t = t_w + 16 * p + (lane & 15);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int n = nq + 16 * c;
+            float v[4] = {r16(acc[p][c][0]), r16(acc[p][c][1]), r16(acc[p][c][2]), r16(acc[p][c][3])};  // conv(x, w)
+            if (a.bias) {                                                                                // + bias
+                v[0] = r16(v[0] + bv[c].x); v[1] = r16(v[1] + bv[c].y); v[2] = r16(v[2] + bv[c].z); v[3] = r16(v[3] + bv[c].w);
+            }
+            if (a.res) {                                                                                 // residual + h
+                float rr[4];
+                unpack_h4(rv[p][c], rr);
+                v[0] = r16(rr[0] + v[0]); v[1] = r16(rr[1] + v[1]); v[2] = r16(rr[2] + v[2]); v[3] = r16(rr[3] + v[3]);
+            }
+            if (a.out && t < T && n < a.N)
+                *reinterpret_cast<uint2*>(a.out + (size_t)b * a.out_bstride + (size_t)t * a.ldo + n) = pack_h4(v[0], v[1], v[2], v[3]);
+            acc[p][c] = f32x4{v[0], v[1], v[2], v[3]};  // kept for the SnakeBeta pass (float16 values, exactly)
+        }
+    }
+    if (a.out2) {
+        // Second output: SnakeBeta of the finished tile, for the conv that consumes it. The accumulators are parked in LDS (each
+        // lane its own slots) and walked by a rolled loop: one inlined sine body per 16-position slice (codec_conv.hip snake_pass).
+        float4* stash = reinterpret_cast<float4*>(smem1) + wave * (CT * 64);
+        float4* par = reinterpret_cast<float4*>(smem1) + 4 * (CT * 64);  // [BN / 4] ea, then [BN / 4] ib
+        __syncthreads();
+        if (tid < BN / 4) {
+            const int n = n0 + 4 * tid;
+            if (n < a.N) {
+                const int ch = n % a.post_C;  // transposed convs: n = phase * Cout + channel
+                par[tid] = *reinterpret_cast<const float4*>(a.post_ea + ch);
+                par[BN / 4 + tid] = *reinterpret_cast<const float4*>(a.post_ib + ch);
+            }
+        }
+        __syncthreads();
+        const int nl0 = wn * (BN / 2) + 4 * (lane >> 4);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+#pragma unroll
+            for (int c = 0; c < CT; ++c) stash[c * 64 + lane] = make_float4(acc[p][c][0], acc[p][c][1], acc[p][c][2], acc[p][c][3]);
+            const int t = t_w + p * 16 + (lane & 15);
+            if (t >= T) continue;
+            uint16_t* dst = a.out2 + (size_t)b * a.out_bstride + (size_t)t * a.ldo + n0;
+#pragma unroll 1
+            for (int c = 0; c < CT; ++c) {
+                const int nl = nl0 + c * 16;
+                if (n0 + nl >= a.N) break;
+                const float4 v = stash[c * 64 + lane];
+                const float4 ea = par[nl >> 2], ib = par[BN / 4 + (nl >> 2)];
+                *reinterpret_cast<uint2*>(dst + nl) =
+                    pack_h4(snake_h(v.x, ea.x, ib.x), snake_h(v.y, ea.y, ib.y), snake_h(v.z, ea.z, ib.z), snake_h(v.w, ea.w, ib.w));
+            }
+        }
+    }
+}
+
+// out[t] = clip(fp16(fp16(sum_{k,c} snake(x[t-6+k][c]) * w[k][c]) + bias)): the MainDecoder's tail on a float16 tensor
+// (SpeechTokenizer.swift:687-688, 781). 64 positions per workgroup, 4 lanes each, activated tile and taps in LDS (the layout of
+// codec_misc.hip out_conv_kernel).
+__global__ __launch_bounds__(256) void out_conv_h1_kernel(const uint16_t* x, int C, const float* ea, const float* ib, const float* w,
+                                                          const float* bias, const int32_t* frames, int ppf, int Tmax, float* pcm,
+                                                          int32_t* nonfinite) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [(64 + 6)][C + 4] snake(x), then [7][C] taps
+    const int ld = C + 4, C4 = C >> 2;
+    float* ws = xs + 70 * ld;
+    const int b = blockIdx.y, t0 = blockIdx.x * 64;
+    const int T = frames[b] * ppf;
+    if (t0 >= T) return;
+    const uint16_t* xb = x + (size_t)b * Tmax * C;
+    for (int i = threadIdx.x; i < 7 * C4; i += 256) *reinterpret_cast<float4*>(ws + 4 * i) = *reinterpret_cast<const float4*>(w + 4 * i);
+    for (int i = threadIdx.x; i < 70 * C4; i += 256) {
+        const int r = i / C4, c4 = i % C4;
+        const int t = t0 - 6 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t >= 0 && t < T) {
+            float xv[4];
+            unpack_h4(*reinterpret_cast<const uint2*>(xb + (int64_t)t * C + 4 * c4), xv);
+            const float4 e = *reinterpret_cast<const float4*>(ea + 4 * c4), q = *reinterpret_cast<const float4*>(ib + 4 * c4);
+            v = make_float4(snake_h(xv[0], e.x, q.x), snake_h(xv[1], e.y, q.y), snake_h(xv[2], e.z, q.z), snake_h(xv[3], e.w, q.w));
+        }
+        *reinterpret_cast<float4*>(xs + r * ld + 4 * c4) = v;
+    }
+    __syncthreads();
+    const int pos = threadIdx.x >> 2, sub = threadIdx.x & 3;
+    float acc = 0.f;
+    for (int k = 0; k < 7; ++k) {
+        const float* xr = xs + (pos + k) * ld;
+        const float* wr = ws + k * C;
+        for (int c4 = sub; c4 < C4; c4 += 4) {
+            const float4 xv = *reinterpret_cast<const float4*>(xr + 4 * c4), wv = *reinterpret_cast<const float4*>(wr + 4 * c4);
+            acc += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+        }
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    const int t = t0 + pos;
+    if (sub == 0 && t < T) {
+        float v = r16(acc);
+        if (bias) v = r16(v + bias[0]);
+        if (nonfinite && !(fabsf(v) <= 3.0e38f)) atomicOr(reinterpret_cast<unsigned int*>(nonfinite + b), 1u);
+        pcm[(size_t)b * Tmax + t] = fminf(fmaxf(v, -1.0f), 1.0f);
+    }
+}
+
+}  // namespace
+
+void launch_conv_gemm_h1(const ConvH1Args& a, hipStream_t st) {
+    Q3_CHECK((a.K - 1) * a.dil <= MAX_HALO, 3, "conv_gemm_h1: receptive field too large");
+    Q3_CHECK(a.Cin % 8 == 0 && a.N % 4 == 0 && a.ldx % 8 == 0 && a.ldo % 4 == 0, 3, "conv_gemm_h1: channel counts must be multiples of 8 / 4");
+    Q3_CHECK(!a.out2 || (a.post_ea && a.post_ib && a.post_C > 0 && a.post_C % 4 == 0), 3, "conv_gemm_h1: activated output without its parameters");
+    const int mt = (a.Tmax + BM - 1) / BM;
+    if (mt <= 0 || a.B <= 0) return;
+    int BN = 64;
+    if (a.N % 128 == 0) BN = 128;
+    else if (a.N % 96 == 0) BN = 96;
+    else if (a.N > 128 && (a.N % 64) != 0) BN = 128;
+    const dim3 grid((a.N + BN - 1) / BN, mt, a.B), block(256);
+    // LDS: the tiles, or the SnakeBeta pass's stash (4 waves x CT x 64 float4) + parameters, whichever is larger
+    const size_t tiles = size_t(BM + (a.K - 1) * a.dil + 2 * BN) * RH * sizeof(uint32_t);
+    const size_t pass = size_t(4 * (BN / 32) * 64 + 2 * (BN / 4)) * sizeof(float4);
+    const size_t smem = std::max(tiles, pass);
+    Q3_CHECK(smem <= 64 * 1024, 3, "conv_gemm_h1: tile does not fit the static LDS limit");
+#define Q3_H1(BNv)                                                                                              \
+    do {                                                                                                        \
+        if (a.x_f32) hipLaunchKernelGGL((conv_gemm_h1_kernel<BNv, true>), grid, block, smem, st, a);            \
+        else hipLaunchKernelGGL((conv_gemm_h1_kernel<BNv, false>), grid, block, smem, st, a);                   \
+    } while (0)
+    switch (BN) {
+        case 128: Q3_H1(128); break;
+        case 96: Q3_H1(96); break;
+        default: Q3_H1(64); break;
+    }
+#undef Q3_H1
+}
+
+void launch_out_conv_h1(const uint16_t* x, int C, const float* ea, const float* ib, const float* w, const float* bias,
+                        const int32_t* frames, int ppf, int Tmax, int B, float* pcm, hipStream_t st, int32_t* nonfinite) {
+    const size_t smem = size_t(70 * (C + 4) + 7 * C) * sizeof(float);
+    Q3_CHECK(smem <= 64 * 1024 && C % 4 == 0 && C >= 4 && C <= 1024, 3, "out_conv_h1: unsupported channel count");
+    hipLaunchKernelGGL(out_conv_h1_kernel, dim3((Tmax + 63) / 64, B), dim3(256), smem, st, x, C, ea, ib, w, bias, frames, ppf, Tmax, pcm,
+                       nonfinite);
+}
+
+}  // namespace q3

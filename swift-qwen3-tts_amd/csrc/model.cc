@@ -24,6 +24,7 @@ namespace {
 struct HostTensor {
     std::vector<int64_t> shape;
     std::vector<float> data;  // empty when only the shape is known (skip_tensor_data)
+    bool f16 = false;         // stored as float16 in the checkpoint (the "lite" speech tokenizers, docs/paper.tex:207)
     int64_t numel() const {
         int64_t n = 1;
         for (auto s : shape) n *= s;
@@ -214,6 +215,7 @@ std::map<std::string, HostTensor> sanitize_speech_tokenizer(const SafetensorsDir
         }
         HostTensor t;
         t.shape = tv.shape;
+        t.f16 = tv.dtype == DType::F16;
         if (with_data) t.data = to_f32(tv);
         const bool is_proj = (contains(nk, "input_proj.weight") || contains(nk, "output_proj.weight")) && contains(nk, "quantizer");
         HostTensor nv;
@@ -234,6 +236,7 @@ std::map<std::string, HostTensor> sanitize_speech_tokenizer(const SafetensorsDir
             nv = permute3(t, 1, 2, 0);
             changed = true;
         }
+        if (changed) nv.f16 = t.f16;
         out[nk] = changed ? std::move(nv) : std::move(t);
     }
     for (auto& kv : cb) {  // codebook = embedding_sum / clip(cluster_usage, 1e-5) (:1716-1724)
@@ -299,6 +302,7 @@ struct Builder {
     uint8_t* staging = nullptr;   // device staging for raw matrices before tiling
     size_t max_staging = 0;       // bytes, collected in the dry pass
     bool split3 = false;          // codec decoder: convs also get the two-plane fp16 copy of their weights (attach_h2)
+    bool h1 = false;              // float16 speech tokenizer: the MainDecoder's convs also get their exact one-plane tiles (attach_h1)
 
     template <class T>
     T* alloc(size_t n) {
@@ -615,6 +619,23 @@ void attach_h2_perm(Builder& b, ConvW& c, const std::vector<float>& w) {
     c.whp = b.put<uint16_t>(p.empty() ? nullptr : p.data(), n);
 }
 
+// float16 checkpoints: w [N][K][Cin] (float16-exact values) -> [K][chunks of 32 input channels][N][32] fp16, zero beyond Cin
+// (codec_conv_h1.hip conv_gemm_h1_kernel: one matrix-core product per block, no row scaling -- the values ARE float16)
+void attach_h1(Builder& b, ConvW& c, const std::vector<float>& w) {
+    if (!b.h1) return;
+    const int chunks = (c.Cin + 31) / 32;
+    const size_t n = size_t(c.K) * chunks * c.N * 32;
+    std::vector<uint16_t> p;
+    if (!b.dry && b.fill && !w.empty()) {
+        p.assign(n, 0);
+        for (int nn = 0; nn < c.N; ++nn)
+            for (int tap = 0; tap < c.K; ++tap)
+                for (int ci = 0; ci < c.Cin; ++ci)
+                    p[((size_t(tap) * chunks + ci / 32) * c.N + nn) * 32 + (ci % 32)] = f32_to_f16_bits(w[(size_t(nn) * c.K + tap) * c.Cin + ci]);
+    }
+    c.w1 = b.put<uint16_t>(p.empty() ? nullptr : p.data(), n);
+}
+
 ConvW put_conv(Builder& b, const TMap& t, const std::string& name, int dil = 1) {
     const HostTensor& w = need(t, name + ".weight");
     ConvW c;
@@ -630,6 +651,7 @@ ConvW put_conv(Builder& b, const TMap& t, const std::string& name, int dil = 1) 
     c.dil = dil;
     c.w = b.put_f32(w);
     attach_h2(b, c, w.data);
+    if (starts_with(name, "decoder.decoder.")) attach_h1(b, c, w.data);
     if (const HostTensor* bias = maybe(t, name + ".bias")) c.bias = b.put_f32(*bias);
     return c;
 }
@@ -688,6 +710,7 @@ ConvW put_tconv(Builder& b, const TMap& t, const std::string& name, int stride) 
     c.dil = 1;
     c.w = b.put_f32(p);
     attach_h2(b, c, p.data);
+    if (starts_with(name, "decoder.decoder.")) attach_h1(b, c, p.data);
     if (const HostTensor* bias = maybe(t, name + ".bias")) {
         HostTensor bb;
         bb.shape = {int64_t(stride) * Cout};
@@ -718,6 +741,18 @@ SnakeW put_snake(Builder& b, const TMap& t, const std::string& name) {
     s.C = int(al.shape[0]);
     s.ea = b.put_f32(ea);
     s.ib = b.put_f32(ib);
+    if (b.h1) {
+        // the same parameters the way MLX forms them on float16 arrays (SpeechTokenizer.swift:247-248, 252): exp(alpha) and
+        // exp(beta) rounded to float16, + eps (a Float 1e-9 is 0 in float16), 1 / . rounded again (codec_conv_h1.hip snake_h)
+        auto r16 = [](float v) { return f16_bits_to_f32(f32_to_f16_bits(v)); };
+        HostTensor ea16 = ea, ib16 = ib;
+        for (size_t i = 0; i < ea16.data.size(); ++i) {
+            ea16.data[i] = r16(expf(r16(al.data[i])));
+            ib16.data[i] = r16(1.0f / r16(expf(r16(be.data[i]))));
+        }
+        s.ea16 = b.put_f32(ea16);
+        s.ib16 = b.put_f32(ib16);
+    }
     return s;
 }
 
@@ -1092,8 +1127,13 @@ void build_all(Builder& b, Model& m, const SafetensorsDir& main, const TMap* cod
                 cp.head_dim, cp.rms_norm_eps, cp.rope_theta, 64);
     if (codec_t) {
         b.split3 = true;
+        // a float16 speech tokenizer ("lite" checkpoints): the MainDecoder runs in float16 like the reference's (codec_conv_h1.hip)
+        const HostTensor* ic = maybe(*codec_t, "decoder.decoder.initConv.conv.weight");
+        b.h1 = ic && ic->f16;
+        m.codec.f16_main = b.h1;
         build_codec(b, *codec_t, cfg.codec, m.codec);
         b.split3 = false;
+        b.h1 = false;
         m.has_codec = true;
         if (cfg.has_codec_encoder) {  // SpeechTokenizer.swift:808-812
             build_codec_encoder(b, *codec_t, cfg.codec_enc, m.codec_enc);

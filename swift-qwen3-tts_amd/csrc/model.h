@@ -52,6 +52,8 @@ struct ConvW {  // fp32 conv as GEMM: w[N][K][Cin]; transposed convs are stored 
     const float* wsc = nullptr;    // wsc[n] = 2^-s[n] (codec_conv.hip conv_gemm_h2_kernel; model.cc attach_h2)
     const uint16_t* whp = nullptr; // pointwise conv behind a k7 conv (DecoderResidualUnit conv2): wh with the 32 input channels of a
                                    // chunk in the order the fused kernel's accumulators hold them (codec_conv.hip resunit_h2_kernel)
+    const uint16_t* w1 = nullptr;  // MainDecoder convs of a float16 checkpoint: the weights themselves, [K][ceil(Cin/32)][N][32] fp16
+                                   // (codec_conv_h1.hip; model.cc attach_h1)
     const float* bias = nullptr;   // [N] or nullptr
     const float* scale = nullptr;  // per-output-channel scale (LayerScale / ConvNeXt gamma) or nullptr
     int Cin = 0, N = 0, K = 1, dil = 1;
@@ -59,6 +61,8 @@ struct ConvW {  // fp32 conv as GEMM: w[N][K][Cin]; transposed convs are stored 
 struct SnakeW {
     const float* ea = nullptr;  // exp(alpha)
     const float* ib = nullptr;  // 1 / (exp(beta) + 1e-9)
+    const float* ea16 = nullptr;  // float16 checkpoints: the same, rounded where MLX rounds on float16 arrays
+    const float* ib16 = nullptr;
     int C = 0;
 };
 
@@ -101,6 +105,7 @@ struct CodecW {
     };
     std::vector<Block> blocks;
     SnakeW out_snake;
+    bool f16_main = false;         // float16 speech tokenizer: the MainDecoder runs on codec_conv_h1.hip
     const float* out_w = nullptr;  // [1][7][C]
     const float* out_b = nullptr;
     int out_C = 0;

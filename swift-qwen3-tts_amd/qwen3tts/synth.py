@@ -166,6 +166,11 @@ def preset(name: str) -> dict:
         p = preset("0.6b")
         p["config"]["quantization"] = {"group_size": 64, "bits": 4}
         p["config"]["talker_config"]["pruned_text_rows"] = 47427
+        p["codec_f16"] = True  # writer-only: the "lite" models store the speech tokenizer in float16 (docs/paper.tex:207)
+        return p
+    if name == "tiny-h":  # tiny-b with a float16 speech tokenizer (the lite checkpoints' storage, docs/paper.tex:207)
+        p = preset("tiny-b")
+        p["codec_f16"] = True
         return p
     if name in ("0.6b", "1.7b"):
         H, I = (1024, 3072) if name == "0.6b" else (2048, 6144)
@@ -524,6 +529,8 @@ def write_checkpoint(model_dir: str, name: str = "tiny-a", seed: int = 1234,
         main.update(speaker_encoder_tensors(p["config"]["speaker_encoder_config"], g))
     if p["speech_tokenizer"].get("encoder_config"):
         codec.update(encoder_tensors(p["speech_tokenizer"]["encoder_config"], g))
+    if p.get("codec_f16"):  # Float32 -> float16 conversion of every speech-tokenizer tensor (docs/paper.tex:207)
+        codec = {k: (("F16", v.astype(np.float16)) if tag == "F32" else (tag, v)) for k, (tag, v) in codec.items()}
     save_safetensors(os.path.join(model_dir, "model.safetensors"), main)
     save_safetensors(os.path.join(model_dir, "speech_tokenizer", "model.safetensors"), codec)
     return p
