@@ -57,38 +57,54 @@ __device__ __forceinline__ void unpack_h4(const uint2& u, float (&o)[4]) {
     o[0] = x[0]; o[1] = x[1]; o[2] = x[2]; o[3] = x[3];
 }
 
-// SnakeBeta the way MLX evaluates it on float16 arrays (SpeechTokenizer.swift:251-252), one rounding per op; ea / ib are
-// the float16-rounded exp(alpha) and 1 / exp(beta) (model.cc put_snake)
-__device__ __forceinline__ float snake_h(float x, float ea, float ib) {
-    const float t = r16(x * ea);
-    // sin(t) in fp32 (Cody-Waite + degree-7 polynomial, < 1 ulp of fp32), then the op's own rounding
-    const float k = __builtin_rintf(t * 0.636619772367581343f);
-    float r = __builtin_fmaf(k, -1.57079637050628662109375f, t);
-    r = __builtin_fmaf(k, 4.37113900018624283e-8f, r);
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+// |sin(t)| is all SnakeBeta needs (it squares it): reduce by multiples of pi to [-pi/2, pi/2] (Cody-Waite, two FMAs; t is a
+// float16 value, |t| <= 65504) and take the odd degree-11 polynomial there (< 1 ulp of fp32); the sign is dropped by the square
+__device__ __forceinline__ float sin_mod_pi(float t) {
+    const float k = __builtin_rintf(t * 0.318309886183790672f);
+    float r = __builtin_fmaf(k, -3.14159274101257324f, t);
+    r = __builtin_fmaf(k, 8.74227765734758577e-8f, r);
     const float r2 = r * r;
-    // sine on [-pi/4, pi/4]
-    float ps = __builtin_fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
-    ps = __builtin_fmaf(r2, ps, -1.6666654611e-1f);
-    const float sn = __builtin_fmaf(r * r2, ps, r);
-    // cosine on [-pi/4, pi/4] (Cephes cosf): the odd quadrants
-    float pc = __builtin_fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
-    pc = __builtin_fmaf(r2, pc, 4.166664568298827e-2f);
-    const float cs = __builtin_fmaf(r2 * r2, pc, __builtin_fmaf(r2, -0.5f, 1.0f));
-    const int q = static_cast<int>(k) & 3;
-    float s = (q & 1) ? cs : sn;
-    s = (q & 2) ? -s : s;
-    const float s16 = r16(s);
-    const float qq = r16(s16 * s16);
-    return r16(x + r16(ib * qq));
+    float p = __builtin_fmaf(r2, -2.50521083854417188e-8f, 2.75573192239858907e-6f);
+    p = __builtin_fmaf(r2, p, -1.98412698412698413e-4f);
+    p = __builtin_fmaf(r2, p, 8.33333333333333333e-3f);
+    p = __builtin_fmaf(r2, p, -1.66666666666666667e-1f);
+    return __builtin_fmaf(r * r2, p, r);
 }
 
-template <int BN, bool X32>
+// SnakeBeta the way MLX evaluates it on float16 arrays (SpeechTokenizer.swift:251-252), two elements at a time on the packed
+// float16 ALU: every mul / add below IS one float16 op with one rounding (x * alpha, s * s, (1 / beta) * q, x + r); the sine is
+// taken in fp32 and rounded once. ea / ib: the float16-rounded exp(alpha) and 1 / exp(beta) (model.cc put_snake).
+__device__ __forceinline__ h2v snake_h2(h2v x, h2v ea, h2v ib) {
+    const h2v t = x * ea;
+    const f32x2v tf = __builtin_convertvector(t, f32x2v);
+    const f32x2v sf = {sin_mod_pi(tf[0]), sin_mod_pi(tf[1])};
+    const h2v s = __builtin_convertvector(sf, h2v);
+    const h2v q = s * s;
+    return x + ib * q;
+}
+__device__ __forceinline__ float snake_h(float x, float ea, float ib) {  // one element (out_conv_h1's staging loop)
+    const h2v r = snake_h2(h2v{static_cast<_Float16>(x), static_cast<_Float16>(0.f)}, h2v{static_cast<_Float16>(ea), static_cast<_Float16>(0.f)},
+                           h2v{static_cast<_Float16>(ib), static_cast<_Float16>(0.f)});
+    return static_cast<float>(r[0]);
+}
+
+// KT = taps (a template parameter: the tap loop is unrolled and every weight fragment has a register of its own).
+// Weights never touch LDS: a wave's A fragment of 16 output channels x 32 input channels is one 16-byte load per lane, 1 KiB
+// contiguous per wave (the [tap][chunk][N][32] layout of model.cc attach_h1), served by the L2 -- a conv's whole weight set is
+// at most 8 MB and every workgroup of a launch reads the same bytes. The fragments of ALL taps of a chunk live in registers
+// (KT x CT x 4 VGPRs) and each is re-requested for the next chunk right after its last use, a whole chunk of MFMAs ahead of
+// its next one. Only the input tile (+ causal halo) goes through LDS: one barrier pair per 32-channel CHUNK instead of one per
+// tap. (The first build staged the weight tiles through LDS with a barrier per tap like conv_gemm_h2_kernel: with a third of
+// that kernel's MFMAs per step the barriers were 85 % of the launch -- block0's k7 conv 3.48 ms against 4.5-4.8 ms.)
+template <int BN, int KT, bool X32>
 __global__ __launch_bounds__(256, 2) void conv_gemm_h1_kernel(ConvH1Args a) {
     constexpr int CT = BN / 32;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem1[];
-    const int halo = (a.K - 1) * a.dil;
-    uint32_t* As = smem1;                       // [(BM + halo)][RH]
-    uint32_t* Ws = smem1 + (BM + halo) * RH;    // [2][BN][RH]
+    const int halo = (KT - 1) * a.dil;
+    uint32_t* As = smem1;  // [(BM + halo)][RH]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -108,7 +124,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_h1_kernel(ConvH1Args a) {
     if (t0 >= T) return;
     const int rows = BM + halo;
     const int nchunks = (a.Cin + KC - 1) / KC;
-    const int steps = nchunks * a.K;
 
     f32x4 acc[4][CT];
 #pragma unroll
@@ -116,30 +131,19 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_h1_kernel(ConvH1Args a) {
 #pragma unroll
         for (int c = 0; c < CT; ++c) acc[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // weight tile of one (tap, chunk) step: BN rows x 4 sixteen-byte pieces, contiguous in global memory
-    constexpr int WITEMS = BN * 4;
-    constexpr int WV = (WITEMS + 255) / 256;
-    uint4 wreg[WV];
-    auto load_w = [&](int step) {
-        const int chunk = step / a.K, tap = step % a.K;
-        const uint4* src = reinterpret_cast<const uint4*>(a.w1 + ((size_t)(tap * nchunks + chunk) * a.N + n0) * 32);
+    // this lane's piece of the wave's weight fragments: row n_w + 16 c + (lane & 15) (clamped: rows past N are computed and never
+    // stored), input channels 8 (lane >> 4) .. + 7 of the chunk
+    const uint4* wlane[CT];
 #pragma unroll
-        for (int i = 0; i < WV; ++i) {
-            const int item = i * 256 + tid;
-            const int ic = item < WITEMS ? item : WITEMS - 1;  // (clamped, not predicated: a predicated load is waited for on the spot)
-            const int nr = n0 + (ic >> 2);
-            wreg[i] = src[nr < a.N ? ic : 0];
-        }
-    };
-    auto store_w = [&](int buf) {
+    for (int c = 0; c < CT; ++c) {
+        const int n = n0 + wn * (BN / 2) + 16 * c + (lane & 15);
+        wlane[c] = reinterpret_cast<const uint4*>(a.w1 + (size_t)(n < a.N ? n : a.N - 1) * 32) + (lane >> 4);
+    }
+    const size_t wchunk = (size_t)a.N * 4;            // sixteen-byte pieces per (tap, chunk) block
+    uint4 wf[KT][CT];
+    auto load_w = [&](int tap, int chunk) {
 #pragma unroll
-        for (int i = 0; i < WV; ++i) {
-            const int item = i * 256 + tid;
-            if (item < WITEMS && n0 + (item >> 2) < a.N)
-                *reinterpret_cast<uint4*>(&Ws[(buf * BN + (item >> 2)) * RH + (item & 3) * 4]) = wreg[i];
-            else if (item < WITEMS)
-                *reinterpret_cast<uint4*>(&Ws[(buf * BN + (item >> 2)) * RH + (item & 3) * 4]) = make_uint4(0u, 0u, 0u, 0u);
-        }
+        for (int c = 0; c < CT; ++c) wf[tap][c] = wlane[c][(size_t)(tap * nchunks + chunk) * wchunk];
     };
 
     // input tile: (BM + halo) rows x 4 pieces of 8 channels
@@ -188,42 +192,41 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_h1_kernel(ConvH1Args a) {
         }
     };
 
-    load_w(0);
     load_a(0);
-    int buf = 0;
+#pragma unroll
+    for (int tap = 0; tap < KT; ++tap) load_w(tap, 0);
     for (int chunk = 0; chunk < nchunks; ++chunk) {
         __syncthreads();  // the previous chunk's MFMAs are done with As
         store_a(chunk);
-        if (chunk + 1 < nchunks) load_a(chunk + 1);
-        for (int tap = 0; tap < a.K; ++tap) {
-            const int step = chunk * a.K + tap;
-            store_w(buf);  // the other buffer may still be read by a wave that is behind: double-buffered
-            __syncthreads();
-            if (step + 1 < steps) load_w(step + 1);
+        const int nxt = chunk + 1 < nchunks ? chunk + 1 : chunk;  // (the last chunk re-requests itself: unconditional loads)
+        load_a(nxt);
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < KT; ++tap) {
             const uint32_t* arow = &As[(wm * 64 + tap * a.dil + (lane & 15)) * RH + 4 * (lane >> 4)];
-            const uint32_t* wrow = &Ws[(buf * BN + wn * (BN / 2) + (lane & 15)) * RH + 4 * (lane >> 4)];
-            uint4 xa[4], wa[CT];
+            uint4 xa[4];
 #pragma unroll
             for (int p = 0; p < 4; ++p) xa[p] = *reinterpret_cast<const uint4*>(arow + p * 16 * RH);
 #pragma unroll
-            for (int c = 0; c < CT; ++c) wa[c] = *reinterpret_cast<const uint4*>(wrow + c * 16 * RH);
-#pragma unroll
             for (int p = 0; p < 4; ++p)
 #pragma unroll
-                for (int c = 0; c < CT; ++c) acc[p][c] = mfma_h(wa[c], xa[p], acc[p][c]);
-            buf ^= 1;
+                for (int c = 0; c < CT; ++c) acc[p][c] = mfma_h(wf[tap][c], xa[p], acc[p][c]);
+            load_w(tap, nxt);  // this tap's fragments for the next chunk: a whole chunk of MFMAs ahead of their use
         }
     }
 
-    // ---- epilogue: the reference's op sequence, one float16 rounding per op. Lane: channels n .. n + 3 of position t ----
+    // ---- epilogue: the reference's op sequence on the packed float16 ALU, one rounding per op. Lane: channels n .. n + 3 of
+    //      position t; `yh` keeps the finished float16 values for the SnakeBeta pass ----
     const int n_w = n0 + wn * (BN / 2), t_w = t0 + wm * 64;
     const int nq = n_w + 4 * (lane >> 4);
-    float4 bv[CT];
+    h2v bh[CT][2];
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         const int n = nq + 16 * c;
-        bv[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.bias && n < a.N) bv[c] = *reinterpret_cast<const float4*>(a.bias + n);
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias && n < a.N) bv = *reinterpret_cast<const float4*>(a.bias + n);
+        bh[c][0] = h2v{static_cast<_Float16>(bv.x), static_cast<_Float16>(bv.y)};  // (float16-exact values)
+        bh[c][1] = h2v{static_cast<_Float16>(bv.z), static_cast<_Float16>(bv.w)};
     }
     uint2 rv[4][CT];
     if (a.res) {
@@ -239,38 +242,43 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_h1_kernel(ConvH1Args a) {
             }
         }
     }
+    uint2 yh[4][CT];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int t = t_w + 16 * p + (lane & 15);
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
             const int n = nq + 16 * c;
-            float v[4] = {r16(acc[p][c][0]), r16(acc[p][c][1]), r16(acc[p][c][2]), r16(acc[p][c][3])};  // conv(x, w)
-            if (a.bias) {                                                                                // + bias
-                v[0] = r16(v[0] + bv[c].x); v[1] = r16(v[1] + bv[c].y); v[2] = r16(v[2] + bv[c].z); v[3] = r16(v[3] + bv[c].w);
+            const f32x2v a0 = {acc[p][c][0], acc[p][c][1]}, a1 = {acc[p][c][2], acc[p][c][3]};
+            h2v v0 = __builtin_convertvector(a0, h2v), v1 = __builtin_convertvector(a1, h2v);  // conv(x, w)
+            if (a.bias) { v0 = v0 + bh[c][0]; v1 = v1 + bh[c][1]; }                             // + bias
+            if (a.res) {                                                                        // residual + h
+                h2v r0, r1;
+                __builtin_memcpy(&r0, &rv[p][c].x, 4);
+                __builtin_memcpy(&r1, &rv[p][c].y, 4);
+                v0 = r0 + v0;
+                v1 = r1 + v1;
             }
-            if (a.res) {                                                                                 // residual + h
-                float rr[4];
-                unpack_h4(rv[p][c], rr);
-                v[0] = r16(rr[0] + v[0]); v[1] = r16(rr[1] + v[1]); v[2] = r16(rr[2] + v[2]); v[3] = r16(rr[3] + v[3]);
-            }
-            if (a.out && t < T && n < a.N)
-                *reinterpret_cast<uint2*>(a.out + (size_t)b * a.out_bstride + (size_t)t * a.ldo + n) = pack_h4(v[0], v[1], v[2], v[3]);
-            acc[p][c] = f32x4{v[0], v[1], v[2], v[3]};  // kept for the SnakeBeta pass (float16 values, exactly)
+            uint2 pk;
+            __builtin_memcpy(&pk.x, &v0, 4);
+            __builtin_memcpy(&pk.y, &v1, 4);
+            yh[p][c] = pk;
+            if (a.out && t < T && n < a.N) *reinterpret_cast<uint2*>(a.out + (size_t)b * a.out_bstride + (size_t)t * a.ldo + n) = pk;
         }
     }
     if (a.out2) {
-        // Second output: SnakeBeta of the finished tile, for the conv that consumes it. The accumulators are parked in LDS (each
-        // lane its own slots) and walked by a rolled loop: one inlined sine body per 16-position slice (codec_conv.hip snake_pass).
-        float4* stash = reinterpret_cast<float4*>(smem1) + wave * (CT * 64);
-        float4* par = reinterpret_cast<float4*>(smem1) + 4 * (CT * 64);  // [BN / 4] ea, then [BN / 4] ib
+        // Second output: SnakeBeta of the finished tile, for the conv that consumes it. The values are parked in LDS (each lane
+        // its own slots) and walked by a rolled loop: one inlined sine body per 16-position slice (codec_conv.hip snake_pass).
+        uint2* stash = reinterpret_cast<uint2*>(smem1) + wave * (CT * 64);
+        uint2* par = reinterpret_cast<uint2*>(smem1) + 4 * (CT * 64);  // [BN / 4] ea as four halfs, then [BN / 4] ib
         __syncthreads();
         if (tid < BN / 4) {
             const int n = n0 + 4 * tid;
             if (n < a.N) {
                 const int ch = n % a.post_C;  // transposed convs: n = phase * Cout + channel
-                par[tid] = *reinterpret_cast<const float4*>(a.post_ea + ch);
-                par[BN / 4 + tid] = *reinterpret_cast<const float4*>(a.post_ib + ch);
+                const float4 e = *reinterpret_cast<const float4*>(a.post_ea + ch), q = *reinterpret_cast<const float4*>(a.post_ib + ch);
+                par[tid] = pack_h4(e.x, e.y, e.z, e.w);
+                par[BN / 4 + tid] = pack_h4(q.x, q.y, q.z, q.w);
             }
         }
         __syncthreads();
@@ -278,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_h1_kernel(ConvH1Args a) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
 #pragma unroll
-            for (int c = 0; c < CT; ++c) stash[c * 64 + lane] = make_float4(acc[p][c][0], acc[p][c][1], acc[p][c][2], acc[p][c][3]);
+            for (int c = 0; c < CT; ++c) stash[c * 64 + lane] = yh[p][c];
             const int t = t_w + p * 16 + (lane & 15);
             if (t >= T) continue;
             uint16_t* dst = a.out2 + (size_t)b * a.out_bstride + (size_t)t * a.ldo + n0;
@@ -286,10 +294,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_h1_kernel(ConvH1Args a) {
             for (int c = 0; c < CT; ++c) {
                 const int nl = nl0 + c * 16;
                 if (n0 + nl >= a.N) break;
-                const float4 v = stash[c * 64 + lane];
-                const float4 ea = par[nl >> 2], ib = par[BN / 4 + (nl >> 2)];
-                *reinterpret_cast<uint2*>(dst + nl) =
-                    pack_h4(snake_h(v.x, ea.x, ib.x), snake_h(v.y, ea.y, ib.y), snake_h(v.z, ea.z, ib.z), snake_h(v.w, ea.w, ib.w));
+                const uint2 v = stash[c * 64 + lane], e = par[nl >> 2], q = par[BN / 4 + (nl >> 2)];
+                h2v x0, x1, e0, e1, q0, q1;
+                __builtin_memcpy(&x0, &v.x, 4); __builtin_memcpy(&x1, &v.y, 4);
+                __builtin_memcpy(&e0, &e.x, 4); __builtin_memcpy(&e1, &e.y, 4);
+                __builtin_memcpy(&q0, &q.x, 4); __builtin_memcpy(&q1, &q.y, 4);
+                const h2v y0 = snake_h2(x0, e0, q0), y1 = snake_h2(x1, e1, q1);
+                uint2 o;
+                __builtin_memcpy(&o.x, &y0, 4);
+                __builtin_memcpy(&o.y, &y1, 4);
+                *reinterpret_cast<uint2*>(dst + nl) = o;
             }
         }
     }
@@ -356,15 +370,19 @@ void launch_conv_gemm_h1(const ConvH1Args& a, hipStream_t st) {
     else if (a.N % 96 == 0) BN = 96;
     else if (a.N > 128 && (a.N % 64) != 0) BN = 128;
     const dim3 grid((a.N + BN - 1) / BN, mt, a.B), block(256);
-    // LDS: the tiles, or the SnakeBeta pass's stash (4 waves x CT x 64 float4) + parameters, whichever is larger
-    const size_t tiles = size_t(BM + (a.K - 1) * a.dil + 2 * BN) * RH * sizeof(uint32_t);
-    const size_t pass = size_t(4 * (BN / 32) * 64 + 2 * (BN / 4)) * sizeof(float4);
+    // LDS: the input tile, or the SnakeBeta pass's stash (4 waves x CT x 64 uint2) + parameters, whichever is larger
+    const size_t tiles = size_t(BM + (a.K - 1) * a.dil) * RH * sizeof(uint32_t);
+    const size_t pass = size_t(4 * (BN / 32) * 64 + 2 * (BN / 4)) * sizeof(uint2);
     const size_t smem = std::max(tiles, pass);
     Q3_CHECK(smem <= 64 * 1024, 3, "conv_gemm_h1: tile does not fit the static LDS limit");
+    Q3_CHECK(a.K == 1 || a.K == 2 || a.K == 7, 3, "conv_gemm_h1: 1, 2 or 7 taps (the MainDecoder's convs)");
+    Q3_CHECK(!a.x_f32 || (a.K == 7 && BN == 128), 3, "conv_gemm_h1: the fp32-input form is initConv's");
 #define Q3_H1(BNv)                                                                                              \
     do {                                                                                                        \
-        if (a.x_f32) hipLaunchKernelGGL((conv_gemm_h1_kernel<BNv, true>), grid, block, smem, st, a);            \
-        else hipLaunchKernelGGL((conv_gemm_h1_kernel<BNv, false>), grid, block, smem, st, a);                   \
+        if (a.x_f32) hipLaunchKernelGGL((conv_gemm_h1_kernel<128, 7, true>), grid, block, smem, st, a);         \
+        else if (a.K == 7) hipLaunchKernelGGL((conv_gemm_h1_kernel<BNv, 7, false>), grid, block, smem, st, a);  \
+        else if (a.K == 2) hipLaunchKernelGGL((conv_gemm_h1_kernel<BNv, 2, false>), grid, block, smem, st, a);  \
+        else hipLaunchKernelGGL((conv_gemm_h1_kernel<BNv, 1, false>), grid, block, smem, st, a);                \
     } while (0)
     switch (BN) {
         case 128: Q3_H1(128); break;

@@ -11,7 +11,8 @@ sys.path.insert(0, os.path.join(ROOT, "swift-qwen3-tts_amd"))
 from qwen3tts import Qwen3TTSModel, synth  # noqa: E402
 
 B, F, reps = int(sys.argv[1]) if len(sys.argv) > 1 else 16, int(sys.argv[2]) if len(sys.argv) > 2 else 200, 3
-d = "/tmp/q3tts_codec_only"
+f16 = os.environ.get("Q3TTS_CODEC_ONLY_F16") == "1"   # the speech tokenizer stored in float16 ("lite" checkpoints): codec_conv_h1.hip
+d = "/tmp/q3tts_codec_only" + ("_f16" if f16 else "")
 if not os.path.exists(os.path.join(d, ".complete")):
     p = synth.preset("tiny-a")          # tiny talker, FULL-SIZE codec decoder
     p["speech_tokenizer"]["decoder_config"] = synth._codec_cfg(False)
@@ -22,8 +23,10 @@ if not os.path.exists(os.path.join(d, ".complete")):
     json.dump(p["config"], open(os.path.join(d, "config.json"), "w"))
     json.dump(p["speech_tokenizer"], open(os.path.join(d, "speech_tokenizer", "config.json"), "w"))
     synth.save_safetensors(os.path.join(d, "model.safetensors"), synth.talker_tensors(p["config"], g))
-    synth.save_safetensors(os.path.join(d, "speech_tokenizer", "model.safetensors"),
-                           synth.codec_tensors(p["speech_tokenizer"]["decoder_config"], g, out_wstd=synth.FULL_WIDTH_OUT_WSTD))
+    ct = synth.codec_tensors(p["speech_tokenizer"]["decoder_config"], g, out_wstd=synth.FULL_WIDTH_OUT_WSTD)
+    if f16:
+        ct = {k: (("F16", v.astype(np.float16)) if tag == "F32" else (tag, v)) for k, (tag, v) in ct.items()}
+    synth.save_safetensors(os.path.join(d, "speech_tokenizer", "model.safetensors"), ct)
     open(os.path.join(d, ".complete"), "w").write("ok")
 rng = np.random.default_rng(0)
 codes = rng.integers(1, 2048, size=(B, F, 16)).astype(np.int32)
