@@ -348,6 +348,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
 // decodes the flagged rows once more on the fp32 matrix-core kernel below (Engine::redo_rows_fp32, Engine::codec_decode).
 // An LDS row holds the two planes of 32 input channels (2 x 64 B) + 32 B of padding = 10 sixteen-byte units (10 = 2 mod 4:
 // conflict-free ds_read_b128); weight tiles are double-buffered (one barrier per tap): (128 + halo + 2 BN) x 160 B <= 70 KiB.
+// (Round 4 tried this kernel with its weight fragments fetched per wave straight from the L2 into registers and one barrier
+// pair per chunk, the form that made codec_conv_h1.hip 1.8x faster: bit-identical, and SLOWER here, 113.9 -> 125.8 ms per
+// 32 x 200-frame decode -- with two planes the two position halves of a workgroup fetch 32 KB of identical fragments per step,
+// and at 48 MFMAs per step the shared LDS tile's barrier is the cheaper of the two. Removed; tools/codec_ab.py measured it.)
 constexpr int ROWH = 40;  // dwords per LDS row
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
