@@ -252,7 +252,10 @@ def main():
         # The job's only collective. Default: the library's own broadcast (q3tts_model_broadcast: RCCL straight from
         # the C ABI, the path a Swift or C host takes -- torch only carries the 128-byte communicator id). Fallback, and the
         # one-device gloo rehearsal: torch.distributed over a zero-copy view of the arena.
-        want_native = os.environ.get("Q3TTS_BENCH_BROADCAST", "native") == "native" and backend == "nccl" and not dry
+        # ("native-force": also in the one-device gloo rehearsal, where RCCL must refuse two ranks on one GPU -- that run
+        # exercises the every-rank-agrees fallback below on hardware)
+        how = os.environ.get("Q3TTS_BENCH_BROADCAST", "native")
+        want_native = ((how == "native" and backend == "nccl") or how == "native-force") and not dry
         ok = 0
         if want_native:
             ids = [None]
