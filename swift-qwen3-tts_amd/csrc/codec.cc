@@ -308,6 +308,31 @@ void CodecRunner::run_main_h1(const Pass& ps, int T, int ppf, int cur, float* co
         const auto& Bk = w.blocks[i];
         uint16_t *hs = H(cur + 1), *y = H(cur + 2), *ya = H(cur + 3), *t1 = H(cur);
         const SnakeW* after = i + 1 < nblk ? &w.blocks[i + 1].snake : nullptr;
+        bool fused = !no_fuse_ && resunit_h1_supported(Bk.Cout, Bk.res[0].conv1.K, 9);
+        for (int j = 0; j < 3; ++j)
+            fused = fused && Bk.res[j].conv1.w1 && Bk.res[j].conv2.w1p && Bk.res[j].conv1.N == Bk.Cout && Bk.res[j].conv2.K == 1 &&
+                    resunit_h1_supported(Bk.Cout, Bk.res[j].conv1.K, Bk.res[j].conv1.dil);
+        if (fused) {
+            // narrow blocks: each residual unit is one launch (resunit_h1_kernel), y ping-pongs between two buffers
+            conv_h1(ps, Bk.tconv, hs, false, T, ppf, y, nullptr, nullptr, nullptr);  // snake (applied by the producer) -> transposed conv
+            T *= Bk.stride;
+            ppf *= Bk.stride;
+            uint16_t *yin = y, *yout = t1;
+            for (int j = 0; j < 3; ++j) {
+                ResUnitH1Args r{};
+                r.y = yin; r.out = yout;
+                if (j == 2 && after) { r.out2 = hs; r.post_ea = after->ea16; r.post_ib = after->ib16; }
+                r.b1 = Bk.res[j].conv1.bias; r.b2 = Bk.res[j].conv2.bias;
+                r.w1 = Bk.res[j].conv1.w1; r.w2p = Bk.res[j].conv2.w1p;
+                r.ea1 = Bk.res[j].act1.ea16; r.ib1 = Bk.res[j].act1.ib16; r.ea2 = Bk.res[j].act2.ea16; r.ib2 = Bk.res[j].act2.ib16;
+                r.frames = ps.fr; r.ppf = ppf; r.Tmax = T; r.B = ps.nb; r.C = Bk.Cout; r.dil = Bk.res[j].conv1.dil;
+                launch_resunit_h1(r, st_);
+                std::swap(yin, yout);
+            }
+            // three units: the result sits in t1 = H(cur), its activated copy (if any) in hs = H(cur + 1)
+            capture_h(ps, ("block" + std::to_string(i)).c_str(), H(cur), T, Bk.Cout);
+            continue;
+        }
         conv_h1(ps, Bk.tconv, hs, false, T, ppf, y, nullptr, &Bk.res[0].act1, ya);  // snake -> transposed conv (:474-475)
         T *= Bk.stride;
         ppf *= Bk.stride;

@@ -67,6 +67,27 @@ struct ConvH1Args {
     int ppf, Tmax, B, Cin, N, K, dil;
 };
 void launch_conv_gemm_h1(const ConvH1Args& a, hipStream_t st);
+// DecoderResidualUnit (SpeechTokenizer.swift:430-437) on float16 tensors in one launch (kernels/codec_conv_h1.hip resunit_h1_kernel):
+// out = y + conv2(act2(conv1(act1(y)))), C = 96, conv1 seven taps. y is read once (+ halo), the sum written once.
+struct ResUnitH1Args {
+    const uint16_t* y;    // [B][Tmax][C] float16
+    uint16_t* out;        // != y
+    uint16_t* out2;       // optional: SnakeBeta(post_ea, post_ib) of the result (the next block's input) or nullptr
+    const float* post_ea; // SnakeW::ea16 / ib16 arrays throughout
+    const float* post_ib;
+    const float* b1;      // [C] or nullptr
+    const float* b2;
+    const uint16_t* w1;   // conv1 [7][C/32][C][32] fp16 (attach_h1)
+    const uint16_t* w2p;  // conv2 [C/32][C][32] fp16 in the fused k order (attach_h1_perm)
+    const float* ea1;
+    const float* ib1;
+    const float* ea2;
+    const float* ib2;
+    const int32_t* frames;
+    int ppf, Tmax, B, C, dil;
+};
+bool resunit_h1_supported(int C, int K, int dil);
+void launch_resunit_h1(const ResUnitH1Args& a, hipStream_t st);
 // SnakeBeta -> k7 conv C -> 1 -> clip on a float16 tensor (kernels/codec_conv_h1.hip)
 void launch_out_conv_h1(const uint16_t* x, int C, const float* ea16, const float* ib16, const float* w, const float* bias,
                         const int32_t* frames, int ppf, int Tmax, int B, float* pcm, hipStream_t st, int32_t* nonfinite);

@@ -309,6 +309,244 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_h1_kernel(ConvH1Args a) {
     }
 }
 
+// ---- a whole DecoderResidualUnit of the two narrow blocks in one launch -------------------------------------------------
+// out = y + conv2(act2(conv1(act1(y))))  (SpeechTokenizer.swift:430-437) for C = 96 on float16 tensors (the template takes 192 too; see resunit_h1_supported). As separate
+// launches the unit moves its tensor six times (act1(y) in, act2(conv1) out and back in, y in, y out, the activated copy out) and
+// its pointwise half is HBM-bound (9.4 GB in 2.4 ms at 96 channels); here y is read once (+ halo; the raw tile a second time
+// from the L2 for the residual) and the sum is written once. The structure is resunit_h2_kernel's (codec_conv.hip) with one
+// plane: every wave owns 16 PT positions x ALL channels, act1 is applied while the raw tile is staged (one 32-channel chunk at a
+// time, the only thing that goes through LDS), conv1's accumulators -- rounded and activated the way MLX rounds them -- ARE
+// conv2's B fragments once conv2's weights are stored in the matching k order (model.cc attach_h1_perm: an accumulator pair of
+// a lane holds 8 k values of its position), so conv1's output never leaves the registers. Weight fragments come per wave
+// straight from the L2 (conv_gemm_h1_kernel), three steps deep in registers; the whole (chunk, tap) loop is unrolled so that
+// the ring's slots are compile-time registers and hipcc's wait counts are exact. The sum goes to a second buffer because
+// neighbouring workgroups still need the old halo rows. Rounding points: _main_decoder16's, op for op.
+template <int CT2, int PT>
+__global__ __launch_bounds__(256, 2) void resunit_h1_kernel(ResUnitH1Args a) {
+    constexpr int C = 16 * CT2, NCH = CT2 / 2, PW = 16 * PT, BMU = 4 * PW, KT = 7, S1 = NCH * KT;
+    constexpr int D = CT2 >= 12 ? 2 : 3;  // ring depth in steps: 12 fragments per step at 192 channels leave room for two
+    constexpr int CG = 6, NG = CT2 / CG;  // conv2 in passes of six output-channel tiles
+    static_assert(CT2 % CG == 0 && CT2 % 2 == 0, "channel tiles must split into passes and into 32-channel chunks");
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem1[];
+    const int halo = (KT - 1) * a.dil;
+    uint32_t* As = smem1;  // [(BMU + halo)][RH]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.y * BMU;
+    const int T = a.frames[b] * a.ppf;
+    if (t0 >= T) return;
+    const int rows = BMU + halo;
+    const size_t boff = (size_t)b * a.Tmax * C;
+    const uint16_t* yb = a.y + boff;
+
+    f32x4 acc1[PT][CT2];
+#pragma unroll
+    for (int p = 0; p < PT; ++p)
+#pragma unroll
+        for (int c = 0; c < CT2; ++c) acc1[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // conv1's fragments: (tap, chunk) blocks of C rows x 4 sixteen-byte pieces; this lane: row 16 c + (lane & 15), piece lane >> 4
+    const uint4* w1l = reinterpret_cast<const uint4*>(a.w1) + (size_t)(lane & 15) * 4 + (lane >> 4);
+    uint4 wf[D][CT2];
+    auto load_w1 = [&](int slot, int step) {
+        const int chunk = step / KT, tap = step - chunk * KT;
+        const uint4* src = w1l + (size_t)(tap * NCH + chunk) * C * 4;
+#pragma unroll
+        for (int c = 0; c < CT2; ++c) wf[slot][c] = src[c * 64];
+    };
+
+    // input tile, one 32-channel chunk at a time: (BMU + halo) rows x 4 pieces of 8 channels
+    constexpr int AV = ((BMU + MAX_HALO) * 4 + 255) / 256;
+    uint4 areg[AV];
+    auto load_a = [&](int chunk) {
+        const int c0 = chunk * KC;
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int item = i * 256 + tid;
+            const int r = item >> 2, c8 = (item & 3) * 8;
+            const int t = t0 - halo + r;
+            const int tc = t < 0 ? 0 : (t < T ? t : T - 1);  // clamped address, value masked when it is staged
+            areg[i] = *reinterpret_cast<const uint4*>(yb + (int64_t)tc * C + c0 + c8);
+        }
+    };
+    auto store_a = [&](int chunk) {
+        const int c0 = chunk * KC, c8 = (tid & 3) * 8;  // a thread's pieces all sit in the same eight channels
+        const float4 e0 = *reinterpret_cast<const float4*>(a.ea1 + c0 + c8), e1 = *reinterpret_cast<const float4*>(a.ea1 + c0 + c8 + 4);
+        const float4 i0 = *reinterpret_cast<const float4*>(a.ib1 + c0 + c8), i1 = *reinterpret_cast<const float4*>(a.ib1 + c0 + c8 + 4);
+        const uint2 eh0 = pack_h4(e0.x, e0.y, e0.z, e0.w), eh1 = pack_h4(e1.x, e1.y, e1.z, e1.w);
+        const uint2 ih0 = pack_h4(i0.x, i0.y, i0.z, i0.w), ih1 = pack_h4(i1.x, i1.y, i1.z, i1.w);
+        const uint32_t ew[4] = {eh0.x, eh0.y, eh1.x, eh1.y}, iw[4] = {ih0.x, ih0.y, ih1.x, ih1.y};
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int item = i * 256 + tid;
+            const int r = item >> 2;
+            if (r >= rows) continue;
+            const int t = t0 - halo + r;
+            uint32_t v[4] = {areg[i].x, areg[i].y, areg[i].z, areg[i].w};
+            if (t >= 0 && t < T) {  // act1 on the raw tile (rows outside the sequence stay zero: causal padding is not activated)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    h2v x, e, q;
+                    __builtin_memcpy(&x, &v[j], 4);
+                    __builtin_memcpy(&e, &ew[j], 4);
+                    __builtin_memcpy(&q, &iw[j], 4);
+                    const h2v y = snake_h2(x, e, q);
+                    __builtin_memcpy(&v[j], &y, 4);
+                }
+            } else {
+                v[0] = v[1] = v[2] = v[3] = 0u;
+            }
+            *reinterpret_cast<uint4*>(&As[r * RH + (item & 3) * 4]) = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+    };
+
+    // ---- conv1: fully unrolled over (chunk, tap); fragments of step s + D - 1 are requested at the top of step s ----
+    load_a(0);
+#pragma unroll
+    for (int s = 0; s < D - 1; ++s) load_w1(s, s);
+#pragma unroll
+    for (int chunk = 0; chunk < NCH; ++chunk) {
+        __syncthreads();  // the previous chunk's MFMAs are done with As
+        store_a(chunk);
+        if (chunk + 1 < NCH) load_a(chunk + 1);
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < KT; ++tap) {
+            const int step = chunk * KT + tap;
+            if (step + D - 1 < S1) load_w1((step + D - 1) % D, step + D - 1);
+            const uint32_t* arow = &As[(PW * wave + tap * a.dil + (lane & 15)) * RH + 4 * (lane >> 4)];
+            uint4 xa[PT];
+#pragma unroll
+            for (int p = 0; p < PT; ++p) xa[p] = *reinterpret_cast<const uint4*>(arow + p * 16 * RH);
+#pragma unroll
+            for (int p = 0; p < PT; ++p)
+#pragma unroll
+                for (int c = 0; c < CT2; ++c) acc1[p][c] = mfma_h(wf[step % D][c], xa[p], acc1[p][c]);
+        }
+    }
+
+    // ---- fp16(acc), + bias1, act2 (the reference's op order), packed into conv2's B fragments: pair (2m, 2m + 1) of a lane ----
+    const int q4 = 4 * (lane >> 4);
+    uint4 xb[PT][NCH];
+#pragma unroll
+    for (int m = 0; m < NCH; ++m) {
+        uint32_t bw[2][2], ew[2][2], iw[2][2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int n = 16 * (2 * m + e) + q4;
+            const float4 bv = a.b1 ? *reinterpret_cast<const float4*>(a.b1 + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 ev = *reinterpret_cast<const float4*>(a.ea2 + n), iv = *reinterpret_cast<const float4*>(a.ib2 + n);
+            const uint2 bp = pack_h4(bv.x, bv.y, bv.z, bv.w), ep = pack_h4(ev.x, ev.y, ev.z, ev.w), ip = pack_h4(iv.x, iv.y, iv.z, iv.w);
+            bw[e][0] = bp.x; bw[e][1] = bp.y; ew[e][0] = ep.x; ew[e][1] = ep.y; iw[e][0] = ip.x; iw[e][1] = ip.y;
+        }
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            uint32_t o[4];
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const f32x2v av = {acc1[p][2 * m + e][2 * hh], acc1[p][2 * m + e][2 * hh + 1]};
+                    h2v v = __builtin_convertvector(av, h2v);  // conv1(x, w)
+                    h2v bh, eh, ih;
+                    __builtin_memcpy(&bh, &bw[e][hh], 4);
+                    __builtin_memcpy(&eh, &ew[e][hh], 4);
+                    __builtin_memcpy(&ih, &iw[e][hh], 4);
+                    if (a.b1) v = v + bh;                       // + bias
+                    v = snake_h2(v, eh, ih);                    // act2
+                    __builtin_memcpy(&o[2 * e + hh], &v, 4);
+                }
+            xb[p][m] = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+
+    // ---- conv2 in NG passes of CG output-channel tiles; fragments of chunk m + 1 are requested while chunk m multiplies ----
+    const uint4* w2l = reinterpret_cast<const uint4*>(a.w2p) + (size_t)(lane & 15) * 4 + (lane >> 4);
+    __syncthreads();  // every wave is done with As: the SnakeBeta pass below parks values there
+    uint2* stash = reinterpret_cast<uint2*>(smem1) + wave * (CG * 64);
+#pragma unroll
+    for (int h = 0; h < NG; ++h) {
+        f32x4 acc2[PT][CG];
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+#pragma unroll
+            for (int c = 0; c < CG; ++c) acc2[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        uint4 w2[2][CG];
+        auto load_w2 = [&](int slot, int m) {
+#pragma unroll
+            for (int c = 0; c < CG; ++c) w2[slot][c] = w2l[((size_t)m * C + 16 * (h * CG + c)) * 4];
+        };
+        load_w2(0, 0);
+#pragma unroll
+        for (int m = 0; m < NCH; ++m) {
+            if (m + 1 < NCH) load_w2((m + 1) & 1, m + 1);
+#pragma unroll
+            for (int p = 0; p < PT; ++p)
+#pragma unroll
+                for (int c = 0; c < CG; ++c) acc2[p][c] = mfma_h(w2[m & 1][c], xb[p][m], acc2[p][c]);
+        }
+        // ---- this pass's channels: fp16(acc), + bias2, residual + . -> out; optionally the next block's SnakeBeta -> out2 ----
+        uint2 rvs[PT][CG];
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            const int t = t0 + PW * wave + 16 * p + (lane & 15);
+            const int tc = t < T ? t : T - 1;
+#pragma unroll
+            for (int c = 0; c < CG; ++c) rvs[p][c] = *reinterpret_cast<const uint2*>(yb + (size_t)tc * C + 16 * (h * CG + c) + q4);
+        }
+        uint2 yh[PT][CG];
+#pragma unroll
+        for (int c = 0; c < CG; ++c) {
+            const int n = 16 * (h * CG + c) + q4;
+            const float4 bv = a.b2 ? *reinterpret_cast<const float4*>(a.b2 + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const h2v b0 = {static_cast<_Float16>(bv.x), static_cast<_Float16>(bv.y)}, b1h = {static_cast<_Float16>(bv.z), static_cast<_Float16>(bv.w)};
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                const int t = t0 + PW * wave + 16 * p + (lane & 15);
+                const f32x2v a0 = {acc2[p][c][0], acc2[p][c][1]}, a1 = {acc2[p][c][2], acc2[p][c][3]};
+                h2v v0 = __builtin_convertvector(a0, h2v), v1 = __builtin_convertvector(a1, h2v);  // conv2(x, w)
+                if (a.b2) { v0 = v0 + b0; v1 = v1 + b1h; }                                         // + bias
+                h2v r0, r1;
+                __builtin_memcpy(&r0, &rvs[p][c].x, 4);
+                __builtin_memcpy(&r1, &rvs[p][c].y, 4);
+                v0 = r0 + v0;                                                                      // residual + h
+                v1 = r1 + v1;
+                uint2 pk;
+                __builtin_memcpy(&pk.x, &v0, 4);
+                __builtin_memcpy(&pk.y, &v1, 4);
+                yh[p][c] = pk;
+                if (t < T) *reinterpret_cast<uint2*>(a.out + boff + (size_t)t * C + n) = pk;
+            }
+        }
+        if (a.out2) {
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+#pragma unroll
+                for (int c = 0; c < CG; ++c) stash[c * 64 + lane] = yh[p][c];
+                const int t = t0 + PW * wave + 16 * p + (lane & 15);
+                if (t >= T) continue;
+#pragma unroll 1
+                for (int c = 0; c < CG; ++c) {
+                    const int n = 16 * (h * CG + c) + q4;
+                    const uint2 v = stash[c * 64 + lane];
+                    const float4 ev = *reinterpret_cast<const float4*>(a.post_ea + n), iv = *reinterpret_cast<const float4*>(a.post_ib + n);
+                    const uint2 ep = pack_h4(ev.x, ev.y, ev.z, ev.w), ip = pack_h4(iv.x, iv.y, iv.z, iv.w);
+                    h2v x0, x1, e0, e1, i0, i1;
+                    __builtin_memcpy(&x0, &v.x, 4); __builtin_memcpy(&x1, &v.y, 4);
+                    __builtin_memcpy(&e0, &ep.x, 4); __builtin_memcpy(&e1, &ep.y, 4);
+                    __builtin_memcpy(&i0, &ip.x, 4); __builtin_memcpy(&i1, &ip.y, 4);
+                    const h2v y0 = snake_h2(x0, e0, i0), y1 = snake_h2(x1, e1, i1);
+                    uint2 o;
+                    __builtin_memcpy(&o.x, &y0, 4);
+                    __builtin_memcpy(&o.y, &y1, 4);
+                    *reinterpret_cast<uint2*>(a.out2 + boff + (size_t)t * C + n) = o;
+                }
+            }
+        }
+    }
+}
+
 // out[t] = clip(fp16(fp16(sum_{k,c} snake(x[t-6+k][c]) * w[k][c]) + bias)): the MainDecoder's tail on a float16 tensor
 // (SpeechTokenizer.swift:687-688, 781). 64 positions per workgroup, 4 lanes each, activated tile and taps in LDS (the layout of
 // codec_misc.hip out_conv_kernel).
@@ -390,6 +628,24 @@ void launch_conv_gemm_h1(const ConvH1Args& a, hipStream_t st) {
         default: Q3_H1(64); break;
     }
 #undef Q3_H1
+}
+
+// Measured at 32 x 200 frames (profiles/r04_codec_f16_launches.txt): at 96 channels the fused unit takes 3.2-3.4 ms against 2.72 +
+// 2.43 for its two convs as launches. At 192 channels the <12, 2> form (32 positions per wave: acc1 for 64 would not fit) took
+// 5.22 ms against 2.77 + 1.90: every wave fetches twelve weight fragments per 24 MFMAs, twice the L2 traffic per MFMA of the other
+// kernels, four waves fetching the same ones -- not instantiated; the 192-channel units stay two launches each.
+bool resunit_h1_supported(int C, int K, int dil) { return C == 96 && K == 7 && 6 * dil <= MAX_HALO; }
+
+void launch_resunit_h1(const ResUnitH1Args& a, hipStream_t st) {
+    Q3_CHECK(resunit_h1_supported(a.C, 7, a.dil) && a.out != a.y, 3, "resunit_h1: unsupported geometry");
+    Q3_CHECK(a.w1 && a.w2p && a.ea1 && a.ib1 && a.ea2 && a.ib2, 3, "resunit_h1: incomplete float16 weights");
+    Q3_CHECK(!a.out2 || (a.post_ea && a.post_ib), 3, "resunit_h1: activated output without its parameters");
+    if (a.Tmax <= 0 || a.B <= 0) return;
+    const int bmu = a.C == 96 ? 256 : 128;  // positions per workgroup (64 PT)
+    // LDS: the input tile of one chunk, or the SnakeBeta pass's stash (4 waves x 6 tiles x 64 uint2), whichever is larger
+    const size_t smem = std::max(size_t(bmu + 6 * a.dil) * RH * sizeof(uint32_t), size_t(4 * 6 * 64) * sizeof(uint2));
+    const dim3 grid(1, (a.Tmax + bmu - 1) / bmu, a.B), block(256);
+    hipLaunchKernelGGL((resunit_h1_kernel<6, 4>), grid, block, smem, st, a);
 }
 
 void launch_out_conv_h1(const uint16_t* x, int C, const float* ea, const float* ib, const float* w, const float* bias,

@@ -636,6 +636,26 @@ void attach_h1(Builder& b, ConvW& c, const std::vector<float>& w) {
     c.w1 = b.put<uint16_t>(p.empty() ? nullptr : p.data(), n);
 }
 
+// conv2 of a residual unit for the fused float16 kernel (codec_conv_h1.hip resunit_h1_kernel): k slot s = 8q + 4e + j of chunk m
+// holds input channel 32m + 16e + 4q + j -- what lane group q of an accumulator pair (tiles 2m, 2m + 1) carries in registers j of
+// tile e (the order of attach_h2_perm)
+void attach_h1_perm(Builder& b, ConvW& c, const std::vector<float>& w) {
+    if (!b.h1 || c.K != 1 || c.Cin % 32 != 0) return;
+    const int chunks = c.Cin / 32;
+    const size_t n = size_t(chunks) * c.N * 32;
+    std::vector<uint16_t> p;
+    if (!b.dry && b.fill && !w.empty()) {
+        p.assign(n, 0);
+        for (int nn = 0; nn < c.N; ++nn)
+            for (int m = 0; m < chunks; ++m)
+                for (int sl = 0; sl < 32; ++sl) {
+                    const int q = sl >> 3, e = (sl >> 2) & 1, j = sl & 3;
+                    p[(size_t(m) * c.N + nn) * 32 + sl] = f32_to_f16_bits(w[size_t(nn) * c.Cin + 32 * m + 16 * e + 4 * q + j]);
+                }
+    }
+    c.w1p = b.put<uint16_t>(p.empty() ? nullptr : p.data(), n);
+}
+
 ConvW put_conv(Builder& b, const TMap& t, const std::string& name, int dil = 1) {
     const HostTensor& w = need(t, name + ".weight");
     ConvW c;
@@ -837,6 +857,7 @@ void build_codec(Builder& b, const TMap& t, const CodecDecoderConfig& dc, CodecW
             B.res[j].act2 = put_snake(b, t, rp + ".act2");
             B.res[j].conv2 = put_conv(b, t, rp + ".conv2.conv");
             attach_h2_perm(b, B.res[j].conv2, need(t, rp + ".conv2.conv.weight").data);
+            attach_h1_perm(b, B.res[j].conv2, need(t, rp + ".conv2.conv.weight").data);
         }
     }
     c.out_snake = put_snake(b, t, "decoder.decoder.outSnake");

@@ -54,6 +54,7 @@ struct ConvW {  // fp32 conv as GEMM: w[N][K][Cin]; transposed convs are stored 
                                    // chunk in the order the fused kernel's accumulators hold them (codec_conv.hip resunit_h2_kernel)
     const uint16_t* w1 = nullptr;  // MainDecoder convs of a float16 checkpoint: the weights themselves, [K][ceil(Cin/32)][N][32] fp16
                                    // (codec_conv_h1.hip; model.cc attach_h1)
+    const uint16_t* w1p = nullptr; // ... and a residual unit's pointwise conv2 in the fused kernel's k order (attach_h1_perm), [Cin/32][N][32]
     const float* bias = nullptr;   // [N] or nullptr
     const float* scale = nullptr;  // per-output-channel scale (LayerScale / ConvNeXt gamma) or nullptr
     int Cin = 0, N = 0, K = 1, dil = 1;
