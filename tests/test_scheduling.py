@@ -76,7 +76,9 @@ def test_launch_geometry_switches_change_nothing(ckpt_dirs, monkeypatch, name):
                     "Q3TTS_CHUNK_QSPLIT", "Q3TTS_PF", "Q3TTS_PF_BUDGET_KB", "Q3TTS_PF_AHEAD")
     for env in ({}, {"Q3TTS_ROWS_64": "1"}, {"Q3TTS_GEMM_NO_ROW_SPLIT": "1", "Q3TTS_GEMM_ONE_PAIR": "1"}, {"Q3TTS_NO_TALL_GEMM": "1"},
                 {"Q3TTS_TALL_SHAPE": "2", "Q3TTS_CHUNK_QSPLIT": "1"}, {"Q3TTS_CHUNK_QSPLIT": "4"},
-                # next-launch weight touch (kernels/prefetch.h): off, and with a plan that looks far ahead on a tiny budget
+                # next-launch weight touch (kernels/prefetch.h): off, and two extreme plans. The SHIPPED build compiles the touch code out
+                # (it lost), so these three only exercise the switches' plumbing there; on a library built by
+                # tools/build_pf_variants.sh they are the bit-identity check of the planner (run that way in round 4)
                 {"Q3TTS_PF": "0"}, {"Q3TTS_PF_BUDGET_KB": "64", "Q3TTS_PF_AHEAD": "7"}, {"Q3TTS_PF_BUDGET_KB": "100000", "Q3TTS_PF_AHEAD": "1"}):
         for k in all_switches:
             monkeypatch.delenv(k, raising=False)
