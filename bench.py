@@ -321,13 +321,15 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     dec_ms = pre_ms = codec_ms = fe_ms = 0.0
+    launches = 0
     frame_steps = 0
     kv_bytes = 0
     frames_done = 0
 
     def account(res):
-        nonlocal dec_ms, pre_ms, codec_ms, fe_ms, frame_steps, kv_bytes, frames_done
+        nonlocal dec_ms, pre_ms, codec_ms, fe_ms, frame_steps, kv_bytes, frames_done, launches
         tm = model.last_timing()  # timing of the job that just ended
+        launches = max(launches, getattr(tm, "launches_per_frame_step", 0))
         pre_ms += tm.prefill_ms
         dec_ms += tm.decode_ms
         codec_ms += tm.codec_ms
@@ -432,6 +434,11 @@ def main():
                      "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": step_ms,
                      "avg_launch_ms_alone": solo["frame_step"] if solo else None,
+                     # what the frame step is made of: a chain of dependent kernel launches (graph nodes). On this part a dependent
+                     # kernel that loads its input and stores its output costs ~4.5 us however small: launch
+                     # count x that floor, not bytes, bounds the step
+                     "chain": ({"launches_per_frame_step": launches, "us_per_launch": step_ms * 1e3 / launches,
+                                "us_per_launch_alone": (solo["frame_step"] * 1e3 / launches) if solo else None} if launches else None),
                      # the same kernel with nothing beside it (last warm-up step): in the pipelined region the frame loop
                      # shares the chip with the previous batch's codec decode, which is what `frac` above includes
                      "frac_alone": (algo_bytes / (solo["frame_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if solo and solo["frame_step"] else None},

@@ -294,6 +294,8 @@ typedef struct {
     int64_t kv_bytes_read;  /* algorithmic KV bytes read over all frame steps */
     double frontend_ms;     /* voice clone: codec encoder + speaker encoder over all rows of the call */
     double first_audio_ms;  /* streamed decode: request in -> first AUDIO_CHUNK samples on the host (0 when nothing streamed) */
+    int32_t launches_per_frame_step; /* kernel launches (graph nodes) of ONE frame step at this call's batch size: the chain decode_ms
+                                        is made of is frame_steps x this many dependent launches */
 } q3tts_timing;
 q3tts_status q3tts_last_timing(const q3tts_model* m, q3tts_timing* out);
 

@@ -527,6 +527,7 @@ void Engine::gemm(GemmArgs a) {
         return;
     }
     a.pf = plan_mode_ == 2 ? pf_[plan_pos_++] : empty_touch(a.W);
+    ++launches_;
     launch_gemm_skinny(a, st_);
 }
 
@@ -540,6 +541,7 @@ bool Engine::gemm_with_norm_rows(GemmArgs a, const NormRowsArgs& n) {
     a.pf = plan_mode_ == 2 ? pf_[plan_pos_] : empty_touch(a.W);
     const bool rode = launch_gemm_skinny_with_norm_rows(a, n, st_);
     if (rode && plan_mode_ == 2) ++plan_pos_;
+    if (rode) ++launches_;
     return rode;
 }
 
@@ -551,6 +553,7 @@ void Engine::attn(AttnArgs a) {
         return;
     }
     a.pf = plan_mode_ == 2 ? pf_[plan_pos_++] : empty_touch(a.qkv);
+    ++launches_;
     launch_attn_decode(a, st_);
 }
 
@@ -599,6 +602,12 @@ void Engine::plan_touches() {
 }
 
 void Engine::enqueue_frame(int B, const DebugOpts* dbg) {
+    struct Count {  // launches of this frame step, for q3tts_timing (the same count whether captured or launched eagerly)
+        Engine* e;
+        int B;
+        ~Count() { e->frame_launches_[B] = e->launches_; }
+    } count{this, B};
+    launches_ = 0;
     if (Q3_PF_MODE == 0) {  // the shipped build: no kernel carries the touch code, nothing to plan
         enqueue_frame_body(B, dbg);
         return;
@@ -1439,6 +1448,10 @@ int Engine::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3
     Q3_HIP(hipEventElapsedTime(&ms, ev_fe_[0], ev_fe_[1]));
     J.timing.frontend_ms = ms;
     J.timing.frame_steps = launched;
+    {
+        auto fl = frame_launches_.find(n);
+        J.timing.launches_per_frame_step = fl == frame_launches_.end() ? 0 : fl->second;
+    }
     J.timing.rows = n;
     {
         int64_t kvb = 0;
@@ -2089,6 +2102,7 @@ void EngineGroup::generate(const q3tts_request* reqs, int n, const q3tts_samplin
         timing.frontend_ms = std::max(timing.frontend_ms, t.frontend_ms);
         timing.first_audio_ms = std::max(timing.first_audio_ms, t.first_audio_ms);
         timing.frame_steps = std::max(timing.frame_steps, t.frame_steps);
+        timing.launches_per_frame_step = std::max(timing.launches_per_frame_step, t.launches_per_frame_step);
         timing.rows += t.rows;
         timing.kv_bytes_read += t.kv_bytes_read;
     }

@@ -217,8 +217,11 @@ class Engine {
     void other(F&& f) {                        // any launch that neither streams weights worth touching nor touches
         if (plan_mode_ == 1) { plan_.emplace_back(); return; }
         if (plan_mode_ == 2) ++plan_pos_;
+        ++launches_;
         f();
     }
+    int launches_ = 0;                         // launches enqueued since enqueue_frame last reset it
+    std::map<int, int> frame_launches_;        // launches of one frame step, keyed by batch size (q3tts_timing)
     std::map<int, hipGraphExec_t> graphs_;  // keyed by batch size
     std::unique_ptr<CodecRunner> codec_;
     std::unique_ptr<VoiceFrontEnd> fe_;

@@ -72,7 +72,7 @@ class Result(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("prefill_ms", C.c_double), ("decode_ms", C.c_double), ("codec_ms", C.c_double),
                 ("frame_steps", C.c_int32), ("rows", C.c_int32), ("kv_bytes_read", C.c_int64),
-                ("frontend_ms", C.c_double), ("first_audio_ms", C.c_double)]
+                ("frontend_ms", C.c_double), ("first_audio_ms", C.c_double), ("launches_per_frame_step", C.c_int32)]
 
 
 _lib = None

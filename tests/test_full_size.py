@@ -49,6 +49,11 @@ def test_full_size_properties(full_dir, monkeypatch):
             assert x.status == 0 and x.codes.shape == (F, 16)
             assert (x.codes == y.codes).all() and (x.audio == y.audio).all()
         assert len({tuple(r.codes[:, 0]) for r in a}) > 16          # rows differ (own prompts, own RNG streams)
+        # the frame step as a chain: 28 talker layers x 5 launches, the head (+ riders), sampler, projection, the predictor's pair
+        # pass and 14 more passes of 5 layers x 5 launches + head + sampler (548 graph nodes)
+        n_launch = m.last_timing().launches_per_frame_step
+        print("launches per 1.7B frame step at batch 32:", n_launch)
+        assert 540 <= n_launch <= 556
         # prefill chunks (512 rows per launch here) go through the tall GEMM (gemm_prefill.hip): the same bits as the skinny
         # kernel's wave partials at K = 2048 and 6144, eight phases
         from qwen3tts import _lib
