@@ -123,48 +123,6 @@ def ensure_checkpoint(preset: str, rank: int, dist) -> str:
     return d
 
 
-class _DryModel:
-    """Stand-in for the engine when there is no GPU (Q3TTS_BENCH_DRY=1, tests/test_distributed_cpu.py): it decodes nothing --
-    rows come back with the requested number of frames -- so that the N > 1 CONTROL path of this file (shard, broadcast,
-    checksum, pipelined begin/end, MAX / SUM reduction, the JSON line) runs end to end under gloo on CPU. Never used on a GPU
-    box: the product path fails loudly when the HIP engine is missing."""
-
-    class _Info:
-        weight_bytes = 1 << 20
-
-    class _Res:
-        def __init__(self, frames):
-            self.codes = np.zeros((frames, 16), np.int32)
-
-    def __init__(self, rank, empty):
-        import torch
-        g = torch.Generator().manual_seed(5)
-        ref = torch.randint(0, 256, (1 << 16,), dtype=torch.uint8, generator=g)
-        self.arena_t = torch.zeros_like(ref) if empty else ref
-        self.info = self._Info()
-        self._frames = 0
-
-    def arena_checksum(self):
-        return int(self.arena_t.view(dtype=__import__("torch").int32).to(__import__("torch").int64).sum().item())
-
-    def generate_batch(self, reqs, force_frames=0, **kw):
-        self._frames = force_frames
-        time.sleep(0.01)
-        return [self._Res(force_frames) for _ in reqs]
-
-    def generate_batch_begin(self, reqs, force_frames=0, **kw):
-        return (len(reqs), force_frames)
-
-    def generate_batch_end(self, job):
-        time.sleep(0.01)
-        return [self._Res(job[1]) for _ in range(job[0])]
-
-    def last_timing(self):
-        from types import SimpleNamespace
-        return SimpleNamespace(prefill_ms=1.0, decode_ms=8.0, codec_ms=2.0, frontend_ms=0.0, frame_steps=max(self._frames, 1),
-                               kv_bytes_read=0, first_audio_ms=0.0)
-
-
 def cpu_baseline(ckpt: str, preset: str, n_text: int, n_instruct: int, frames: int) -> dict:
     """Oracle (CPU restatement, OpenMP) on a bounded sample: batch 1, same prompt shape, `frames`
     frames, greedy, end to end (prompt assembly + prefill + AR loop + codec decode)."""
@@ -237,8 +195,12 @@ def main():
     B = args.batch or (16 if clone else 64 if args.preset == "0.6b-q4" else 32)
     rep = 1.5 if clone else 1.05  # generateVoiceClone's default (Qwen3.swift:1017)
     if dry:
+        # the stand-in lives with the tests (tests/_bench_dry.py): it decodes nothing and exists so that this file's N > 1 control
+        # path can run under gloo on a machine without a GPU. Nothing on a GPU box goes near it.
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from _bench_dry import DryModel
         ckpt = None
-        model = _DryModel(rank, empty=(world > 1 and rank != 0))
+        model = DryModel(rank, empty=(world > 1 and rank != 0))
     else:
         ckpt = ensure_checkpoint(args.preset, rank, dist)
         # rank 0 reads the checkpoint; replicas receive the weight arena by one RCCL broadcast over xGMI
