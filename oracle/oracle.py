@@ -58,7 +58,8 @@ def lib():
         # large as the machine then spends its time in throttled spin-waits (a tiny forward pass took > 60 s once).
         # Sleep in barriers and cap the team unless the caller chose a size.
         os.environ.setdefault("OMP_WAIT_POLICY", "passive")
-        _lib = C.CDLL(build())
+        # tests/test_sanitizers.py points this at an ASan / UBSan build of the same source
+        _lib = C.CDLL(os.environ.get("Q3TTS_ORACLE_LIB") or build())
         if "OMP_NUM_THREADS" not in os.environ:
             try:
                 ncpu = len(os.sched_getaffinity(0))

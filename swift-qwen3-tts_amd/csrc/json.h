@@ -18,6 +18,12 @@ struct Json {
     std::vector<Json> arr;
     std::vector<std::pair<std::string, Json>> obj;  // insertion order kept
 
+    // A JSON number as an integer of the asked range; a value no such integer holds (1e30, -inf, a hostile header) is an error of
+    // the file, not a conversion the language leaves undefined (tests/test_sanitizers.py feeds such files).
+    static int64_t to_int(double v, double lo, double hi, const std::string& what) {
+        if (!(v >= lo && v <= hi)) throw Error(6, "JSON number out of range for " + what);
+        return int64_t(v);
+    }
     const Json* get(const std::string& k) const {
         if (kind != Obj) return nullptr;
         for (auto& kv : obj)
@@ -30,7 +36,7 @@ struct Json {
     }
     int64_t i64(const std::string& k, int64_t def) const {
         const Json* j = get(k);
-        return (j && j->kind == Num) ? int64_t(j->num) : def;
+        return (j && j->kind == Num) ? to_int(j->num, -9.2e18, 9.2e18, "'" + k + "'") : def;
     }
     double f64(const std::string& k, double def) const {
         const Json* j = get(k);
@@ -44,7 +50,10 @@ struct Json {
         const Json* j = get(k);
         if (!j || j->kind != Arr) return def;
         std::vector<int> out;
-        for (auto& e : j->arr) out.push_back(int(e.num));
+        for (auto& e : j->arr) {
+            if (e.kind != Num) throw Error(6, "JSON array '" + k + "' holds something that is not a number");
+            out.push_back(int(to_int(e.num, -2147483648.0, 2147483647.0, "'" + k + "'")));
+        }
         return out;
     }
 };
@@ -53,6 +62,7 @@ class JsonParser {
   public:
     JsonParser(const char* p, size_t n) : p_(p), e_(p + n) {}
     Json parse() {
+        depth_ = 0;
         Json j = value();
         ws();
         return j;
@@ -61,6 +71,12 @@ class JsonParser {
   private:
     const char* p_;
     const char* e_;
+    int depth_ = 0;  // open containers: a file of ten thousand '[' must not be able to overflow the stack
+    struct Nest {
+        int& d;
+        explicit Nest(int& depth) : d(depth) { ++d; }
+        ~Nest() { --d; }
+    };
     void ws() {
         while (p_ < e_ && (*p_ == ' ' || *p_ == '\n' || *p_ == '\t' || *p_ == '\r')) ++p_;
     }
@@ -70,6 +86,8 @@ class JsonParser {
         if (p_ >= e_) fail("unexpected end");
         char c = *p_;
         Json j;
+        Nest nest(depth_);
+        if (depth_ > 128) fail("nested too deeply");
         if (c == '{') {
             j.kind = Json::Obj;
             ++p_;

@@ -94,9 +94,11 @@ class SafetensorsDir {
         int fd = ::open(path.c_str(), O_RDONLY);
         Q3_CHECK(fd >= 0, 6, "cannot open " + path);
         struct stat st;
-        fstat(fd, &st);
+        if (fstat(fd, &st) != 0 || st.st_size < 8) {
+            ::close(fd);
+            throw Error(6, "truncated safetensors file " + path);
+        }
         size_t size = size_t(st.st_size);
-        Q3_CHECK(size >= 8, 6, "truncated safetensors file " + path);
         void* base = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
         ::close(fd);
         Q3_CHECK(base != MAP_FAILED, 6, "mmap failed for " + path);
@@ -104,7 +106,8 @@ class SafetensorsDir {
         const uint8_t* p = static_cast<const uint8_t*>(base);
         uint64_t hlen;
         std::memcpy(&hlen, p, 8);
-        Q3_CHECK(8 + hlen <= size, 6, "bad safetensors header in " + path);
+        Q3_CHECK(hlen <= size - 8, 6, "bad safetensors header in " + path);  // (not 8 + hlen <= size: that sum wraps)
+        const uint64_t data_bytes = uint64_t(size) - 8 - hlen;
         Json hdr = JsonParser(reinterpret_cast<const char*>(p + 8), size_t(hlen)).parse();
         const uint8_t* data = p + 8 + hlen;
         for (auto& kv : hdr.obj) {
@@ -112,16 +115,30 @@ class SafetensorsDir {
             TensorView tv;
             tv.dtype = parse_dtype(kv.second.s("dtype", ""));
             const Json* sh = kv.second.get("shape");
-            if (sh)
-                for (auto& e : sh->arr) tv.shape.push_back(int64_t(e.num));
+            // every number of the header is checked as a number of THIS file before it becomes an integer: a dimension or an
+            // offset beyond the file (or negative, or 1e999) is a damaged checkpoint, and the element count may not wrap
+            uint64_t numel = 1;
+            if (sh) {
+                Q3_CHECK(sh->kind == Json::Arr, 6, "bad shape for " + kv.first);
+                for (auto& e : sh->arr) {
+                    Q3_CHECK(e.kind == Json::Num, 6, "bad shape for " + kv.first);
+                    const int64_t dim = Json::to_int(e.num, 0, 1e15, "the shape of " + kv.first);
+                    Q3_CHECK(!__builtin_mul_overflow(numel, uint64_t(dim), &numel), 6, "bad shape for " + kv.first);
+                    tv.shape.push_back(dim);
+                }
+            }
             const Json* off = kv.second.get("data_offsets");
-            Q3_CHECK(off && off->arr.size() == 2, 6, "bad data_offsets for " + kv.first);
-            uint64_t a = uint64_t(off->arr[0].num), b = uint64_t(off->arr[1].num);
-            Q3_CHECK(8 + hlen + b <= size && a <= b, 6, "tensor out of file bounds: " + kv.first);
+            Q3_CHECK(off && off->kind == Json::Arr && off->arr.size() == 2 && off->arr[0].kind == Json::Num && off->arr[1].kind == Json::Num,
+                     6, "bad data_offsets for " + kv.first);
+            const uint64_t a = uint64_t(Json::to_int(off->arr[0].num, 0, 9.0e18, "data_offsets of " + kv.first));
+            const uint64_t b = uint64_t(Json::to_int(off->arr[1].num, 0, 9.0e18, "data_offsets of " + kv.first));
+            Q3_CHECK(b <= data_bytes && a <= b, 6, "tensor out of file bounds: " + kv.first);
             tv.data = data + a;
             tv.nbytes = size_t(b - a);
-            Q3_CHECK(tv.dtype == DType::Unknown || size_t(tv.numel()) * dtype_size(tv.dtype) == tv.nbytes, 6,
-                     "shape/bytes mismatch for " + kv.first);
+            uint64_t want = 0;
+            Q3_CHECK(tv.dtype == DType::Unknown ||
+                         (!__builtin_mul_overflow(numel, uint64_t(dtype_size(tv.dtype)), &want) && want == tv.nbytes),
+                     6, "shape/bytes mismatch for " + kv.first);
             t_[kv.first] = tv;
         }
     }

@@ -244,6 +244,12 @@ void BpeTokenizer::init_byte_map() {
     }
 }
 
+// a vocabulary entry's id: a non-negative integer that fits the engine's int32 token ids, or the file is damaged
+static int32_t vocab_id(const Json& v) {
+    Q3_CHECK(v.kind == Json::Num, 6, "tokenizer: a vocabulary id is not a number");
+    return int32_t(Json::to_int(v.num, 0, 2147483647.0, "a vocabulary id"));
+}
+
 void BpeTokenizer::load(const std::string& dir) {
     if (file_exists(dir + "/tokenizer.json")) {
         load_json_file(dir + "/tokenizer.json");
@@ -255,7 +261,7 @@ void BpeTokenizer::load(const std::string& dir) {
     {
         const std::string txt = read_file(dir + "/vocab.json");
         Json j = JsonParser(txt.data(), txt.size()).parse();
-        for (auto& kv : j.obj) vocab_[kv.first] = int32_t(kv.second.num);
+        for (auto& kv : j.obj) vocab_[kv.first] = vocab_id(kv.second);
     }
     {
         const std::string txt = read_file(dir + "/merges.txt");
@@ -291,7 +297,7 @@ void BpeTokenizer::load_json_file(const std::string& path) {
     const Json* merges = model->get("merges");
     Q3_CHECK(vocab && vocab->kind == Json::Obj && merges && merges->kind == Json::Arr, 6, "tokenizer.json: vocab / merges missing");
     vocab_.reserve(vocab->obj.size() * 2);
-    for (auto& kv : vocab->obj) vocab_[kv.first] = int32_t(kv.second.num);
+    for (auto& kv : vocab->obj) vocab_[kv.first] = vocab_id(kv.second);
     int rank = 0;
     for (auto& m : merges->arr) {
         if (m.kind == Json::Str) {  // "left right"
@@ -321,7 +327,8 @@ void BpeTokenizer::load_json_file(const std::string& path) {
     }
     if (const Json* at = j.get("added_tokens"); at && at->kind == Json::Arr)
         for (auto& a : at->arr) {
-            Added ad{a.s("content", ""), int32_t(a.i64("id", -1)), false};
+            const int64_t id = a.i64("id", -1);
+            Added ad{a.s("content", ""), id > 2147483647 ? -1 : int32_t(id), false};
             if (const Json* nm = a.get("normalized"); nm && nm->kind == Json::Bool) ad.normalized = nm->b;
             if (!ad.content.empty() && ad.id >= 0) added_.push_back(ad);
         }
