@@ -6,6 +6,7 @@
 #include <map>
 #include <sstream>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "json.h"
@@ -51,6 +52,10 @@ struct TalkerConfig {  // Config.swift:289-333
     int inter(int layer) const {
         return per_layer_intermediate_sizes.empty() ? intermediate_size : per_layer_intermediate_sizes[size_t(layer)];
     }
+    static int id_of(const Json& v, const char* what) {
+        Q3_CHECK(v.kind == Json::Num, 6, std::string("config.json: an entry of ") + what + " is not a number");
+        return int(Json::to_int(v.num, -2147483648.0, 2147483647.0, what));
+    }
     void parse(const Json& j) {
         vocab_size = int(j.i64("vocab_size", vocab_size));
         text_vocab_size = int(j.i64("text_vocab_size", text_vocab_size));
@@ -74,11 +79,11 @@ struct TalkerConfig {  // Config.swift:289-333
         codec_bos_id = int(j.i64("codec_bos_id", codec_bos_id));
         if (const Json* l = j.get("codec_language_id"); l && l->kind == Json::Obj) {
             codec_language_id.clear();
-            for (auto& kv : l->obj) codec_language_id[kv.first] = int(kv.second.num);
+            for (auto& kv : l->obj) codec_language_id[kv.first] = id_of(kv.second, "codec_language_id");
         }
         if (const Json* s = j.get("spk_id"); s && s->kind == Json::Obj) {
             has_spk_id = true;
-            for (auto& kv : s->obj) spk_id[kv.first] = int(kv.second.num);
+            for (auto& kv : s->obj) spk_id[kv.first] = id_of(kv.second, "spk_id");
         }
         if (const Json* s = j.get("spk_is_dialect"); s && s->kind == Json::Obj) {
             for (auto& kv : s->obj)  // DialectValue: false or a dialect name (Config.swift:17-53)
@@ -233,6 +238,124 @@ struct ModelConfig {  // Config.swift:635-657, 584-594
         if (const Json* sp = j.get("speaker_encoder_config"); sp && sp->kind == Json::Obj) {  // Qwen3.swift:55-57
             has_speaker_encoder = true;
             speaker.parse(*sp);
+        }
+    }
+    // What the engine relies on without looking again: sizes that are sizes, one intermediate size per layer, ids inside the tables
+    // they index (an id beyond the codec vocabulary would be a row gather outside the embedding table ON THE GPU). Every field of
+    // a config.json arrives through an `int(...)` of whatever number the file held; this is where a damaged or hostile file stops.
+    // The tensors' shapes are checked against these numbers afterwards (model.cc), so nothing here needs to know the kernels' tiles.
+    static void in_range(int64_t v, int64_t lo, int64_t hi, const std::string& what) {
+        Q3_CHECK(v >= lo && v <= hi, 6, "config.json: " + what + " = " + std::to_string(v) + " is outside [" + std::to_string(lo) + ", " + std::to_string(hi) + "]");
+    }
+    static void finite_pos(float v, const std::string& what) {
+        Q3_CHECK(v > 0.0f && v < 3.0e38f, 6, "config.json: " + what + " must be a positive finite number");
+    }
+    void validate() const {
+        if (has_talker) {
+            const TalkerConfig& t = talker;
+            in_range(t.hidden_size, 16, 1 << 16, "talker hidden_size");
+            in_range(t.text_hidden_size, 16, 1 << 16, "talker text_hidden_size");
+            in_range(t.intermediate_size, 16, 1 << 20, "talker intermediate_size");
+            in_range(t.num_hidden_layers, 1, 1024, "talker num_hidden_layers");
+            in_range(t.num_attention_heads, 1, 1024, "talker num_attention_heads");
+            in_range(t.num_key_value_heads, 1, t.num_attention_heads, "talker num_key_value_heads");
+            Q3_CHECK(t.num_attention_heads % t.num_key_value_heads == 0, 6, "config.json: talker attention heads are not a multiple of the kv heads");
+            in_range(t.vocab_size, 16, 1 << 24, "talker vocab_size");
+            in_range(t.text_vocab_size, 1, 1 << 24, "talker text_vocab_size");
+            in_range(t.num_code_groups, 2, 64, "talker num_code_groups");
+            Q3_CHECK(t.per_layer_intermediate_sizes.empty() || int64_t(t.per_layer_intermediate_sizes.size()) == t.num_hidden_layers, 6,
+                     "config.json: per_layer_intermediate_sizes must name every layer");
+            for (int v : t.per_layer_intermediate_sizes) in_range(v, 16, 1 << 20, "a per-layer intermediate size");
+            finite_pos(t.rms_norm_eps, "talker rms_norm_eps");
+            finite_pos(t.rope_theta, "talker rope_theta");
+            for (auto [v, name] : {std::pair<int, const char*>{t.codec_eos_token_id, "codec_eos_token_id"}, {t.codec_think_id, "codec_think_id"},
+                                   {t.codec_nothink_id, "codec_nothink_id"}, {t.codec_think_bos_id, "codec_think_bos_id"},
+                                   {t.codec_think_eos_id, "codec_think_eos_id"}, {t.codec_pad_id, "codec_pad_id"}, {t.codec_bos_id, "codec_bos_id"}})
+                in_range(v, 0, t.vocab_size - 1, name);
+            for (auto& kv : t.codec_language_id) in_range(kv.second, 0, t.vocab_size - 1, "codec_language_id." + kv.first);
+            for (auto& kv : t.spk_id) in_range(kv.second, 0, t.vocab_size - 1, "spk_id." + kv.first);
+            for (auto [v, name] : {std::pair<int, const char*>{tts_pad_token_id, "tts_pad_token_id"}, {tts_bos_token_id, "tts_bos_token_id"},
+                                   {tts_eos_token_id, "tts_eos_token_id"}})
+                in_range(v, 0, t.text_vocab_size - 1, name);
+            if (t.has_code_predictor) {
+                const CodePredictorConfig& c = t.cp;
+                in_range(c.hidden_size, 16, 1 << 16, "code predictor hidden_size");
+                in_range(c.intermediate_size, 16, 1 << 20, "code predictor intermediate_size");
+                in_range(c.num_hidden_layers, 1, 1024, "code predictor num_hidden_layers");
+                in_range(c.num_attention_heads, 1, 1024, "code predictor num_attention_heads");
+                in_range(c.num_key_value_heads, 1, c.num_attention_heads, "code predictor num_key_value_heads");
+                Q3_CHECK(c.num_attention_heads % c.num_key_value_heads == 0, 6, "config.json: code predictor attention heads are not a multiple of the kv heads");
+                in_range(c.vocab_size, 16, 1 << 24, "code predictor vocab_size");
+                finite_pos(c.rms_norm_eps, "code predictor rms_norm_eps");
+                finite_pos(c.rope_theta, "code predictor rope_theta");
+            }
+        }
+        in_range(sample_rate, 1, 1 << 20, "sample_rate");
+        if (has_quantization) {
+            in_range(quant_bits, 1, 8, "quantization.bits");
+            in_range(quant_group_size, 1, 1 << 16, "quantization.group_size");
+        }
+        if (has_speaker_encoder) {
+            const SpeakerEncoderConfig& s = speaker;
+            in_range(s.mel_dim, 1, 4096, "speaker encoder mel_dim");
+            in_range(s.enc_dim, 1, 1 << 16, "speaker encoder enc_dim");
+            in_range(s.enc_attention_channels, 1, 1 << 16, "speaker encoder enc_attention_channels");
+            in_range(s.enc_res2net_scale, 1, 64, "speaker encoder enc_res2net_scale");
+            in_range(s.enc_se_channels, 1, 1 << 16, "speaker encoder enc_se_channels");
+            in_range(s.sample_rate, 1, 1 << 20, "speaker encoder sample_rate");
+            in_range(int64_t(s.enc_channels.size()), 1, 16, "speaker encoder enc_channels (count)");
+            for (int v : s.enc_channels) in_range(v, 1, 1 << 16, "a speaker encoder channel count");
+            for (int v : s.enc_kernel_sizes) in_range(v, 1, 64, "a speaker encoder kernel size");
+            for (int v : s.enc_dilations) in_range(v, 1, 64, "a speaker encoder dilation");
+        }
+        if (has_codec) {
+            const CodecDecoderConfig& d = codec;
+            in_range(decode_upsample_rate, 1, 1 << 20, "decode_upsample_rate");
+            in_range(d.latent_dim, 1, 1 << 16, "codec latent_dim");
+            in_range(d.codebook_dim, 2, 1 << 16, "codec codebook_dim");
+            in_range(d.codebook_size, 1, 1 << 24, "codec codebook_size");
+            in_range(d.semantic_codebook_size, 1, 1 << 24, "codec semantic_codebook_size");
+            in_range(d.decoder_dim, 1, 1 << 16, "codec decoder_dim");
+            in_range(d.hidden_size, 1, 1 << 16, "codec hidden_size");
+            in_range(d.intermediate_size, 1, 1 << 20, "codec intermediate_size");
+            in_range(d.num_hidden_layers, 0, 1024, "codec num_hidden_layers");
+            in_range(d.num_attention_heads, 1, 1024, "codec num_attention_heads");
+            in_range(d.num_quantizers, 1, 256, "codec num_quantizers");
+            in_range(d.num_semantic_quantizers, 0, d.num_quantizers, "codec num_semantic_quantizers");
+            finite_pos(d.rms_norm_eps, "codec rms_norm_eps");
+            in_range(int64_t(d.upsample_rates.size()), 1, 16, "codec upsample_rates (count)");
+            in_range(int64_t(d.upsampling_ratios.size()), 0, 16, "codec upsampling_ratios (count)");
+            int64_t total = 1;
+            for (int v : d.upsample_rates) { in_range(v, 1, 64, "a codec upsample rate"); total *= v; }
+            for (int v : d.upsampling_ratios) { in_range(v, 1, 64, "a codec upsampling ratio"); total *= v; }
+            in_range(total, 1, 1 << 20, "the codec's total upsampling");
+        }
+        if (has_codec_encoder) {
+            const CodecEncoderConfig& e = codec_enc;
+            Q3_CHECK(e.frame_rate >= 0.01f && e.frame_rate <= 1.0e6f, 6, "config.json: codec encoder frame_rate is outside [0.01, 1e6]");
+            finite_pos(e.rope_theta, "codec encoder rope_theta");
+            in_range(e.codebook_dim, 1, 1 << 16, "codec encoder codebook_dim");
+            in_range(e.codebook_size, 1, 1 << 24, "codec encoder codebook_size");
+            in_range(e.hidden_size, 1, 1 << 16, "codec encoder hidden_size");
+            in_range(e.intermediate_size, 1, 1 << 20, "codec encoder intermediate_size");
+            in_range(e.kernel_size, 1, 64, "codec encoder kernel_size");
+            in_range(e.last_kernel_size, 1, 64, "codec encoder last_kernel_size");
+            in_range(e.residual_kernel_size, 1, 64, "codec encoder residual_kernel_size");
+            in_range(e.compress, 1, 64, "codec encoder compress");
+            in_range(e.dilation_growth_rate, 1, 64, "codec encoder dilation_growth_rate");
+            in_range(e.num_filters, 1, 1 << 16, "codec encoder num_filters");
+            in_range(e.num_hidden_layers, 0, 1024, "codec encoder num_hidden_layers");
+            in_range(e.num_attention_heads, 1, 1024, "codec encoder num_attention_heads");
+            in_range(e.num_key_value_heads, 1, 1024, "codec encoder num_key_value_heads");
+            in_range(e.num_quantizers, 1, 256, "codec encoder num_quantizers");
+            in_range(e.num_residual_layers, 0, 64, "codec encoder num_residual_layers");
+            in_range(e.sampling_rate, 1, 1 << 20, "codec encoder sampling_rate");
+            in_range(e.max_position_embeddings, 1, 1 << 24, "codec encoder max_position_embeddings");
+            in_range(int64_t(e.upsampling_ratios.size()), 1, 16, "codec encoder upsampling_ratios (count)");
+            int64_t hop = 1;
+            for (int v : e.upsampling_ratios) { in_range(v, 1, 64, "a codec encoder ratio"); hop *= v; }
+            in_range(hop, 1, 1 << 20, "the codec encoder's hop");
+            in_range(e.downsample_stride(), 1, 1 << 16, "the codec encoder's downsample stride");
         }
     }
     void parse_speech_tokenizer(const Json& j) {

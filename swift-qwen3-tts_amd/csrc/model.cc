@@ -1188,6 +1188,7 @@ std::unique_ptr<Model> load_model(const std::string& dir, const LoadOptions& opt
         m->cfg.parse(j);
     }
     Q3_CHECK(m->cfg.has_talker, 1, "Talker config is required");  // fatalError at Qwen3.swift:48-50
+    m->cfg.validate();
     if (m->cfg.has_quantization)  // MLX affine quantisation as shipped with the "lite" checkpoints (docs/paper.tex:232,239)
         Q3_CHECK(m->cfg.quant_bits == 4 && m->cfg.quant_group_size == 64, 6, "only 4-bit, group-size-64 quantisation is supported");
     SafetensorsDir main;
@@ -1201,6 +1202,7 @@ std::unique_ptr<Model> load_model(const std::string& dir, const LoadOptions& opt
         Json j = JsonParser(txt.data(), txt.size()).parse();
         m->cfg.parse_speech_tokenizer(j);
         Q3_CHECK(m->cfg.has_codec, 1, "Decoder config is required");  // fatalError at SpeechTokenizer.swift:804
+        m->cfg.validate();
         st.open_dir(st_dir);
         codec_t = sanitize_speech_tokenizer(st, !opt.skip_tensor_data);
     }

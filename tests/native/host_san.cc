@@ -7,6 +7,7 @@
 //   host_san jsonfuzz <file.json> <seed> <n>           n seeded manglings of the file through JsonParser; prints "ok A rejected B"
 //   host_san stfuzz <file.safetensors> <tmpdir> <seed> <n>   the same for the header of one safetensors file through SafetensorsDir
 //   host_san tokfuzz <tokenizer.json> <tmpdir> <seed> <n>    the same for a tokenizer.json through BpeTokenizer::load_json_file + encode
+//   host_san cfgfuzz <config.json> <speech_tokenizer/config.json> <seed> <n>   manglings through ModelConfig::parse + validate + use
 //   host_san textfuzz <tokenizer.json> <seed> <n>            n byte strings that are not (or are unusual) UTF-8 through encode
 #include <cstdio>
 #include <cstdlib>
@@ -16,6 +17,7 @@
 #include <string>
 #include <vector>
 
+#include "config.h"
 #include "json.h"
 #include "safetensors.h"
 #include "tokenizer.h"
@@ -210,6 +212,37 @@ int cmd_textfuzz(int argc, char** argv) {
     return 0;
 }
 
+// config.json / speech_tokenizer/config.json through ModelConfig: parse, validate, then use it the way the loader does
+int cmd_cfgfuzz(int argc, char** argv) {
+    if (argc < 6) return 2;
+    std::string main_good = slurp(argv[2]), st_good = slurp(argv[3]);
+    Rng r{uint64_t(std::strtoull(argv[4], nullptr, 10))};
+    int n = std::atoi(argv[5]), ok = 0, rejected = 0;
+    for (int i = -1; i < n; ++i) {
+        std::string a = (i < 0 || i % 2) ? main_good : mangle(main_good, r);
+        std::string b = (i < 0 || !(i % 2)) ? st_good : mangle(st_good, r);
+        try {
+            q3::ModelConfig c;
+            c.parse(q3::JsonParser(a.data(), a.size()).parse());
+            c.parse_speech_tokenizer(q3::JsonParser(b.data(), b.size()).parse());
+            c.validate();
+            // the loader's own arithmetic on the validated numbers: indices, products, the float division of the encoder rate
+            int64_t sum = 0;
+            if (c.has_talker)
+                for (int l = 0; l < c.talker.num_hidden_layers; ++l) sum += c.talker.inter(l);
+            if (c.has_codec) sum += c.codec.total_upsample();
+            if (c.has_codec_encoder) sum += c.codec_enc.hop() + c.codec_enc.downsample_stride();
+            if (sum < 0) return 3;
+            ++ok;
+        } catch (const q3::Error&) {
+            if (i < 0) return 3;  // the unmangled pair is a valid configuration
+            ++rejected;
+        }
+    }
+    std::printf("ok %d rejected %d\n", ok - 1, rejected);
+    return 0;
+}
+
 int cmd_stfuzz(int argc, char** argv) {
     if (argc < 6) return 2;
     std::string good = slurp(argv[2]);
@@ -270,6 +303,7 @@ int main(int argc, char** argv) {
         if (mode == "jsonfuzz") return cmd_jsonfuzz(argc, argv);
         if (mode == "stfuzz") return cmd_stfuzz(argc, argv);
         if (mode == "tokfuzz") return cmd_tokfuzz(argc, argv);
+        if (mode == "cfgfuzz") return cmd_cfgfuzz(argc, argv);
         if (mode == "textfuzz") return cmd_textfuzz(argc, argv);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "uncaught: %s\n", e.what());

@@ -66,3 +66,33 @@ def test_product_never_references_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle|oracle/_build|libq3tts_oracle", txt, flags=re.M):
                     bad.append(os.path.join(dp, f))
     assert not bad, f"product files reference the oracle: {bad}"
+
+
+def test_ctypes_mirror_has_the_headers_layout(tmp_path):
+    """Every struct of include/q3tts.h against its ctypes mirror (qwen3tts/_lib.py): size and the offset of every field, as a C
+    compiler lays the header out (which also shows that the header is plain C). A field appended on one side only -- the way
+    q3tts_timing grew in round 4 -- fails here and not as a garbled read on the GPU box."""
+    import subprocess
+    from qwen3tts import _lib
+    pairs = [("q3tts_load_opts", _lib.LoadOpts), ("q3tts_comm_id", _lib.CommId), ("q3tts_model_info", _lib.ModelInfo),
+             ("q3tts_request", _lib.Request), ("q3tts_sampling", _lib.Sampling), ("q3tts_gen_info", _lib.GenInfo),
+             ("q3tts_event", _lib.Event), ("q3tts_result", _lib.Result), ("q3tts_timing", _lib.Timing)]
+    lines = ['#include <stddef.h>', '#include <stdio.h>', '#include "q3tts.h"', 'int main(void) {']
+    for cname, cls in pairs:
+        lines.append('  printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, *_ in cls._fields_:
+            lines.append('  printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    c_layout = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, cls in pairs:
+        assert int(c_layout[cname]) == ctypes.sizeof(cls), cname
+        for fname, *_ in cls._fields_:
+            assert int(c_layout["%s.%s" % (cname, fname)]) == getattr(cls, fname).offset, "%s.%s" % (cname, fname)
+    # and no C field is missing from a mirror: the last mirrored field ends where the struct does (up to tail padding)
+    for cname, cls in pairs:
+        fname, ftype = cls._fields_[-1][0], cls._fields_[-1][1]
+        assert getattr(cls, fname).offset + ctypes.sizeof(ftype) > ctypes.sizeof(cls) - 8, cname

@@ -40,7 +40,7 @@ pytestmark = pytest.mark.skipif(not _have_sanitizers(), reason="gcc / g++ with l
 def host_san():
     out = os.path.join(NATIVE, "_build", "host_san")
     srcs = [os.path.join(NATIVE, "host_san.cc"), os.path.join(ROOT, "swift-qwen3-tts_amd", "csrc", "tokenizer.cc")]
-    deps = srcs + [os.path.join(ROOT, "swift-qwen3-tts_amd", "csrc", h) for h in ("json.h", "safetensors.h", "tokenizer.h", "common.h")]
+    deps = srcs + [os.path.join(ROOT, "swift-qwen3-tts_amd", "csrc", h) for h in ("json.h", "safetensors.h", "tokenizer.h", "common.h", "config.h")]
     if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
         os.makedirs(os.path.dirname(out), exist_ok=True)
         # common.h includes the HIP runtime header for the error macro; with g++ that needs the platform define and nothing else
@@ -80,6 +80,15 @@ def test_committed_tokenizer_cases_under_sanitizers(host_san, tmp_path):
 def test_mangled_config_json_is_parsed_or_rejected(host_san, ckpt_dirs):
     ok, rejected = _counts(_run([host_san, "jsonfuzz", os.path.join(ckpt_dirs["tiny-a"], "config.json"), "1", "4000"]))
     assert ok + rejected == 4000 and ok > 100 and rejected > 1000   # both outcomes are exercised
+
+
+def test_mangled_model_configs_validate_or_are_rejected(host_san, ckpt_dirs):
+    """ModelConfig::validate (csrc/config.h) is where a damaged config.json stops: after it, every size is a size, there is one
+    intermediate size per layer and every special id lies inside the table it indexes -- the loader and the engine index with
+    these numbers without looking again (an id beyond the codec vocabulary would be a gather outside a table on the GPU)."""
+    d = ckpt_dirs["tiny-a"]
+    ok, rejected = _counts(_run([host_san, "cfgfuzz", os.path.join(d, "config.json"), os.path.join(d, "speech_tokenizer", "config.json"), "11", "4000"]))
+    assert ok + rejected == 4000 and ok > 100 and rejected > 1000
 
 
 def test_mangled_safetensors_headers_are_opened_or_rejected(host_san, tmp_path):
