@@ -220,14 +220,19 @@ def main():
         want_native = ((how == "native" and backend == "nccl") or how == "native-force") and not dry
         ok = 0
         if want_native:
+            # Pre-flight on EVERY rank before anything collective: a rank whose process cannot open RCCL must say so here -- once the
+            # others are inside ncclCommInitRank they wait for it for ever. (ncclGetUniqueId is local; rank 0's id is the one used.)
             ids = [None]
-            if rank == 0:
-                try:
-                    ids[0] = Qwen3TTSModel.comm_unique_id()
-                except Exception as e:  # RCCL missing: every rank takes the torch path
-                    print(f"[bench] native broadcast unavailable: {e}", file=sys.stderr)
-            dist.broadcast_object_list(ids, src=0)
-            if ids[0] is not None:
+            avail = 1
+            try:
+                ids[0] = Qwen3TTSModel.comm_unique_id()
+            except Exception as e:
+                avail = 0
+                print(f"[bench] rank {rank}: native broadcast unavailable: {e}", file=sys.stderr)
+            every = torch.tensor([avail], device=dev, dtype=torch.int32)
+            dist.all_reduce(every, op=dist.ReduceOp.MIN)
+            if int(every.item()):
+                dist.broadcast_object_list(ids, src=0)
                 try:
                     model.broadcast_weights(ids[0], rank, world, 0)
                     ok = 1

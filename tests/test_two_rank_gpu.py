@@ -92,3 +92,29 @@ def test_native_broadcast_on_a_single_rank_communicator(ckpt_dirs):
     finally:
         m.close()
         e.close()
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_device_agree_to_fall_back_from_the_native_broadcast(tmp_path):
+    """bench.py itself, launched the way the driver launches it for N > 1 (torch.distributed.run, one process per rank), on the one
+    card this pool offers: both ranks share device 0 over gloo and ask for the library's own RCCL broadcast. RCCL must refuse a
+    communicator with two ranks on one GPU; what this run pins ON HARDWARE is everything around that refusal -- the pre-flight
+    (every rank can open RCCL), the 128-byte id travelling through torch, the every-rank agreement that the native path failed,
+    the torch fallback over the zero-copy arena view, the checksum agreement, the sharded rows, the MAX / SUM reduction and ONE
+    JSON line from rank 0. (The RCCL broadcast proper is covered on a one-rank communicator above; > 1 GPU is the driver's.)"""
+    import json
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, Q3TTS_BENCH_ONE_DEVICE="1", Q3TTS_BENCH_BACKEND="gloo", Q3TTS_BENCH_BROADCAST="native-force",
+               Q3TTS_BENCH_CKPT=str(tmp_path / "ckpt"), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--preset", "0.6b", "--batch", "4", "--frames", "8", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["weight_broadcast"].startswith("torch.distributed (gloo)")     # the agreed fallback
+    assert "native broadcast failed" in r.stderr                                       # ... after RCCL refused on both ranks
+    assert abs(d["value"] * d["ms_per_step"] / 1e3 - 2 * 4 * 8) < 1e-6 * 64            # both ranks' frames are in the aggregate
