@@ -149,7 +149,7 @@ void CodecRunner::run_front(const Pass& ps, const int32_t* codes, int code_strid
     int T = Fmax, ppf = 1;
     // 1-2. Split-RVQ dequantisation (SpeechTokenizer.swift:214-226)
     launch_rvq_gather(codes, code_stride_frames, w.cb_first, w.cb_rest_dev, int(w.cb_rest.size()), w.inner, fr, Fmax, nb,
-                      bufs[0], st_);
+                      bufs[0], w.cb_first_rows, w.cb_rest_rows, st_);
     conv(ps, w.rvq_out, bufs[0], T, ppf, bufs[1], nullptr, nullptr, 0);
     capture(ps, "quantizer", bufs[1], T, w.rvq_out.N);
     // 3. pre_conv (:759)

@@ -122,7 +122,7 @@ void launch_resunit(const ResUnitArgs& a, hipStream_t st);
 // Split-RVQ gather (SpeechTokenizer.swift:214-226, 81-96): out[b][f] = [cb_first[c0] | sum_j cb_rest[j][c_{j+1}]]
 void launch_rvq_gather(const int32_t* codes, int code_stride_frames, const float* cb_first,
                        const float* const* cb_rest, int n_rest, int inner, const int32_t* frames, int Fmax, int B,
-                       float* out, hipStream_t st);
+                       float* out, int rows_first, int rows_rest, hipStream_t st);  // rows: a code is clamped into its table
 // fp32 RMSNorm over the last dim (SpeechTokenizer.swift:581-582,626): out = (x*rstd)*w
 void launch_rmsnorm_f32(const float* x, const float* w, float eps, int C, const int32_t* frames, int ppf, int Tmax,
                         int B, float* out, hipStream_t st);

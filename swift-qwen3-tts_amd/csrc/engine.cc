@@ -1148,6 +1148,11 @@ int Engine::begin(const q3tts_request* reqs, int n, const q3tts_sampling& sp, q3
         tl_dump_ = cl_dump_ = nullptr;
         const size_t nf = size_t(n) * dbg->frames;
         if (dbg->forced_codes) {
+            // teacher-forced codes are fed back as rows of the codec / predictor embedding tables
+            for (size_t i = 0; i < nf * 16; ++i) {
+                const int32_t c = dbg->forced_codes[i];
+                Q3_CHECK(c >= 0 && c < ((i & 15) == 0 ? V : Vc), 3, "Invalid input: forced code outside its vocabulary");
+            }
             Q3_HIP(hipMalloc(reinterpret_cast<void**>(&forced_dev_), nf * 16 * 4));
             Q3_HIP(hipMemcpy(forced_dev_, dbg->forced_codes, nf * 16 * 4, hipMemcpyHostToDevice));
         }
@@ -1842,14 +1847,24 @@ void Engine::debug_linear(const uint16_t* x, const uint16_t* W, const uint16_t* 
         if (p) (void)hipFree(p);
 }
 
+// Codes a CALLER hands in (q3tts_codec_decode, q3tts_codec_decode_streamed) index the RVQ tables on the GPU: every code of every frame
+// that will be decoded is checked against the tables as loaded. (Codes the engine sampled itself are inside by construction:
+// the samplers draw below the vocabulary, the tables have at least that many rows.)
+static void check_caller_codes(const CodecW& w, const int32_t* codes, const int32_t* n_frames, int batch, int max_frames) {
+    for (int b = 0; b < batch; ++b)
+        for (int f = 0; f < n_frames[b]; ++f) {
+            const int32_t* c = codes + (size_t(b) * max_frames + f) * 16;
+            Q3_CHECK(c[0] >= 0 && c[0] < w.cb_first_rows, 3, "Invalid input: first code outside the semantic codebook");
+            for (size_t j = 0; j < w.cb_rest.size(); ++j)
+                Q3_CHECK(c[1 + j] >= 0 && c[1 + j] < w.cb_rest_rows, 3, "Invalid input: code outside the acoustic codebook");
+        }
+}
+
 void Engine::codec_decode(const int32_t* codes, const int32_t* n_frames, int batch, int max_frames, float* pcm,
                           int64_t* audio_lengths) {
     Q3_CHECK(m_->has_codec, 1, "Model not initialized: Speech tokenizer not loaded");
     Q3_CHECK(batch >= 1 && max_frames >= 1, 3, "Invalid input: empty codec batch");
     const int up = codec_->upsample();
-    int32_t* dcodes = nullptr;
-    Q3_HIP(hipMalloc(reinterpret_cast<void**>(&dcodes), size_t(batch) * max_frames * 16 * 4));
-    Q3_HIP(hipMemcpy(dcodes, codes, size_t(batch) * max_frames * 16 * 4, hipMemcpyHostToDevice));
     std::vector<int> frames((size_t)(batch));
     int Fmax = 0;
     for (int b = 0; b < batch; ++b) {
@@ -1857,6 +1872,10 @@ void Engine::codec_decode(const int32_t* codes, const int32_t* n_frames, int bat
         frames[size_t(b)] = n_frames[b];
         Fmax = std::max(Fmax, n_frames[b]);
     }
+    check_caller_codes(m_->codec, codes, n_frames, batch, max_frames);
+    int32_t* dcodes = nullptr;
+    Q3_HIP(hipMalloc(reinterpret_cast<void**>(&dcodes), size_t(batch) * max_frames * 16 * 4));
+    Q3_HIP(hipMemcpy(dcodes, codes, size_t(batch) * max_frames * 16 * 4, hipMemcpyHostToDevice));
     float* pcm_dev = nullptr;
     hipStream_t cst = codec_stream(false);
     int32_t* nf = nullptr;  // pinned: rows whose waveform came out non-finite
@@ -1938,6 +1957,7 @@ void Engine::codec_decode_streamed(const int32_t* codes, const int32_t* n_frames
             avail[size_t(b)] = n_frames[b];
             Fmax = std::max(Fmax, n_frames[b]);
         }
+        check_caller_codes(m_->codec, codes, n_frames, batch, max_frames);
         hipStream_t cst = codec_stream(false);
         CodecRunner::StreamCfg cfg;
         cfg.rows = batch; cfg.chunk_frames = chunk_frames; cfg.window = window; cfg.lookahead = lookahead; cfg.max_frames = std::max(Fmax, 1);

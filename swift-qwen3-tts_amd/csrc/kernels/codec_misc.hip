@@ -22,15 +22,19 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {
 // one workgroup per (frame, row)
 __global__ __launch_bounds__(256) void rvq_gather_kernel(const int32_t* codes, int code_stride_frames,
                                                          const float* cb_first, const float* const* cb_rest, int n_rest,
-                                                         int inner, const int32_t* frames, int Fmax, float* out) {
+                                                         int inner, const int32_t* frames, int Fmax, float* out,
+                                                         int rows_first, int rows_rest) {
     const int f = blockIdx.x, b = blockIdx.y;
     if (f >= frames[b]) return;
     const int32_t* c = codes + ((size_t)b * code_stride_frames + f) * 16;
     float* o = out + ((size_t)b * Fmax + f) * 2 * inner;
+    // a code is a row index: kept inside the table whatever produced it (caller codes are rejected on the host before they get
+    // here, Engine::check_caller_codes; sampled codes are inside by construction -- the clamp is the seat belt, not the rule)
+    auto row = [](int32_t code, int rows) { return (size_t)(code < 0 ? 0 : (code < rows ? code : rows - 1)); };
     for (int i = threadIdx.x; i < inner; i += 256) {
-        o[i] = cb_first[(size_t)c[0] * inner + i];
-        float q = cb_rest[0][(size_t)c[1] * inner + i];  // layers summed in index order (:84-93)
-        for (int j = 1; j < n_rest; ++j) q = q + cb_rest[j][(size_t)c[1 + j] * inner + i];
+        o[i] = cb_first[row(c[0], rows_first) * inner + i];
+        float q = cb_rest[0][row(c[1], rows_rest) * inner + i];  // layers summed in index order (:84-93)
+        for (int j = 1; j < n_rest; ++j) q = q + cb_rest[j][row(c[1 + j], rows_rest) * inner + i];
         o[inner + i] = q;
     }
 }
@@ -244,9 +248,11 @@ void launch_roll_history(float* cur, int64_t bstride, int64_t keep_floats, int64
 }
 
 void launch_rvq_gather(const int32_t* codes, int code_stride_frames, const float* cb_first, const float* const* cb_rest,
-                       int n_rest, int inner, const int32_t* frames, int Fmax, int B, float* out, hipStream_t st) {
+                       int n_rest, int inner, const int32_t* frames, int Fmax, int B, float* out, int rows_first, int rows_rest,
+                       hipStream_t st) {
+    Q3_CHECK(rows_first >= 1 && rows_rest >= 1 && n_rest >= 1 && n_rest <= 15, 3, "rvq_gather: empty codebook");
     hipLaunchKernelGGL(rvq_gather_kernel, dim3(Fmax, B), dim3(256), 0, st, codes, code_stride_frames, cb_first, cb_rest,
-                       n_rest, inner, frames, Fmax, out);
+                       n_rest, inner, frames, Fmax, out, rows_first, rows_rest);
 }
 void launch_rmsnorm_f32(const float* x, const float* w, float eps, int C, const int32_t* frames, int ppf, int Tmax, int B,
                         float* out, hipStream_t st) {

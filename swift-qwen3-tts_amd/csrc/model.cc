@@ -4,6 +4,7 @@
 
 #include "kernels.h"
 
+#include <climits>
 #include <cmath>
 #include <functional>
 #include <map>
@@ -779,13 +780,23 @@ SnakeW put_snake(Builder& b, const TMap& t, const std::string& name) {
 void build_codec(Builder& b, const TMap& t, const CodecDecoderConfig& dc, CodecW& c) {
     const std::string q = "decoder.quantizer.";
     const HostTensor& cb0 = need(t, q + "rvq_first.vq.layers.0.codebook.embed.weight");
+    Q3_CHECK(cb0.shape.size() == 2 && cb0.shape[0] >= 1 && cb0.shape[1] >= 1, 6, "unexpected semantic codebook shape");
     c.inner = int(cb0.shape[1]);
+    c.cb_first_rows = int(cb0.shape[0]);
     Q3_CHECK(dc.num_semantic_quantizers == 1, 6, "only one semantic quantizer is supported");
     c.cb_first = b.put_f32(cb0);
     const int nrest = dc.num_quantizers - dc.num_semantic_quantizers;
+    // a frame is 16 codes everywhere (engine, kernels, the ABI's codes[F][16]): one semantic + at most 15 acoustic tables
+    Q3_CHECK(nrest >= 1 && nrest <= 15, 6, "the speech tokenizer must have 2..16 quantizers");
     c.cb_rest.resize(size_t(nrest));
-    for (int i = 0; i < nrest; ++i)
-        c.cb_rest[size_t(i)] = b.put_f32(need(t, q + "rvq_rest.vq.layers." + std::to_string(i) + ".codebook.embed.weight"));
+    c.cb_rest_rows = INT_MAX;
+    for (int i = 0; i < nrest; ++i) {
+        const HostTensor& cb = need(t, q + "rvq_rest.vq.layers." + std::to_string(i) + ".codebook.embed.weight");
+        // the gather indexes every table with the semantic table's row length
+        Q3_CHECK(cb.shape.size() == 2 && cb.shape[0] >= 1 && cb.shape[1] == c.inner, 6, "unexpected acoustic codebook shape");
+        c.cb_rest_rows = std::min(c.cb_rest_rows, int(cb.shape[0]));
+        c.cb_rest[size_t(i)] = b.put_f32(cb);
+    }
     c.cb_rest_dev = b.put_side<const float*>(c.cb_rest.data(), c.cb_rest.size());
     {  // fused output projection: [cd][1][inner] x2 -> [cd][1][2*inner]
         const HostTensor& w1 = need(t, q + "rvq_first.output_proj.weight");

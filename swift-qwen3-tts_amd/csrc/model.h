@@ -73,6 +73,7 @@ struct CodecW {
     std::vector<const float*> cb_rest;             // 15 x [codebook_size][inner]
     const float* const* cb_rest_dev = nullptr;     // device array of the pointers above
     int inner = 0;
+    int cb_first_rows = 0, cb_rest_rows = 0;       // rows of the tables as loaded (the smallest of the 15): what a code may index
     ConvW rvq_out;   // [codebook_dim][1][2*inner]  (semantic | acoustic)
     ConvW pre_conv;
     ConvW t_in, t_out;

@@ -447,3 +447,33 @@ def test_long_sequence_crosses_kv_pages(engines, oracles):
     assert (np.abs(a - b) <= tol).all(), (int(np.argmax((np.abs(a - b) > tol).any(-1))), float(np.abs(a - b).max()))
     a, b = bf16_to_f32(cl[0]), bf16_to_f32(np.stack(tr.cp_logits))
     assert (np.abs(a - b) <= 2 * ULP * np.abs(b).max(axis=-1, keepdims=True)).all()
+
+
+@pytest.mark.gpu
+def test_caller_codes_outside_the_codebooks_are_rejected_on_the_host(engines, ckpt_dirs):
+    """q3tts_codec_decode / q3tts_codec_decode_streamed take codes from the caller, and a code is a row index into the RVQ tables on
+    the GPU: a code outside its table is an 'Invalid input' on the host, before anything is uploaded -- never an out-of-bounds
+    gather. Frames behind a row's n_frames are not looked at (they are never decoded). The decoder still works afterwards."""
+    import json
+    from qwen3tts import Qwen3TTSError
+    m = engines["tiny-a"]
+    dc = json.load(open(os.path.join(ckpt_dirs["tiny-a"], "speech_tokenizer", "config.json")))["decoder_config"]
+    n_first, n_rest = int(dc.get("semantic_codebook_size", 4096)), int(dc.get("codebook_size", 2048))
+    rng = np.random.default_rng(3)
+    good = np.stack([rng.integers(1, n_first, (2, 6)), *[rng.integers(0, n_rest, (2, 6)) for _ in range(15)]], axis=-1).astype(np.int32)
+    want, _ = m.codec_decode(good)
+    for group, value, what in ((0, n_first, "semantic"), (0, -1, "semantic"), (5, n_rest, "acoustic"), (15, -7, "acoustic"),
+                               (1, 2 ** 31 - 1, "acoustic")):
+        bad = good.copy()
+        bad[1, 3, group] = value
+        with pytest.raises(Qwen3TTSError) as e:
+            m.codec_decode(bad)
+        assert e.value.status == 3 and what in str(e.value)
+        with pytest.raises(Qwen3TTSError) as e:
+            m.codec_decode_streamed(bad, 2, 4)
+        assert e.value.status == 3 and what in str(e.value)
+        # the same frame behind the row's length is padding
+        got, _ = m.codec_decode(bad, n_frames=[6, 3])
+        assert (got[0] == want[0]).all()
+    again, _ = m.codec_decode(good)
+    assert (again == want).all()
