@@ -683,6 +683,11 @@ ResolvedRequest Engine::resolve(const q3tts_request& r, const q3tts_sampling& sp
                  "Model not initialized: Voice cloning (ICL mode) requires the speech tokenizer encoder. Make sure to load a model "
                  "with encoder weights.");  // :1033-1038
         Q3_CHECK(r.n_ref_samples > 0, 3, "Invalid input: reference audio is empty");
+        {   // a NaN sample would spread through the encoders into every logit of the row
+            bool finite = true;
+            for (int64_t i = 0; i < int64_t(r.n_ref_samples); ++i) finite = finite && (std::fabs(r.ref_audio[i]) <= 3.0e38f);
+            Q3_CHECK(finite, 3, "Invalid input: reference audio holds non-finite samples");
+        }
         Q3_CHECK(r.ref_text_ids && r.n_ref_text_ids >= 5, 3, "Invalid input: ref_text_ids must hold the chat-template tokens");
         Q3_CHECK(r.n_text_ids >= 8, 3, "Invalid input: text_ids must hold the chat-template tokens");
         Q3_CHECK(m_->codec_enc.bins <= t.vocab_size && m_->codec_enc.bins <= t.cp.vocab_size, 3,
@@ -698,7 +703,7 @@ ResolvedRequest Engine::resolve(const q3tts_request& r, const q3tts_sampling& sp
         }
         o.target_token_count = r.target_token_count;
         const int mt = r.max_tokens > 0 ? r.max_tokens : 2048;
-        o.max_frames = sp.force_frames > 0 ? sp.force_frames : std::min(mt, std::max(75, r.target_token_count * 6));  // :1051-1052
+        o.max_frames = sp.force_frames > 0 ? sp.force_frames : int(std::min<int64_t>(mt, std::max<int64_t>(75, int64_t(r.target_token_count) * 6)));  // :1051-1052
         for (int id : o.text_ids) Q3_CHECK(id >= 0 && id < t.text_vocab_size, 3, "Invalid input: text token id out of range");
         for (int id : o.ref_text_ids) Q3_CHECK(id >= 0 && id < t.text_vocab_size, 3, "Invalid input: reference text token id out of range");
         return o;
@@ -743,7 +748,7 @@ ResolvedRequest Engine::resolve(const q3tts_request& r, const q3tts_sampling& sp
     }
     o.target_token_count = r.target_token_count;
     const int mt = r.max_tokens > 0 ? r.max_tokens : 2048;
-    o.max_frames = sp.force_frames > 0 ? sp.force_frames : std::min(mt, std::max(75, r.target_token_count * 6));  // :822-823
+    o.max_frames = sp.force_frames > 0 ? sp.force_frames : int(std::min<int64_t>(mt, std::max<int64_t>(75, int64_t(r.target_token_count) * 6)));  // :822-823
     for (int id : o.text_ids) Q3_CHECK(id >= 0 && id < t.text_vocab_size, 3, "Invalid input: text token id out of range");
     for (int id : o.instruct_ids) Q3_CHECK(id >= 0 && id < t.text_vocab_size, 3, "Invalid input: instruct token id out of range");
     return o;

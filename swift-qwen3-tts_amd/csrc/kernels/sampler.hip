@@ -242,6 +242,7 @@ __device__ __forceinline__ void sampler_body(const SamplerArgs& a, const FrameEn
             if (i < V) x = better(x, Best{l[k], i});
         }
         tok = block_argmax<kThreads>(x, scratch).i;
+        if (tok == 0x7fffffff) tok = 0;  // every logit NaN (a damaged checkpoint): no maximum exists; the token is a table row next step
     } else {
         const bool have_eos = TALKER && a.eos_id >= 0 && a.eos_id < V;
         const float eos_logit = have_eos ? vals[a.eos_id] : 0.f;

@@ -477,3 +477,44 @@ def test_caller_codes_outside_the_codebooks_are_rejected_on_the_host(engines, ck
         assert (got[0] == want[0]).all()
     again, _ = m.codec_decode(good)
     assert (again == want).all()
+
+
+@pytest.mark.gpu
+def test_a_checkpoint_whose_logits_are_all_nan_stays_inside_the_tables(tmp_path, engines):
+    """A damaged checkpoint (the talker's final norm weight overwritten with NaN: every logit of every step is NaN) must not turn
+    into an out-of-range row index on the GPU: "no maximum exists" used to leave the greedy draw at its sentinel 0x7fffffff, which
+    the next step would have used as an embedding row. Greedy and sampled draws both fall back to token 0; the call returns,
+    every code is a valid row, and a healthy engine in the same process still produces what it produced before."""
+    import json
+    import struct
+    from qwen3tts import GenerationRequest, Qwen3TTSModel, synth
+    d = str(tmp_path / "nan_ckpt")
+    synth.write_checkpoint(d, "tiny-a", seed=1234)
+    path = os.path.join(d, "model.safetensors")
+    raw = bytearray(open(path, "rb").read())
+    hlen = struct.unpack("<Q", raw[:8])[0]
+    hdr = json.loads(raw[8:8 + hlen])
+    ent = hdr["talker.model.norm.weight"]
+    assert ent["dtype"] == "BF16"
+    a, b = ent["data_offsets"]
+    raw[8 + hlen + a:8 + hlen + b] = struct.pack("<H", 0x7FC0) * ((b - a) // 2)
+    open(path, "wb").write(bytes(raw))
+    healthy = engines["tiny-a"]
+    r = tiny_request(row=0, n_text=8)
+    req = GenerationRequest(r["text_ids"], r["target_token_count"], r["instruct_ids"], r["speaker"], r["language"])
+    before = healthy.generate_batch([req], temperature=0.0, seed=5, force_frames=4)[0]
+    m = Qwen3TTSModel.from_pretrained(d, max_batch=2, max_frames=16, max_prompt=64)
+    try:
+        V = max(m.info.vocab_size, m.info.cp_vocab_size)
+        for temp in (0.0, 0.9):
+            res = m.generate_batch([req, req], temperature=temp, top_k=20, seed=5, force_frames=4)
+            for x in res:
+                assert x.codes.shape == (4, 16) and (x.codes >= 0).all() and (x.codes < V).all()
+                # the predictor has no suppressed range: no logit compares, the fallback token 0 is drawn. (The talker's suppressed
+                # logits are -inf, not NaN, so ITS draw is the first of them -- a valid embedding row, and a code the gather
+                # clamps into the semantic table when the waveform is decoded.)
+                assert (x.codes[:, 1:] == 0).all()
+    finally:
+        m.close()
+    after = healthy.generate_batch([req], temperature=0.0, seed=5, force_frames=4)[0]
+    assert (after.codes == before.codes).all() and (after.audio == before.audio).all()

@@ -520,3 +520,20 @@ def test_gpu_clone_audio_chunks_skip_the_reference_part(engine_base):
         assert a.status == 0 and (a.codes == b.codes).all() and (a.audio == b.audio).all()
         assert pieces[i][0][0] == 0 and (np.concatenate([p for _, p in pieces[i]]) == b.audio).all()
         assert b.audio.size < (14 + 12) * 1920   # the reference's frames are not part of the result
+
+
+@pytest.mark.gpu
+def test_gpu_reference_audio_with_a_nan_sample_is_rejected(engine_base):
+    """One NaN in the clip would spread through both encoders into every logit of the row: an 'Invalid input' instead."""
+    from qwen3tts import Qwen3TTSError
+    g, _ = _reqs(0, n_text=6, seconds=0.5)
+    bad = np.array(g.ref_audio, np.float32, copy=True)
+    bad[1234] = np.nan
+    g.ref_audio = bad
+    with pytest.raises(Qwen3TTSError) as e:
+        engine_base.generate_batch([g], temperature=0.0, force_frames=3)
+    assert e.value.status == 3 and "non-finite" in str(e.value)
+    g.ref_audio[1234] = np.inf
+    with pytest.raises(Qwen3TTSError) as e:
+        engine_base.generate_batch([g], temperature=0.0, force_frames=3)
+    assert e.value.status == 3 and "non-finite" in str(e.value)
