@@ -12,7 +12,9 @@
  * torch/HIP types across the boundary. Tokenisation stays on the caller's side
  * (swift-transformers in the reference, Qwen3.swift:274-275): the engine takes token ids.
  * One q3tts_model per GPU; calls on one handle are serialised by the caller (the reference
- * model object is not re-entrant either).
+ * model object is not re-entrant either). The library checks this: a call that finds the handle
+ * inside another thread's call returns Q3TTS_ERR_INVALID_INPUT at once (nested calls from the
+ * same thread, e.g. from an event callback running on the calling thread, are fine).
  */
 #ifndef Q3TTS_H
 #define Q3TTS_H

@@ -1,8 +1,10 @@
 // api.cc -- extern "C" surface declared in include/q3tts.h. No exception crosses the boundary:
 // every entry point returns a q3tts_status and records the message for q3tts_last_error().
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "codec.h"
@@ -14,6 +16,11 @@ using q3::EngineGroup;
 
 struct q3tts_model {
     std::unique_ptr<EngineGroup> eng;
+    // "Calls on one handle are serialised by the caller" (q3tts.h; the reference's model object is not re-entrant either). The
+    // contract is checked, not assumed: a call that finds the handle inside another thread's call fails with INVALID_INPUT instead
+    // of racing on the engine's state. Nested calls from the SAME thread (an event callback asking for q3tts_model_info) pass.
+    std::atomic<std::thread::id> owner{std::thread::id()};
+    std::atomic<int> depth{0};
 };
 struct q3tts_tokenizer {
     q3::BpeTokenizer tok;
@@ -21,9 +28,35 @@ struct q3tts_tokenizer {
 
 namespace {
 thread_local std::string g_load_error;
+thread_local const q3tts_model* g_refused = nullptr;  // this thread's last call on that handle found it in use (HandleUse)
+const char* const kBusyMsg =
+    "Invalid input: the model handle is inside another thread's call (calls on one handle must be serialised by the caller)";
+
+struct HandleUse {  // the handle's one-caller-at-a-time contract (struct q3tts_model)
+    q3tts_model* m;
+    bool mine = false;
+    explicit HandleUse(q3tts_model* model) : m(model) {
+        if (!m) return;
+        const std::thread::id me = std::this_thread::get_id();
+        std::thread::id none;
+        if (m->owner.load(std::memory_order_acquire) == me || m->owner.compare_exchange_strong(none, me, std::memory_order_acq_rel)) {
+            m->depth.fetch_add(1, std::memory_order_relaxed);
+            mine = true;
+        }
+    }
+    ~HandleUse() {
+        if (m && mine && m->depth.fetch_sub(1, std::memory_order_relaxed) == 1) m->owner.store(std::thread::id(), std::memory_order_release);
+    }
+};
 
 template <class F>
 q3tts_status guarded(q3tts_model* m, F&& f) {
+    HandleUse use(m);
+    if (m && !use.mine) {
+        g_refused = m;  // (not written to the engine's last_error: that string belongs to the call that is running)
+        return Q3TTS_ERR_INVALID_INPUT;
+    }
+    if (m && g_refused == m) g_refused = nullptr;
     try {
         f();
         return Q3TTS_OK;
@@ -95,6 +128,7 @@ q3tts_status q3tts_model_load(const char* model_dir, const q3tts_load_opts* opts
 void q3tts_model_free(q3tts_model* m) { delete m; }
 
 const char* q3tts_last_error(const q3tts_model* m) {
+    if (m && g_refused == m) return kBusyMsg;
     if (m && m->eng) return m->eng->last_error.c_str();
     return g_load_error.c_str();
 }

@@ -4,6 +4,7 @@ Bars: integer / index work bit-exact; bf16 LM logits withi
 row's largest |logit| under teacher forcing, tokens consistent with the oracle's argmax within the
 same margin; fp32 codec activations within 1e-4 of the stage's scale, PCM within 1e-4 absolute."""
 import os
+import time
 
 import numpy as np
 import pytest
@@ -518,3 +519,47 @@ def test_a_checkpoint_whose_logits_are_all_nan_stays_inside_the_tables(tmp_path,
         m.close()
     after = healthy.generate_batch([req], temperature=0.0, seed=5, force_frames=4)[0]
     assert (after.codes == before.codes).all() and (after.audio == before.audio).all()
+
+
+@pytest.mark.gpu
+def test_a_second_thread_is_refused_while_a_call_is_running(engines):
+    """q3tts.h: calls on one handle are serialised by the caller (the reference's model object is not re-entrant). The library
+    checks the contract instead of trusting it: a call from another thread while q3tts_generate runs gets INVALID_INPUT with
+    a message that names the reason -- and the running call's result is what it is without the intruder."""
+    import threading
+    from qwen3tts import GenerationRequest, Qwen3TTSError
+    m = engines["tiny-a"]
+    r = tiny_request(row=2, n_text=9)
+    req = GenerationRequest(r["text_ids"], r["target_token_count"], r["instruct_ids"], r["speaker"], r["language"])
+    kw = dict(temperature=0.9, top_k=30, seed=11, force_frames=24)
+    want = m.generate_batch([req], **kw)[0]
+    got, refused, others = [], [], []
+    running = threading.Event()
+
+    def busy(e):
+        return e.status == 3 and "another thread" in str(e)
+
+    def worker():
+        running.set()
+        while len(got) < 6:
+            try:
+                got.append(m.generate_batch([req], **kw)[0])
+            except Qwen3TTSError as e:      # the intruder held the handle at that instant: the call did not start
+                (refused if busy(e) else others).append("worker: " + str(e))
+
+    t = threading.Thread(target=worker)
+    t.start()
+    running.wait()
+    while t.is_alive():
+        try:
+            m.arena_checksum()
+        except Qwen3TTSError as e:
+            (refused if busy(e) else others).append("main: " + str(e))
+        time.sleep(0.001)
+    t.join()
+    assert refused and not others, (len(refused), others[:2])
+    assert any(x.startswith("main") for x in refused)        # a generate call was running when the second thread came
+    assert len(got) == 6
+    for g in got:
+        assert (g.codes == want.codes).all() and (g.audio == want.audio).all()
+    assert m.arena_checksum() == m.arena_checksum()      # and the handle is free again
