@@ -58,6 +58,9 @@ q3tts_status guarded(q3tts_model* m, F&& f) {
     }
     if (m && g_refused == m) g_refused = nullptr;
     try {
+        // every call on a handle runs with the handle's GPU current, whatever the calling thread had selected (a process may hold one
+        // handle per GPU; allocations and per-device kernel attributes inside the call belong to THIS device)
+        if (m && m->eng) Q3_HIP(hipSetDevice(m->eng->model().device));
         f();
         return Q3TTS_OK;
     } catch (const q3::Error& e) {

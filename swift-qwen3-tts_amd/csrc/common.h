@@ -47,6 +47,16 @@ inline bf16_t f32_to_bf16_host(float f) {
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// per-device one-time setup (hipFuncSetAttribute and the like): the flag of the CURRENT device out of an array of kMaxDevices
+constexpr int kMaxDevices = 64;
+template <class Flag>
+inline Flag& device_once(Flag (&flags)[kMaxDevices]) {
+    int dev = 0;
+    Q3_HIP(hipGetDevice(&dev));
+    Q3_CHECK(dev >= 0 && dev < kMaxDevices, 7, "device ordinal beyond kMaxDevices");
+    return flags[dev];
+}
+
 // Fragment-major ("tiled") activation layout. Every GEMM x operand [rows][K] (K % 128 == 0) is
 // stored so that the 64 lanes of a wave read one MFMA B fragment as 1 KiB contiguous:
 //   block (kc = k/128, mb = m/16, i = (k/8)%4) holds [lane = ((k/32)%4)*16 + m%16][k%8].

@@ -1056,12 +1056,14 @@ bool resunit_supported(int C, int K, int dil) {
 }
 
 void launch_resunit(const ResUnitArgs& a0, hipStream_t st) {
+    static std::once_flag attr_once[kMaxDevices];
     ResUnitArgs a = a0;
     Q3_CHECK(resunit_supported(a.C, a.K, a.dil) && a.out != a.y, 3, "resunit: unsupported geometry");
     Q3_CHECK(a.w1h && a.w2ph && a.wsc1 && a.wsc2, 3, "resunit: incomplete fp16x2 weights");
     if (a.Tmax <= 0 || a.B <= 0) return;
-    static std::once_flag attr_once;  // (lanes launch from their own threads)
-    std::call_once(attr_once, [] {
+    // once per DEVICE (a process may hold one handle per GPU; the attribute belongs to the device's copy of the kernel) and
+    // thread-safe (lanes launch from their own threads)
+    std::call_once(device_once(attr_once), [] {
         void (*ks[4])(ResUnitArgs) = {&resunit_h2_kernel<2, 2>, &resunit_h2_kernel<4, 2>, &resunit_h2_kernel<6, 4>, &resunit_h2_kernel<12, 2>};
         for (auto k : ks)
             Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
@@ -1081,6 +1083,7 @@ void launch_resunit(const ResUnitArgs& a0, hipStream_t st) {
 }
 
 void launch_conv_gemm(const ConvGemmArgs& a, hipStream_t st) {
+    static std::once_flag attr_once[kMaxDevices];
     Q3_CHECK((a.K - 1) * a.dil <= MAX_HALO, 3, "conv_gemm: receptive field too large");
     Q3_CHECK(!a.x2 || (a.B == 1 && a.ldx2 % 4 == 0), 3, "conv_gemm: the pre-add input is single-row only");
     Q3_CHECK(a.Cin % 4 == 0 && a.N % 4 == 0 && a.ldx % 4 == 0 && a.ldo % 4 == 0, 3, "conv_gemm: channels must be multiples of 4");
@@ -1092,8 +1095,9 @@ void launch_conv_gemm(const ConvGemmArgs& a, hipStream_t st) {
     else if (a.N % 96 == 0) BN = 96;
     else if (a.N > 128 && (a.N % 64) != 0) BN = 128;
     dim3 grid((a.N + BN - 1) / BN, mt, a.B), block(256);
-    static std::once_flag attr_once;  // (lanes launch from their own threads)
-    std::call_once(attr_once, [] {  // 160 KiB of LDS per CU on gfx950; the default static cap is 64 KiB
+    // once per DEVICE (a process may hold one handle per GPU; the attribute belongs to the device's copy of the kernel) and
+    // thread-safe (lanes launch from their own threads)
+    std::call_once(device_once(attr_once), [] {  // 160 KiB of LDS per CU on gfx950; the default static cap is 64 KiB
         Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<96>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
         Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
