@@ -252,3 +252,75 @@ def test_mimi_full_encode_matches_hf(base, mimi):
         assert (st["gaps"][layer][diff] < 1e-3).all(), (layer, st["gaps"][layer][diff])
         alive &= ~diff
     assert (got == want).mean() > 0.9
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the code predictor's frame loop vs transformers' Qwen3-Omni talker code predictor (A12)
+# ---------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def tiny_a(tmp_path_factory):
+    from oracle import oracle as O
+    from qwen3tts import synth
+    d = str(tmp_path_factory.mktemp("tiny_a_hf"))
+    synth.write_checkpoint(d, "tiny-a", seed=2025)   # talker and predictor share the hidden size: no small_to_mtp projection
+    return d, O.OracleModel(d)
+
+
+def test_code_predictor_frame_matches_hf_qwen3_omni_code_predictor(tiny_a):
+    """Qwen3-TTS's code predictor is the Qwen3-Omni talker's (same upstream): 5 Qwen3 layers over a per-frame cache, fifteen
+    embedding tables and fifteen heads. What this pins against an implementation the oracle was not written from is the
+    INDEXING of a frame (CodePredictor.swift:320-339, Qwen3.swift:879-909): pass 0 takes two positions [hidden, embed(c0)]
+    and reads lm_head[0] at the last one; pass s >= 1 takes table s - 1 at code s and reads lm_head[s]; positions run
+    0, 1, 2, ... over one cache. The checkpoint's tensors load into the HF module by their own names."""
+    from transformers.models.qwen3_omni_moe import modeling_qwen3_omni_moe as M
+    from transformers.models.qwen3_omni_moe.configuration_qwen3_omni_moe import Qwen3OmniMoeTalkerCodePredictorConfig
+    from oracle import oracle as O
+    d, om = tiny_a
+    assert not om.has_proj          # (HF's module embeds the codes itself: a projection in front of it could not be injected)
+    import json
+    cpc = json.load(open(os.path.join(d, "config.json")))["talker_config"]["code_predictor_config"]
+    cfg = Qwen3OmniMoeTalkerCodePredictorConfig(
+        vocab_size=cpc["vocab_size"], hidden_size=cpc["hidden_size"], intermediate_size=cpc["intermediate_size"],
+        num_hidden_layers=cpc["num_hidden_layers"], num_attention_heads=cpc["num_attention_heads"],
+        num_key_value_heads=cpc["num_key_value_heads"], head_dim=cpc["head_dim"], rms_norm_eps=cpc["rms_norm_eps"],
+        rope_theta=cpc["rope_theta"], max_position_embeddings=64, num_code_groups=cpc["num_code_groups"], attention_bias=False,
+        use_sliding_window=False)
+    cfg._attn_implementation = "eager"
+    hf = M.Qwen3OmniMoeTalkerCodePredictorModelForConditionalGeneration(cfg).float().eval()
+    pre = "talker.code_predictor."
+    sd = {k[len(pre):]: torch.from_numpy(O.bf16_to_f32(v)) for k, v in om.w.items()
+          if k.startswith(pre) and "small_to_mtp" not in k}
+    missing, unexpected = hf.load_state_dict(sd, strict=False)
+    assert not unexpected and all("rotary" in k or "inv_freq" in k for k in missing), (missing, unexpected)
+
+    rng = np.random.default_rng(17)
+    ncg, Vc, H = cpc["num_code_groups"], cpc["vocab_size"], cpc["hidden_size"]
+    worst, agree, confident = 0.0, 0, 0
+    for frame in range(3):
+        hidden = O.f32_to_bf16(rng.standard_normal((1, H)).astype(np.float32))
+        c0 = int(rng.integers(0, 2048))
+        codes = [c0]
+        cache = om.cpm.new_cache(ncg + 1)
+        past = None
+        for s in range(ncg - 1):
+            if s == 0:
+                x = np.concatenate([hidden, om.codec_embed([c0])], 0)
+                with torch.no_grad():
+                    out = hf(inputs_embeds=torch.from_numpy(O.bf16_to_f32(x))[None], use_cache=True)
+            else:
+                x = om.cp_embed(s - 1, [codes[s]])
+                with torch.no_grad():
+                    out = hf(input_ids=torch.tensor([[codes[s]]]), generation_steps=s, past_key_values=past, use_cache=True)
+            past = out.past_key_values
+            ref = t2n(out.logits[0, -1])
+            got = O.bf16_to_f32(om.cp_forward(cache, x, s)[-1])
+            assert got.shape == ref.shape == (Vc,)
+            worst = max(worst, float(np.abs(got - ref).max()) / max(1.0, float(np.abs(ref).max())))
+            top2 = np.sort(ref)[-2:]
+            if top2[1] - top2[0] > 0.05 * max(1.0, float(np.abs(ref).max())):   # a winner no bf16 rounding can flip
+                confident += 1
+                agree += int(np.argmax(got) == np.argmax(ref))
+            codes.append(int(np.argmax(got)))
+    # bf16 storage at every op vs fp32 HF over <= 16 positions: the bar of the decoder-layer test (test_oracle_blocks.py)
+    assert worst < 0.05, worst
+    assert confident >= 10 and agree == confident, (agree, confident)
