@@ -324,3 +324,88 @@ def test_code_predictor_frame_matches_hf_qwen3_omni_code_predictor(tiny_a):
     # bf16 storage at every op vs fp32 HF over <= 16 positions: the bar of the decoder-layer test (test_oracle_blocks.py)
     assert worst < 0.05, worst
     assert confident >= 10 and agree == confident, (agree, confident)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the speaker encoder vs transformers' ECAPA_TimeDelayNet (V2)
+# ---------------------------------------------------------------------------------------------------------
+def test_speaker_encoder_matches_hf_ecapa_tdnn(base):
+    """Qwen3TTSSpeakerEncoder (SpeakerEncoder.swift:278-395) is the ECAPA-TDNN of Qwen2.5-Omni's token2wav, which transformers
+    carries as `ECAPA_TimeDelayNet` with the same block names -- so the checkpoint's `speaker_encoder.*` tensors load into it BY
+    NAME, in the torch conv layout the checkpoint stores (which also checks the oracle's conv-layout sanitiser, Qwen3.swift:
+    1246-1260, from the other side: the oracle transposes what HF takes as is). Same log-mel in, every block's output and the
+    x-vector out: reflect 'same' padding, the Res2Net chain (chunk i takes chunk + previous output from i = 2 on), squeeze-
+    excitation over the time mean, multi-layer aggregation of blocks 1-3, attentive statistics pooling, the final 1x1 conv."""
+    import types
+    from transformers.models.qwen2_5_omni import modeling_qwen2_5_omni as M
+    from oracle import oracle as O
+    from qwen3tts import synth
+    d, om = base
+    raw = O.load_safetensors_dir(d)
+    hf = M.ECAPA_TimeDelayNet(types.SimpleNamespace(**om.sc)).float().eval()
+    sd = {k[len("speaker_encoder."):]: torch.from_numpy(O.bf16_to_f32(v) if v.dtype == np.uint16 else v.astype(np.float32))
+          for k, v in raw.items() if k.startswith("speaker_encoder.")}
+    hf.load_state_dict(sd, strict=True)
+    for row, seconds in ((0, 0.6), (1, 1.3)):
+        audio = synth.synthetic_reference_audio(row, seconds)
+        stages = {}
+        emb = om.speaker_embedding(audio, stages)
+        mel = torch.from_numpy(stages["mel"])[None]                    # [1][T][128]
+        with torch.no_grad():
+            x = mel.transpose(1, 2)
+            outs = []
+            for blk in hf.blocks:
+                x = blk(x)
+                outs.append(x)
+            mfa = hf.mfa(torch.cat(outs[1:], dim=1))
+            ref = hf(mel)[0]
+        for name, t in (("h0", outs[0]), ("h1", outs[1]), ("h2", outs[2]), ("h3", outs[3]), ("mfa", mfa)):
+            assert close(stages[name], t2n(t[0]).T, 2e-5), name
+        assert close(emb, t2n(ref), 5e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the decoder's split-RVQ dequantisation vs transformers' Mimi RVQ (C2)
+# ---------------------------------------------------------------------------------------------------------
+def test_decoder_rvq_dequantisation_matches_hf_mimi(base):
+    """SplitResidualVectorQuantizer.decode (SpeechTokenizer.swift:175-227, 124-170, 61-97): codebook = embedding_sum /
+    clip(cluster_usage, 1e-5) (the sanitiser's job, Qwen3.swift:1716-1724), the layers' rows summed, one bias-free 1x1
+    output projection per half, the halves added. Mimi's `MimiResidualVectorQuantizer.decode` is the upstream of both halves:
+    two instances (the reference's semantic table is larger than the acoustic ones, which one MimiConfig cannot say) take the
+    checkpoint's raw `decoder.quantizer.rvq_{first,rest}.*` tensors -- sums and usages, not the divided tables -- so the
+    division, the layer order and the projection are all HF's."""
+    from safetensors.numpy import load_file
+    from transformers.models.mimi import modeling_mimi as MM
+    from transformers.models.mimi.configuration_mimi import MimiConfig
+    d, om = base
+    raw = load_file(os.path.join(d, "speech_tokenizer", "model.safetensors"))
+    dc = om.dc
+
+    def half(name, n_layers, bins):
+        w_out = raw[f"decoder.quantizer.{name}.output_proj.weight"]       # torch layout [out][in][1]
+        cfg = MimiConfig(codebook_size=bins, codebook_dim=w_out.shape[1], vector_quantization_hidden_dimension=w_out.shape[1],
+                         hidden_size=w_out.shape[0], num_quantizers=max(n_layers, 2), num_semantic_quantizers=1)   # (the config wants > 1)
+        q = MM.MimiResidualVectorQuantizer(cfg, n_layers).eval()
+        sd = {"output_proj.weight": torch.from_numpy(w_out.copy()),
+              "input_proj.weight": torch.from_numpy(raw[f"decoder.quantizer.{name}.input_proj.weight"].copy())}
+        for j in range(n_layers):
+            p = f"decoder.quantizer.{name}.vq.layers.{j}._codebook."
+            sd[f"layers.{j}.codebook.embed_sum"] = torch.from_numpy(raw[p + "embedding_sum"].copy())
+            sd[f"layers.{j}.codebook.cluster_usage"] = torch.from_numpy(raw[p + "cluster_usage"].copy())
+            sd[f"layers.{j}.codebook.initialized"] = torch.tensor([1.0])
+        q.load_state_dict(sd, strict=True)
+        return q
+
+    nsem, nq = dc["num_semantic_quantizers"], dc["num_quantizers"]
+    first = half("rvq_first", nsem, dc["semantic_codebook_size"])
+    rest = half("rvq_rest", nq - nsem, dc["codebook_size"])
+    rng = np.random.default_rng(23)
+    F = 9
+    codes = np.concatenate([rng.integers(0, dc["semantic_codebook_size"], (F, nsem)),
+                            rng.integers(0, dc["codebook_size"], (F, nq - nsem))], 1).astype(np.int64)
+    stages = {}
+    om._codec_front(codes, stages)
+    ct = torch.from_numpy(codes.T[None])                                   # [1][K][F]
+    with torch.no_grad():
+        ref = first.decode(ct[:, :nsem]) + rest.decode(ct[:, nsem:])       # [1][C][F]
+    assert close(stages["quantizer"], t2n(ref[0]).T, 1e-5)
