@@ -886,7 +886,16 @@ class OracleModel:
         valid = int((codes[:, 0] > 0).sum()) * up  # :831-833
         return pcm, valid
 
-    def codec_decode_streamed(self, codes: np.ndarray, chunk: int, window: int, lookahead: int) -> np.ndarray:
+    def _codec_tail16(self, h: np.ndarray) -> np.ndarray:
+        """_codec_tail for a float16 speech tokenizer: the upsample stages as above, the MainDecoder in float16 (codec_decode's
+        f16 branch, as one function so that the streamed restatement below can share it)."""
+        dc = self.dc
+        for i, r in enumerate(dc["upsampling_ratios"]):
+            h = self._convtr(h, f"decoder.upsample.{i}.0.conv", r, r)
+            h = self._convnext(h, f"decoder.upsample.{i}.1")
+        return self._main_decoder16(h)
+
+    def codec_decode_streamed(self, codes: np.ndarray, chunk: int, window: int, lookahead: int, f16: bool = False) -> np.ndarray:
         """What a STREAM can compute of the decode above (row f1 of SURVEY 8f; the reference has no streaming decode -- gap noted
         at README.md:140 -- so this restates the engine's definition, include/q3tts.h `audio_window_frames`, as a composition
         of the reference's own functions). The tail (steps 5-7) is causal, so feeding it frame by frame with carried conv
@@ -896,14 +905,15 @@ class OracleModel:
         (the one-shot decode). codes [F][16] -> pcm [F * upsample]."""
         codes = np.asarray(codes, np.int64)
         F = codes.shape[0]
+        tail = self._codec_tail16 if f16 else self._codec_tail   # f16: a float16 ("lite") speech tokenizer, as codec_decode(f16=True)
         if window < 0:
-            return self._codec_tail(self._codec_front(codes))
+            return tail(self._codec_front(codes))
         lat = []
         for f0 in range(0, F, chunk):
             f1 = min(F, f0 + chunk)
             w0, w1 = max(0, f0 - window), min(F, f1 + lookahead)
             lat.append(self._codec_front(codes[w0:w1])[f0 - w0: f1 - w0])
-        return self._codec_tail(np.ascontiguousarray(np.concatenate(lat, 0)))
+        return tail(np.ascontiguousarray(np.concatenate(lat, 0)))
 
     def generate(self, req: Request, s: Sampling, row: int = 0):
         """generateCustomVoice end to end (Qwen3.swift:783-962): codes -> PCM, trimmed (:954-959)."""

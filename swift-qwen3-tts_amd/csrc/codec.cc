@@ -264,8 +264,16 @@ void CodecRunner::run_tail(const Pass& ps, int Tframes, float* const* bufs, floa
 // ---- float16 speech tokenizers ("lite" checkpoints, docs/paper.tex:207): the MainDecoder as the reference computes it ----
 void CodecRunner::conv_h1(const Pass& ps, const ConvW& cw, const void* x, bool x_f32, int Tmax, int ppf, uint16_t* out, const uint16_t* res,
                           const SnakeW* post, uint16_t* out2) {
+    if (stream_.dry) return;
     Q3_CHECK(cw.w1 != nullptr, 7, "internal error: float16 decoder without its one-plane weights");
     ConvH1Args a{};
+    // streamed decode (as conv()): Tmax counts the allocation's rows, row 0 of the chunk sits behind the history margin
+    const int64_t m_in = int64_t(ps.hist_frames) * ppf * cw.Cin, m_out = int64_t(ps.hist_frames) * ppf * cw.N;
+    x = x_f32 ? static_cast<const void*>(static_cast<const float*>(x) + m_in) : static_cast<const void*>(static_cast<const uint16_t*>(x) + m_in);
+    if (out) out += m_out;
+    if (res) res += m_out;
+    if (out2) out2 += m_out;
+    a.hist = ps.hist_frames * ppf;
     a.x = x; a.x_f32 = x_f32 ? 1 : 0; a.ldx = cw.Cin; a.x_bstride = int64_t(Tmax) * cw.Cin;
     a.w1 = cw.w1; a.bias = cw.bias;
     a.res = res; a.ldr = cw.N; a.res_bstride = int64_t(Tmax) * cw.N;
@@ -345,6 +353,78 @@ void CodecRunner::run_main_h1(const Pass& ps, int T, int ppf, int cur, float* co
         capture_h(ps, ("block" + std::to_string(i)).c_str(), H(cur), T, Bk.Cout);
     }
     launch_out_conv_h1(H(cur), w.out_C, w.out_snake.ea16, w.out_snake.ib16, w.out_w, w.out_b, ps.fr, ppf, T, ps.nb, pcm, st_, nf_dev_ + ps.row0);
+    Q3_CHECK(ppf == up_, 7, "internal error: codec upsampling mismatch");
+}
+
+// run_main_h1 over one chunk of a stream (run_tail_stream's rules: every tensor in its own persistent buffer of hist + chunk frames
+// per row, float16 here, the ones a k7 / transposed conv reads back carrying the previous chunk's last frames in their margin).
+// in: h32 = the last ConvNeXt stage's fp32 output (stream layout, history kept by the caller's sbuf).
+void CodecRunner::run_main_h1_stream(const Pass& ps, const float* h32, int T, int ppf, float* pcm) {
+    const CodecW& w = m_.codec;
+    const Stream& S = stream_;
+    const int H = ps.hist_frames;
+    const size_t nblk = w.blocks.size();
+    auto hb = [&](size_t frame_halves, bool keeps) { return reinterpret_cast<uint16_t*>(sbuf(frame_halves / 2, keeps)); };
+    uint16_t* h = nullptr;   // the residual stream
+    uint16_t* ys = nullptr;  // SnakeBeta of the previous stage's output = the next transposed conv's input
+    size_t fh = size_t(ppf) * w.init_conv.N;  // float16 elements per frame of the current tensor
+    Q3_CHECK(fh % 2 == 0, 7, "internal error: odd float16 frame size in a streamed decode");
+    {
+        uint16_t* y = hb(fh, nblk == 0);
+        ys = nblk ? hb(fh, true) : nullptr;  // transposed conv: one row back
+        conv_h1(ps, w.init_conv, h32, true, T, ppf, y, nullptr, nblk ? &w.blocks[0].snake : nullptr, ys);
+        h = y;
+    }
+    for (size_t i = 0; i < nblk; ++i) {
+        const auto& Bk = w.blocks[i];
+        const SnakeW* after = i + 1 < nblk ? &w.blocks[i + 1].snake : nullptr;
+        const bool lastb = i + 1 == nblk;
+        bool fused = !no_fuse_ && resunit_h1_supported(Bk.Cout, Bk.res[0].conv1.K, 9);
+        for (int j = 0; j < 3; ++j)
+            fused = fused && Bk.res[j].conv1.w1 && Bk.res[j].conv2.w1p && Bk.res[j].conv1.N == Bk.Cout && Bk.res[j].conv2.K == 1 &&
+                    resunit_h1_supported(Bk.Cout, Bk.res[j].conv1.K, Bk.res[j].conv1.dil);
+        fh = size_t(ppf) * Bk.stride * Bk.Cout;
+        Q3_CHECK(fh % 2 == 0, 7, "internal error: odd float16 frame size in a streamed decode");
+        uint16_t* hs_next = after ? hb(fh, true) : nullptr;
+        if (fused) {
+            uint16_t* yb[4];
+            for (int j = 0; j < 3; ++j) yb[j] = hb(fh, true);   // inputs of the three units (k7, dilated)
+            yb[3] = hb(fh, lastb);                               // block output; the last one feeds outConv (k7)
+            conv_h1(ps, Bk.tconv, ys, false, T, ppf, yb[0], nullptr, nullptr, nullptr);
+            T *= Bk.stride;
+            ppf *= Bk.stride;
+            for (int j = 0; j < 3; ++j) {
+                ResUnitH1Args r{};
+                r.y = yb[j] + size_t(H) * fh; r.out = yb[j + 1] + size_t(H) * fh;
+                if (j == 2 && after) { r.out2 = hs_next + size_t(H) * fh; r.post_ea = after->ea16; r.post_ib = after->ib16; }
+                r.b1 = Bk.res[j].conv1.bias; r.b2 = Bk.res[j].conv2.bias;
+                r.w1 = Bk.res[j].conv1.w1; r.w2p = Bk.res[j].conv2.w1p;
+                r.ea1 = Bk.res[j].act1.ea16; r.ib1 = Bk.res[j].act1.ib16; r.ea2 = Bk.res[j].act2.ea16; r.ib2 = Bk.res[j].act2.ib16;
+                r.frames = ps.fr; r.ppf = ppf; r.Tmax = T; r.B = ps.nb; r.C = Bk.Cout; r.dil = Bk.res[j].conv1.dil;
+                r.hist = H * ppf;
+                if (!S.dry) launch_resunit_h1(r, st_);
+            }
+            h = yb[3];
+        } else {
+            uint16_t* y = hb(fh, lastb);
+            uint16_t* ya[3];
+            for (int j = 0; j < 3; ++j) ya[j] = hb(fh, true);  // act1_j(y): conv1_j's input (k7, dilated)
+            uint16_t* t1 = hb(fh, false);
+            conv_h1(ps, Bk.tconv, ys, false, T, ppf, y, nullptr, &Bk.res[0].act1, ya[0]);
+            T *= Bk.stride;
+            ppf *= Bk.stride;
+            for (int j = 0; j < 3; ++j) {
+                conv_h1(ps, Bk.res[j].conv1, ya[j], false, T, ppf, nullptr, nullptr, &Bk.res[j].act2, t1);
+                const SnakeW* next = j < 2 ? &Bk.res[j + 1].act1 : after;
+                conv_h1(ps, Bk.res[j].conv2, t1, false, T, ppf, y, y, next, j < 2 ? ya[j + 1] : hs_next);
+            }
+            h = y;
+        }
+        ys = hs_next;
+    }
+    if (!S.dry)
+        launch_out_conv_h1(h + size_t(H) * fh, w.out_C, w.out_snake.ea16, w.out_snake.ib16, w.out_w, w.out_b, ps.fr, ppf, T, ps.nb,
+                           pcm + size_t(H) * ppf, st_, nf_dev_, H * ppf);
     Q3_CHECK(ppf == up_, 7, "internal error: codec upsampling mismatch");
 }
 
@@ -718,6 +798,10 @@ void CodecRunner::run_tail_stream(const Pass& ps, float* lat, float* pcm) {
     }
     // 6. MainDecoder
     const size_t nblk = w.blocks.size();
+    if (w.f16_main && !fp32_mfma_ && !no_h1_) {  // a float16 speech tokenizer: float16 from initConv on, as in run_tail
+        run_main_h1_stream(ps, h, T, ppf, pcm);
+        return;
+    }
     float* ys = nullptr;  // SnakeBeta of the previous stage's output = the next transposed conv's input
     {
         const size_t ff = size_t(ppf) * w.init_conv.N;

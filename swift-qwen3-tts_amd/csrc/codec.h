@@ -86,6 +86,7 @@ class CodecRunner {
     void capture_h(const Pass& ps, const char* name, const uint16_t* t, int T, int C);
     // the tail over one chunk of a stream: `lat` = the chunk's pre-transformer frames (stream layout), pcm out (stream layout)
     void run_tail_stream(const Pass& ps, float* lat, float* pcm);
+    void run_main_h1_stream(const Pass& ps, const float* h32, int T, int ppf, float* pcm);  // its float16 half (run_main_h1's twin)
     float* sbuf(size_t frame_floats, bool keeps_history);  // next persistent tensor of the stream (same order every chunk)
     struct Stream {
         bool open = false, dry = false;

@@ -65,6 +65,7 @@ struct ConvH1Args {
     int post_C;
     const int32_t* frames;
     int ppf, Tmax, B, Cin, N, K, dil;
+    int hist;              // streamed decode: rows -hist .. -1 in front of x are the previous chunk's last rows (else zero padding)
 };
 void launch_conv_gemm_h1(const ConvH1Args& a, hipStream_t st);
 // DecoderResidualUnit (SpeechTokenizer.swift:430-437) on float16 tensors in one launch (kernels/codec_conv_h1.hip resunit_h1_kernel):
@@ -85,12 +86,13 @@ struct ResUnitH1Args {
     const float* ib2;
     const int32_t* frames;
     int ppf, Tmax, B, C, dil;
+    int hist;             // as ConvH1Args::hist, for y
 };
 bool resunit_h1_supported(int C, int K, int dil);
 void launch_resunit_h1(const ResUnitH1Args& a, hipStream_t st);
 // SnakeBeta -> k7 conv C -> 1 -> clip on a float16 tensor (kernels/codec_conv_h1.hip)
 void launch_out_conv_h1(const uint16_t* x, int C, const float* ea16, const float* ib16, const float* w, const float* bias,
-                        const int32_t* frames, int ppf, int Tmax, int B, float* pcm, hipStream_t st, int32_t* nonfinite);
+                        const int32_t* frames, int ppf, int Tmax, int B, float* pcm, hipStream_t st, int32_t* nonfinite, int hist = 0);
 
 // DecoderResidualUnit (SpeechTokenizer.swift:430-437) in one launch: out = y + conv2(act2(conv1(act1(y)))) with conv1
 // k taps / dilation `dil`, conv2 pointwise, C channels on both (C = 32, 64 or 96). Neither act1(y) nor conv1's

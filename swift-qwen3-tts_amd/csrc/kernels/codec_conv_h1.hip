@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_h1_kernel(ConvH1Args a) {
             const int r = item >> 2, c8 = (item & 3) * 8;
             const int t = t0 - halo + r;
             // clamped address, value masked when it is staged (hipcc waits on the spot for a load it has to predicate)
-            const int tc = t < 0 ? 0 : (t < T ? t : T - 1);
+            const int tc = t < -a.hist ? -a.hist : (t < T ? t : T - 1);  // (hist: rows in front of x that hold the previous chunk's last rows)
             const int cc = c0 + c8 < a.Cin ? c0 + c8 : 0;
             if constexpr (X32) {
                 const float* p = xf + (int64_t)tc * a.ldx + cc;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_h1_kernel(ConvH1Args a) {
             } else {
                 v = areg[i];
             }
-            if (t < 0 || t >= T || c0 + c8 >= a.Cin) v = make_uint4(0u, 0u, 0u, 0u);
+            if (t < -a.hist || t >= T || c0 + c8 >= a.Cin) v = make_uint4(0u, 0u, 0u, 0u);
             *reinterpret_cast<uint4*>(&As[r * RH + (item & 3) * 4]) = v;
         }
     };
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void resunit_h1_kernel(ResUnitH1Args a) {
             const int item = i * 256 + tid;
             const int r = item >> 2, c8 = (item & 3) * 8;
             const int t = t0 - halo + r;
-            const int tc = t < 0 ? 0 : (t < T ? t : T - 1);  // clamped address, value masked when it is staged
+            const int tc = t < -a.hist ? -a.hist : (t < T ? t : T - 1);  // clamped address, value masked when it is staged
             areg[i] = *reinterpret_cast<const uint4*>(yb + (int64_t)tc * C + c0 + c8);
         }
     };
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void resunit_h1_kernel(ResUnitH1Args a) {
             if (r >= rows) continue;
             const int t = t0 - halo + r;
             uint32_t v[4] = {areg[i].x, areg[i].y, areg[i].z, areg[i].w};
-            if (t >= 0 && t < T) {  // act1 on the raw tile (rows outside the sequence stay zero: causal padding is not activated)
+            if (t >= -a.hist && t < T) {  // act1 on the raw tile (rows outside the sequence stay zero: causal padding is not activated)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     h2v x, e, q;
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(256, 2) void resunit_h1_kernel(ResUnitH1Args a) {
 // codec_misc.hip out_conv_kernel).
 __global__ __launch_bounds__(256) void out_conv_h1_kernel(const uint16_t* x, int C, const float* ea, const float* ib, const float* w,
                                                           const float* bias, const int32_t* frames, int ppf, int Tmax, float* pcm,
-                                                          int32_t* nonfinite) {
+                                                          int32_t* nonfinite, int hist) {
     extern __shared__ __attribute__((aligned(16))) float xs[];  // [(64 + 6)][C + 4] snake(x), then [7][C] taps
     const int ld = C + 4, C4 = C >> 2;
     float* ws = xs + 70 * ld;
@@ -565,7 +565,7 @@ __global__ __launch_bounds__(256) void out_conv_h1_kernel(const uint16_t* x, int
         const int r = i / C4, c4 = i % C4;
         const int t = t0 - 6 + r;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t >= 0 && t < T) {
+        if (t >= -hist && t < T) {
             float xv[4];
             unpack_h4(*reinterpret_cast<const uint2*>(xb + (int64_t)t * C + 4 * c4), xv);
             const float4 e = *reinterpret_cast<const float4*>(ea + 4 * c4), q = *reinterpret_cast<const float4*>(ib + 4 * c4);
@@ -649,11 +649,11 @@ void launch_resunit_h1(const ResUnitH1Args& a, hipStream_t st) {
 }
 
 void launch_out_conv_h1(const uint16_t* x, int C, const float* ea, const float* ib, const float* w, const float* bias,
-                        const int32_t* frames, int ppf, int Tmax, int B, float* pcm, hipStream_t st, int32_t* nonfinite) {
+                        const int32_t* frames, int ppf, int Tmax, int B, float* pcm, hipStream_t st, int32_t* nonfinite, int hist) {
     const size_t smem = size_t(70 * (C + 4) + 7 * C) * sizeof(float);
     Q3_CHECK(smem <= 64 * 1024 && C % 4 == 0 && C >= 4 && C <= 1024, 3, "out_conv_h1: unsupported channel count");
     hipLaunchKernelGGL(out_conv_h1_kernel, dim3((Tmax + 63) / 64, B), dim3(256), smem, st, x, C, ea, ib, w, bias, frames, ppf, Tmax, pcm,
-                       nonfinite);
+                       nonfinite, hist);
 }
 
 }  // namespace q3

@@ -146,3 +146,75 @@ def test_float16_main_decoder_at_the_real_layer_widths(tmp_path_factory):
         assert np.abs(want).max() < 0.999 and np.sqrt((want ** 2).mean()) > 1e-3
     finally:
         m.close()
+
+
+def _full_width_f16_checkpoint(d):
+    import json
+    from qwen3tts import synth
+    p = synth.preset("tiny-a")
+    p["speech_tokenizer"]["decoder_config"] = synth._codec_cfg(False)
+    p["config"]["talker_config"]["code_predictor_config"]["vocab_size"] = 2048
+    os.makedirs(os.path.join(d, "speech_tokenizer"), exist_ok=True)
+    g = synth._Gen(1234, False)
+    json.dump(p["config"], open(os.path.join(d, "config.json"), "w"))
+    json.dump(p["speech_tokenizer"], open(os.path.join(d, "speech_tokenizer", "config.json"), "w"))
+    synth.save_safetensors(os.path.join(d, "model.safetensors"), synth.talker_tensors(p["config"], g))
+    codec = synth.codec_tensors(p["speech_tokenizer"]["decoder_config"], g, out_wstd=synth.FULL_WIDTH_OUT_WSTD)
+    codec = {k: (("F16", v.astype(np.float16)) if tag == "F32" else (tag, v)) for k, (tag, v) in codec.items()}
+    synth.save_safetensors(os.path.join(d, "speech_tokenizer", "model.safetensors"), codec)
+
+
+@pytest.mark.parametrize("width", ["tiny", "real"])
+def test_float16_streamed_decode_is_the_float16_decode(tiny_h, tmp_path_factory, width):
+    """Audio that leaves while tokens are still being generated, from a float16 speech tokenizer: the stream's tail runs the same
+    float16 kernels with the conv state carried in the tensors' history margins (CodecRunner::run_main_h1_stream), so
+      * with the pre-transformer over all frames (window < 0) the streamed waveform IS the one-shot float16 decode, bit for bit,
+        ragged rows included -- the property the fp32-equivalent stream has had since round 3;
+      * with a sliding window it is the oracle's windowed restatement with the float16 tail (codec_decode_streamed(f16=True))
+        within the float16 noise floor of test_float16_main_decoder_matches_the_float16_oracle;
+      * and a streamed generate call delivers chunks that concatenate to the call's own audio."""
+    from oracle import oracle as O
+    from qwen3tts import GenerationRequest, Qwen3TTSModel
+    if width == "tiny":
+        d, hi = tiny_h, 32
+    else:
+        d, hi = str(tmp_path_factory.mktemp("full_codec_f16_stream")), 2048
+        _full_width_f16_checkpoint(d)
+    om = O.OracleModel(d)
+    assert om.codec_f16
+    rng = np.random.default_rng(8)
+    F = [13, 7, 10]
+    codes = np.zeros((3, 13, 16), np.int32)
+    for b, f in enumerate(F):
+        codes[b, :f] = rng.integers(1, hi, size=(f, 16))
+    m = Qwen3TTSModel.from_pretrained(d, max_batch=4, max_frames=32, max_prompt=64)
+    try:
+        one_shot, _ = m.codec_decode(codes, n_frames=F)
+        for chunk in (4, 5):
+            streamed = m.codec_decode_streamed(codes, chunk, -1, n_frames=F)
+            for b, f in enumerate(F):
+                assert (streamed[b, : f * 1920] == one_shot[b, : f * 1920]).all(), (chunk, b)
+        # a sliding window: against the oracle's windowed decode with the float16 tail, bar = the one-shot float16 bar
+        chunk, window, look = 4, 4, 2
+        got = m.codec_decode_streamed(codes, chunk, window, look, n_frames=F)
+        for b, f in enumerate(F):
+            want = om.codec_decode_streamed(codes[b, :f], chunk, window, look, f16=True)
+            ref32 = om.codec_decode_streamed(codes[b, :f], chunk, window, look)
+            err, floor = np.abs(got[b, : f * 1920] - want), np.abs(want - ref32)
+            print("row %d windowed: engine vs float16 oracle max %.2e rms %.2e | float16 vs fp32 oracle max %.2e rms %.2e"
+                  % (b, err.max(), np.sqrt((err ** 2).mean()), floor.max(), np.sqrt((floor ** 2).mean())))
+            assert err.max() <= 1.5 * floor.max() + 1e-3 and np.sqrt((err ** 2).mean()) <= 1.25 * np.sqrt((floor ** 2).mean()) + 1e-4
+            assert err.max() <= 2e-2 and np.sqrt((err ** 2).mean()) <= 4e-3
+        if width == "tiny":
+            # streamed generate: AUDIO_CHUNK events while the frame loop runs, exact mode (window < 0 is not a generate option; the
+            # default window) -- the chunks concatenate to what the call returns
+            r = tiny_request(row=1, n_text=7)
+            chunks = []
+            res = m.generate_batch([GenerationRequest(r["text_ids"], r["target_token_count"], None, "aiden", "english")], temperature=0.9,
+                                   top_k=40, seed=6, force_frames=12, audio_chunk_frames=4, audio_window_frames=8,
+                                   on_event=lambda i, kind, payload: chunks.append(payload) if kind == "audio_chunk" else None)[0]
+            assert res.status == 0 and chunks
+            cat = np.concatenate([c[1] for c in sorted(chunks, key=lambda c: c[0])])
+            assert cat.shape == res.audio.shape and (cat == res.audio).all()
+    finally:
+        m.close()
