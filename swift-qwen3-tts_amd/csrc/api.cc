@@ -128,7 +128,10 @@ q3tts_status q3tts_model_load(const char* model_dir, const q3tts_load_opts* opts
     });
 }
 
-void q3tts_model_free(q3tts_model* m) { delete m; }
+void q3tts_model_free(q3tts_model* m) {
+    if (g_refused == m) g_refused = nullptr;  // (a later handle may be allocated at the same address)
+    delete m;
+}
 
 const char* q3tts_last_error(const q3tts_model* m) {
     if (m && g_refused == m) return kBusyMsg;
