@@ -308,6 +308,7 @@ def main():
     # K steps, all of their work inside the timed region. Back-to-back batches are pipelined two deep: step i+1's prompt
     # assembly, prefill and AR loop are issued while step i's codec decode runs on the engine's second stream; a step's
     # PCM is on the host when its generate_batch_end returns. --no-pipeline issues the steps strictly one after another.
+    iter_ms = []  # wall time of each pipelined iteration (a begin + the previous job's end): the steady state, reported beside `value`
     if args.no_pipeline:
         for _ in range(args.steps):
             account(step())
@@ -321,9 +322,11 @@ def main():
             return r
         job = timed("begin", model.generate_batch_begin, reqs, more_follows=(args.steps > 1), **gen_kw)
         for i in range(args.steps - 1):
+            t_it = time.perf_counter()
             nxt = timed("begin", model.generate_batch_begin, reqs, more_follows=(i + 2 < args.steps), **gen_kw)
             account(timed("end", model.generate_batch_end, job))
             job = nxt
+            iter_ms.append(1e3 * (time.perf_counter() - t_it))
         account(timed("end", model.generate_batch_end, job))
     sync_all()
     elapsed = time.perf_counter() - t0
@@ -396,6 +399,10 @@ def main():
                                        "prefill / ar_decode of step i+1, so the phases add up to more than ms_per_step")
                               if pipelined else "phases run back to back on one batch"},
         "phase_ms_alone": solo,
+        # informational: the median pipelined iteration. `value` / `ms_per_step` above are the contract's K steps as a whole, which
+        # also hold the pipeline's fill (a first step nothing overlaps) and drain (the last batch's decode, alone)
+        "steady_state": ({"ms_per_step": sorted(iter_ms)[len(iter_ms) // 2],
+                          "frames_per_s": world * B * args.frames / (sorted(iter_ms)[len(iter_ms) // 2] / 1e3)} if len(iter_ms) >= 3 else None),
         "roofline": {"bound": "hbm", "kernel": "frame_step (hipGraph: talker step + 16 code-predictor passes + samplers)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src,
