@@ -409,3 +409,27 @@ def test_decoder_rvq_dequantisation_matches_hf_mimi(base):
     with torch.no_grad():
         ref = first.decode(ct[:, :nsem]) + rest.decode(ct[:, nsem:])       # [1][C][F]
     assert close(stages["quantizer"], t2n(ref[0]).T, 1e-5)
+
+
+def test_text_projection_matches_hf_resize_mlp(tiny_a):
+    """ResizeMLP (Talker.swift:475-487) = transformers' Qwen3OmniMoeTalkerResizeMLP: fc2(silu(fc1(x))) with both biases. The HF
+    module is built on a stand-in config (three sizes and the activation are all it reads) and takes the checkpoint's
+    `talker.text_projection.*` tensors by name."""
+    import types
+    from transformers.models.qwen3_omni_moe import modeling_qwen3_omni_moe as M
+    from oracle import oracle as O
+    d, om = tiny_a
+    w1 = om.w["talker.text_projection.linear_fc1.weight"]
+    w2 = om.w["talker.text_projection.linear_fc2.weight"]
+    cfg = types.SimpleNamespace(thinker_hidden_size=w1.shape[1],
+                                text_config=types.SimpleNamespace(intermediate_size=w1.shape[0], hidden_size=w2.shape[0], hidden_act="silu"))
+    hf = M.Qwen3OmniMoeTalkerResizeMLP(cfg).float().eval()
+    sd = {k[len("talker.text_projection."):]: torch.from_numpy(O.bf16_to_f32(v)) for k, v in om.w.items()
+          if k.startswith("talker.text_projection.")}
+    hf.load_state_dict(sd, strict=True)
+    x = O.f32_to_bf16(np.random.default_rng(29).standard_normal((7, w1.shape[1])).astype(np.float32))
+    with torch.no_grad():
+        ref = t2n(hf(torch.from_numpy(O.bf16_to_f32(x))))
+    got = O.bf16_to_f32(om.text_projection(x))
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 0.03 * max(1.0, float(np.abs(ref).max()))   # bf16 storage after each of the three ops
