@@ -563,3 +563,65 @@ def test_a_second_thread_is_refused_while_a_call_is_running(engines):
     for g in got:
         assert (g.codes == want.codes).all() and (g.audio == want.audio).all()
     assert m.arena_checksum() == m.arena_checksum()      # and the handle is free again
+
+
+def test_a_row_whose_first_token_is_eos_fails_alone_and_limits_are_errors(tmp_path, engines):
+    """Edges of the driver loop. (1) EOS as the very first token: the reference throws "Generation failed: No tokens generated"
+    (Qwen3.swift:939-941); in a batch that is the ROW's status, the other rows are delivered -- made to happen by writing the
+    same checkpoint with codec_eos_token_id set to the token row 0 draws first. (2) A prompt one token beyond max_prompt,
+    a batch one row beyond max_batch and max_tokens beyond max_frames are 'Invalid input', and the engine decodes normally
+    afterwards."""
+    import json
+    from qwen3tts import GenerationRequest, Qwen3TTSError, Qwen3TTSModel, synth
+    m = engines["tiny-a"]
+    rows = [greq(row=i, n_text=6 + i) for i in range(4)]
+    draw = dict(temperature=0.9, top_k=50, seed=2)
+    base = m.generate_batch(rows, force_frames=3, **draw)   # sampled: the rows' streams differ, so do their first tokens
+    first = [int(r.codes[0, 0]) for r in base]
+    victim = 0
+    others = [i for i in range(4) if first[i] != first[victim]]
+    assert others, first
+    d, d0 = str(tmp_path / "eos_first"), str(tmp_path / "plain")
+    synth.write_checkpoint(d, "tiny-a", seed=1234)
+    synth.write_checkpoint(d0, "tiny-a", seed=1234)
+    cfg_path = os.path.join(d, "config.json")
+    cfg = json.load(open(cfg_path))
+    cfg["talker_config"]["codec_eos_token_id"] = first[victim]
+    json.dump(cfg, open(cfg_path, "w"))
+    e = Qwen3TTSModel.from_pretrained(d, max_batch=4, max_frames=96, max_prompt=64)   # (free-running rows: up to max(75, 6 n) frames)
+    try:
+        kinds = {i: [] for i in range(4)}
+        res = e.generate_batch(rows, on_event=lambda i, k, p: kinds[i].append(k), **draw)
+        assert res[victim].status == 2 and res[victim].audio.size == 0 and res[victim].codes.shape == (0, 16)
+        assert res[victim].info.generation_token_count == 0
+        assert "token" not in kinds[victim] and "audio" not in kinds[victim]      # nothing to report for that row (Qwen3.swift:868-871)
+        for i in others:
+            assert res[i].status == 0 and res[i].codes.shape[0] >= 1 and res[i].audio.size > 0
+            assert int(res[i].codes[0, 0]) == first[i]
+            assert kinds[i][-2:] == ["info", "audio"]
+        with pytest.raises(Qwen3TTSError) as err:                                  # the single-utterance call: the reference's throw
+            e.generate(text_ids=rows[victim].text_ids, target_token_count=rows[victim].target_token_count, speaker="aiden",
+                       language="english", **draw)
+        assert err.value.status == 2 and "Generation failed: No tokens generated" in str(err.value)
+        assert b"Generation failed: No tokens generated" in e._lib.q3tts_last_error(e._h)   # and the library's own message
+    finally:
+        e.close()
+    # (2) limits
+    small = Qwen3TTSModel.from_pretrained(d0, max_batch=2, max_frames=8, max_prompt=32)
+    try:
+        ok = greq(row=0, n_text=8)
+        fine = small.generate_batch([ok], temperature=0.0, force_frames=2)[0]
+        assert fine.status == 0
+        with pytest.raises(Qwen3TTSError) as err:
+            small.generate_batch([greq(row=0, n_text=40)], temperature=0.0, force_frames=2)
+        assert err.value.status == 3 and ("max_prompt" in str(err.value) or "too long" in str(err.value))
+        with pytest.raises(Qwen3TTSError) as err:
+            small.generate_batch([ok, ok, ok], temperature=0.0, force_frames=2)
+        assert err.value.status == 3 and "max_batch" in str(err.value)
+        with pytest.raises(Qwen3TTSError) as err:
+            small.generate_batch([ok], temperature=0.0, force_frames=9)
+        assert err.value.status == 3 and "max_frames" in str(err.value)
+        again = small.generate_batch([ok], temperature=0.0, force_frames=2)[0]
+        assert (again.codes == fine.codes).all() and (again.audio == fine.audio).all()
+    finally:
+        small.close()
