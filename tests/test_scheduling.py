@@ -142,3 +142,35 @@ def test_pipelined_jobs_equal_sequential_calls(ckpt_dirs):
         m.close()
     for a, a0, c, c0 in keep:
         assert (a == a0).all() and (c == c0).all()
+
+
+def test_a_failed_begin_leaves_the_outstanding_job_and_both_slots_intact(ckpt_dirs):
+    """q3tts_generate_begin that fails -- an unknown speaker (caught while the requests are resolved), a prompt beyond max_prompt
+    (caught while the prompts are assembled, after the voice front end would have run) -- must not leak its job slot or disturb
+    the job already in flight: that job ends with the undisturbed result, and two further jobs can be begun afterwards."""
+    from qwen3tts import GenerationRequest, Qwen3TTSError, Qwen3TTSModel
+    m = Qwen3TTSModel.from_pretrained(ckpt_dirs["tiny-b"], max_batch=4, max_frames=48, max_prompt=64)
+    try:
+        a = [_req(row=i, n_text=5 + i) for i in range(3)]
+        b = [_req(row=7 + i, n_text=6 + i) for i in range(2)]
+        kw = dict(temperature=0.9, top_k=40, seed=9, force_frames=10)
+        want_a, want_b = m.generate_batch(a, **kw), m.generate_batch(b, **kw)
+        ja = m.generate_batch_begin(a, **kw)
+        bad_speaker = _req(row=1, n_text=5)
+        bad_speaker.speaker = "nobody"
+        too_long = _req(row=2, n_text=80)
+        for bad in ([bad_speaker], [a[0], too_long]):
+            with pytest.raises(Qwen3TTSError) as e:
+                m.generate_batch_begin(bad, **kw)
+            assert e.value.status == 3
+        ra = m.generate_batch_end(ja)
+        for x, y in zip(ra, want_a):
+            assert x.status == 0 and (x.codes == y.codes).all() and (x.audio == y.audio).all()
+        j1 = m.generate_batch_begin(b, **kw)           # both slots are free again
+        j2 = m.generate_batch_begin(a, more_follows=False, **kw)
+        r1, r2 = m.generate_batch_end(j1), m.generate_batch_end(j2)
+        for got, exp in ((r1, want_b), (r2, want_a)):
+            for x, y in zip(got, exp):
+                assert x.status == 0 and (x.codes == y.codes).all() and (x.audio == y.audio).all()
+    finally:
+        m.close()
