@@ -174,3 +174,14 @@ def test_a_failed_begin_leaves_the_outstanding_job_and_both_slots_intact(ckpt_di
                 assert x.status == 0 and (x.codes == y.codes).all() and (x.audio == y.audio).all()
     finally:
         m.close()
+
+
+def test_model_freed_with_jobs_outstanding():
+    """q3tts_model_free with two begun jobs that were never ended (a host that gives up mid-queue): the streams are drained, the
+    staging thread is joined, nothing is leaked into the next model of the process -- which then generates what the first one
+    did. In a child process: the failure mode of this path is a crash or a hang, not an assertion."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "_free_outstanding_worker.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-1000:] + r.stderr[-3000:]
