@@ -1,5 +1,7 @@
 """Scheduling switches that only regroup work must leave results bit-identical: projected embedding tables vs run-time
 projection, a replica filled through the weight arena, rows per launch / row split / gate-up pairing."""
+import os
+
 import numpy as np
 import pytest
 
