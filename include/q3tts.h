@@ -129,7 +129,8 @@ typedef struct {
     int32_t max_tokens;   /* 0 = 2048 (reference default) */
     /* Voice clone -- generateVoiceClone(text:referenceAudio:referenceText:language:...) (Qwen3.swift:1009-1020).
      * ref_audio != NULL selects it; speaker / instruct_ids are then ignored, as in the reference.
-     *   ref_audio     = reference waveform, 24 kHz mono float32 (host memory, read during the call)
+     *   ref_audio     = reference waveform, 24 kHz mono float32 (host memory, read during the call; a NaN or infinite
+     *                   sample is Q3TTS_ERR_INVALID_INPUT)
      *   ref_text_ids  = tokens of "<|im_start|>assistant\n{referenceText}<|im_end|>\n" (:448-449)
      * The reference's default repetition penalty on this path is 1.5 (:1017): set it in q3tts_sampling.
      * Result: pcm = audio of the target text only (reference part cut proportionally, :1195-1199),
@@ -245,7 +246,8 @@ q3tts_status q3tts_generate_end(q3tts_model* m, q3tts_job* job, q3tts_result* re
 
 /* Qwen3TTSSpeechTokenizer.decode (Models/SpeechTokenizer.swift:823-836): codes
  * [batch][max_frames][num_code_groups] -> pcm [batch][max_frames*1920] (caller-allocated),
- * audio_lengths[batch] = count(code0 > 0) * 1920. n_frames[b] <= max_frames are the valid rows. */
+ * audio_lengths[batch] = count(code0 > 0) * 1920. n_frames[b] <= max_frames are the valid rows. Every code of a valid row is
+ * a row of its RVQ table: one outside it is Q3TTS_ERR_INVALID_INPUT (checked on the host before anything is uploaded). */
 q3tts_status q3tts_codec_decode(q3tts_model* m, const int32_t* codes, const int32_t* n_frames,
                                 int32_t batch, int32_t max_frames, float* pcm, int64_t* audio_lengths);
 
